@@ -1,0 +1,382 @@
+"""ORACLE (test infrastructure, not product code).
+
+CPU restatement, in numpy, of the reference's variational update loop for the
+linear-dynamical-system graph of examples/Linear_Dynamic_System.py:46-77
+(hstack A and C with Gaussian columns, Gamma-family or Wishart noise precisions,
+Gaussian states, observed Gaussian outputs).  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this file; nothing under pyvb_amd/ does.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function below
+against tests/golden/*.npz, which tests/golden/make_golden.py produced by running
+the reference's own node classes (a lib2to3-translated scratch copy, see that
+script) on the same inputs.
+
+The reference sends messages node by node; because the parameter posteriors are
+frozen while the states are swept, every X_t sees one of three posterior
+precisions (t = 0, interior, t = T-1) and all parameter updates reduce to five
+sums over t.  The functions below compute exactly those quantities, batched over
+N independent replicates (leading axis), in the reference's association order
+where that is cheap.  Each cites the reference lines it restates (paths relative
+to /root/reference/src/pyvb/).
+
+Reference quirks that are reproduced on purpose:
+  Q1  gaussian.py:120   q_ln_det = 0.5 / ln(prod(diag(chol(qprec))))  (a reciprocal)
+  Q2  nodes_todo.py:144-147,195-197; node.py:301-302   pass_down_lndet = ln det E[Lambda]
+State layout (all float64, N = replicates):
+  X        [N,T,D]   state means qmu_t
+  A_mean   [N,D,D]   E[A] as a matrix [row, col]; column i is Gaussian node As[i]
+  A_cov    [N,D,D,D] A_cov[n,i] = qcov of column i
+  C_mean   [N,K,D], C_cov [N,D,K,K]
+  Q_a,Q_b  [N,D] (diagonal_gamma) or [N] (gamma);  R_a,R_b likewise with K
+  Q_v,Q_w  Wishart: [N], [N,D,D]
+"""
+import numpy as np
+from scipy.special import digamma, gammaln
+
+LN2PI = np.log(2.0 * np.pi)
+
+
+# ----------------------------------------------------------------------------
+# noise-precision nodes
+# ----------------------------------------------------------------------------
+def noise_expect(kind, a, b, dim):
+    """E[Lambda] as a dense [N,dim,dim] matrix.
+    DiagonalGamma.pass_down_Ex nodes_todo.py:192-193; Gamma.pass_down_Ex :140-142;
+    Wishart.pass_down_Ex :233-234 (a = qv, b = qw)."""
+    if kind == "diagonal_gamma":
+        return np.einsum("nd,de->nde", a / b, np.eye(dim))
+    if kind == "gamma":
+        return (a / b)[:, None, None] * np.eye(dim)[None]
+    if kind == "wishart":
+        return a[:, None, None] * np.linalg.inv(b)
+    raise ValueError(kind)
+
+
+def noise_lndet(kind, a, b, dim):
+    """pass_down_lndet (quirk Q2: log det of the EXPECTED precision).
+    DiagonalGamma nodes_todo.py:195-197 (ln prod(qa/qb)); Gamma :144-147."""
+    if kind == "diagonal_gamma":
+        return np.sum(np.log(a / b), axis=-1)
+    if kind == "gamma":
+        return dim * (np.log(a) - np.log(b))
+    raise AttributeError("Wishart has no pass_down_lndet in the reference (SURVEY Q8)")
+
+
+def noise_a(kind, a0, n_children, dim):
+    """update_a: DiagonalGamma nodes_todo.py:183-186 (+0.5 per child);
+    Gamma :125-128 (+0.5*child.shape[0] per child); Wishart.update_v :224-227."""
+    if kind == "gamma":
+        return a0 + 0.5 * dim * n_children
+    return a0 + 0.5 * n_children
+
+
+def noise_llb(kind, a0, b0, a, b):
+    """log_lower_bound of a Gamma / DiagonalGamma node (nodes_todo.py:149-157, :199-204)."""
+    Elnx = digamma(a) - np.log(b)
+    ret = (a0 - 1) * Elnx - gammaln(a0) + a0 * np.log(b0) - b0 * (a / b)
+    ret = ret - ((a - 1) * Elnx - gammaln(a) + a * np.log(b) - b * (a / b))
+    if kind == "diagonal_gamma":
+        return ret.sum(axis=-1)
+    return ret
+
+
+# ----------------------------------------------------------------------------
+# expectations of the hstack matrices
+# ----------------------------------------------------------------------------
+def quad_expect(M, Mcov, Lam):
+    """<M^T Lam M> for an hstack M with independent Gaussian columns.
+    Multiplication.pass_up_m1_m2, requester = B, A is hstack: node.py:213-227
+    (the 4-D outer-product tensor and its trace against the child's m1)."""
+    m1 = np.einsum("nki,nkl,nlj->nij", M, Lam, M)
+    tr = np.einsum("nikl,nlk->ni", Mcov, Lam)
+    idx = np.arange(M.shape[2])
+    m1[:, idx, idx] += tr
+    return m1
+
+
+def outer_expect(M, Mcov, G):
+    """sum_t <(M x_t)(M x_t)^T> given G = sum_t <x_t x_t^T>.
+    Multiplication.pass_down_ExxT, hstack branch: node.py:260-271."""
+    out = np.einsum("nki,nij,nlj->nkl", M, G, M)
+    out += np.einsum("nikl,ni->nkl", Mcov, np.einsum("nii->ni", G))
+    return out
+
+
+def _chol_qld(P):
+    """cho_factor + the reference's q_ln_det (gaussian.py:118-120, quirk Q1)."""
+    L = np.linalg.cholesky(P)
+    s = np.sum(np.log(np.einsum("nii->ni", L)), axis=-1)
+    return 0.5 / s
+
+
+# ----------------------------------------------------------------------------
+# state sweeps  (Gaussian.update for X_t: gaussian.py:102-123)
+# ----------------------------------------------------------------------------
+def state_posteriors(st, pri):
+    """The three distinct posterior precisions / covariances of the X_t
+    (t = 0, interior, t = T-1) and their q_ln_det.
+    qprec = pprec + sum of child m1 (gaussian.py:117); children of X_t are
+    Mult(C,X_t) and, for t < T-1, Mult(A,X_t) (Linear_Dynamic_System.py:58-66)."""
+    kind = pri["noise"]
+    D = st["A_mean"].shape[1]
+    K = st["C_mean"].shape[1]
+    T = st["X"].shape[1]
+    Qb = noise_expect(kind, st["Q_a"], st["Q_b"], D)
+    Rb = noise_expect(kind, st["R_a"], st["R_b"], K)
+    MA = quad_expect(st["A_mean"], st["A_cov"], Qb)
+    MC = quad_expect(st["C_mean"], st["C_cov"], Rb)
+    L0 = np.broadcast_to(pri["x0_prec"], MA.shape)
+    P = np.stack([L0 + (MC + MA if T > 1 else MC), Qb + (MC + MA), Qb + MC], axis=1)
+    Sig = np.linalg.inv(P)
+    qld = np.stack([_chol_qld(P[:, c]) for c in range(3)], axis=1)
+    return {"Qbar": Qb, "Rbar": Rb, "P": P, "Sigma": Sig, "qld": qld}
+
+
+def _x_step(st, pri, post, Y, t, X):
+    """One Gaussian.update() of X_t in the reference's association order:
+    weighted = pprec.pmu + (m2 from Mult(C,.) + m2 from Mult(A,.))   gaussian.py:122
+    pmu = <A> qmu_{t-1} (node.py:235-242), m2_A = <A>^T (<Q> qmu_{t+1}) (node.py:204,
+    gaussian.py:179-183), m2_C = <C>^T (<R> y_t)."""
+    T = X.shape[1]
+    A, C = st["A_mean"], st["C_mean"]
+    Qb, Rb = post["Qbar"], post["Rbar"]
+    m2 = np.einsum("nki,nk->ni", C, np.einsum("nkl,nl->nk", Rb, Y[:, t]))
+    if t < T - 1:
+        m2 = m2 + np.einsum("nki,nk->ni", A, np.einsum("nkl,nl->nk", Qb, X[:, t + 1]))
+    if t == 0:
+        w = np.einsum("ij,j->i", pri["x0_prec"], pri["x0_mean"])[None] + m2
+        cls = 0
+    else:
+        pmu = np.einsum("nki,ni->nk", A, X[:, t - 1])
+        w = np.einsum("nkl,nl->nk", Qb, pmu) + m2
+        cls = 1 if t < T - 1 else 2
+    X[:, t] = np.einsum("nij,nj->ni", post["Sigma"][:, cls], w)
+
+
+def sweep(st, pri, Y, direction, post=None):
+    """Forward (t = 0..T-1) or backward (t = T-1..0) Gauss-Seidel sweep, in place
+    (Linear_Dynamic_System.py:70-73).  Returns the posterior-class record."""
+    post = post or state_posteriors(st, pri)
+    T = st["X"].shape[1]
+    order = range(T) if direction == "forward" else range(T - 1, -1, -1)
+    for t in order:
+        _x_step(st, pri, post, Y, t, st["X"])
+    st["Sigma"], st["qld_x"] = post["Sigma"], post["qld"]
+    return post
+
+
+def update_x(st, pri, Y, t, post=None):
+    """A single X_t.update()."""
+    post = post or state_posteriors(st, pri)
+    _x_step(st, pri, post, Y, t, st["X"])
+    st["Sigma"], st["qld_x"] = post["Sigma"], post["qld"]
+    return post
+
+
+# ----------------------------------------------------------------------------
+# sufficient statistics of the states
+# ----------------------------------------------------------------------------
+def statistics(st, Y):
+    """Sums over t of <x x^T> (pass_down_ExxT gaussian.py:162-168 = qmu qmu^T + qcov),
+    qmu_{t+1} qmu_t^T, y_t qmu_t^T and y_t y_t^T, which are all the hstack and
+    noise updates ever read (nodes_todo.py:43-62, :187-190)."""
+    X, Sig = st["X"], st["Sigma"]
+    T = X.shape[1]
+    XX = np.einsum("nti,ntj->nij", X, X)
+    x0 = np.einsum("ni,nj->nij", X[:, 0], X[:, 0])
+    xL = np.einsum("ni,nj->nij", X[:, -1], X[:, -1])
+    nint = max(T - 2, 0)
+    cov_all = Sig[:, 0] + nint * Sig[:, 1] + (Sig[:, 2] if T > 1 else 0.0)
+    S = {
+        "Sxx": XX + cov_all,
+        "Sxx_m": XX - xL + cov_all - Sig[:, 2],       # t = 0..T-2
+        "Sxx_p": XX - x0 + cov_all - Sig[:, 0],       # t = 1..T-1
+        "Sx1x": np.einsum("nti,ntj->nij", X[:, 1:], X[:, :-1]),
+        "Syx": np.einsum("ntk,ntj->nkj", Y, X),
+        "Syy": np.einsum("ntk,ntl->nkl", Y, Y),
+        "x0x0": x0 + Sig[:, 0],
+    }
+    return S
+
+
+# ----------------------------------------------------------------------------
+# hstack columns  (Gaussian.update for As[i] / Cs[i])
+# ----------------------------------------------------------------------------
+def _update_columns(M, Mcov, prior_mean, prior_prec, Lam, G, H):
+    """Gauss-Seidel over the columns i = 0..D-1 of an hstack.
+    hstack.pass_up_m1_m2 nodes_todo.py:43-62:
+      m1 = sum_t Lam <x x^T>[i,i]                          (:56)
+      m2 = sum_t (Lam mu_child) x[i] - sum_t sum_{j!=i} Lam <x x^T>[i,j] <m_j>   (:59-61)
+    then Gaussian.update gaussian.py:117-123 with the column's Constant parents.
+    G = sum <x x^T>, H = sum (child mean) x^T  ([rows, D]).  prior_prec[i] is the
+    diagonal of column i's prior precision."""
+    N, rows, D = M.shape
+    qld = np.empty((N, D))
+    LH = np.einsum("nkl,nli->nki", Lam, H)
+    for i in range(D):
+        prec = np.einsum("nkl,n->nkl", Lam, G[:, i, i]) + np.diag(prior_prec[i])[None]
+        Gi = G[:, i, :].copy()
+        Gi[:, i] = 0.0
+        m2 = LH[:, :, i] - np.einsum("nkl,nl->nk", Lam, np.einsum("nlj,nj->nl", M, Gi))
+        w = (prior_prec[i] * prior_mean[:, i])[None] + m2
+        cov = np.linalg.inv(prec)
+        Mcov[:, i] = cov
+        M[:, :, i] = np.einsum("nkl,nl->nk", cov, w)
+        qld[:, i] = _chol_qld(prec)
+    return qld
+
+
+def update_A(st, pri, S):
+    """[a.update() for a in As]  (Linear_Dynamic_System.py:74).  Children of the
+    hstack A are Mult(A, X_t), t = 0..T-2, whose own children X_{t+1} send
+    (<Q>, <Q> qmu_{t+1})."""
+    Qb = noise_expect(pri["noise"], st["Q_a"], st["Q_b"], st["A_mean"].shape[1])
+    st["qld_A"] = _update_columns(st["A_mean"], st["A_cov"], pri["A_prior_mean"],
+                                  pri["A_prior_prec"], Qb, S["Sxx_m"], S["Sx1x"])
+
+
+def update_C(st, pri, S):
+    """[c.update() for c in Cs]  (:75).  Children Mult(C, X_t), t = 0..T-1; the
+    observed Y_t send (<R>, <R> y_t)."""
+    Rb = noise_expect(pri["noise"], st["R_a"], st["R_b"], st["C_mean"].shape[1])
+    st["qld_C"] = _update_columns(st["C_mean"], st["C_cov"], pri["C_prior_mean"],
+                                  pri["C_prior_prec"], Rb, S["Sxx"], S["Syx"])
+
+
+# ----------------------------------------------------------------------------
+# noise precisions
+# ----------------------------------------------------------------------------
+def _residual_second_moment(own, M, Mcov, G, H):
+    """sum over children of <x x^T> + <mu mu^T> - 2 sym(<x><mu>^T) restricted to what
+    the callers need; returns the full [rows,rows] matrix
+    own + E(M,Mcov,G) - H M^T - M H^T  (callers take diag / trace, for which the
+    last two terms coincide)."""
+    HM = np.einsum("nkj,nlj->nkl", H, M)
+    return own + outer_expect(M, Mcov, G), HM
+
+
+def update_Q(st, pri, S, T):
+    """Q.update(): DiagonalGamma nodes_todo.py:187-190, Gamma :130-138, Wishart :228-231.
+    Children X_t, t = 1..T-1, mean parent Mult(A, X_{t-1})."""
+    kind = pri["noise"]
+    D = st["A_mean"].shape[1]
+    E, HM = _residual_second_moment(S["Sxx_p"], st["A_mean"], st["A_cov"], S["Sxx_m"], S["Sx1x"])
+    if kind == "diagonal_gamma":
+        st["Q_b"] = pri["Q_b0"][None] + 0.5 * np.einsum("nii->ni", E) - np.einsum("nii->ni", HM)
+    elif kind == "gamma":
+        st["Q_b"] = pri["Q_b0"] + 0.5 * np.einsum("nii->n", E) - np.einsum("nii->n", HM)
+    else:
+        st["Q_b"] = pri["Q_b0"][None] + 0.5 * E - HM
+    st["Q_a"] = _bcast_a(noise_a(kind, pri["Q_a0"], T - 1, D), st["Q_b"], kind)
+
+
+def update_R(st, pri, S, T):
+    """R.update(); children Y_t, t = 0..T-1 (observed: <y y^T> = y y^T), mean parent Mult(C, X_t)."""
+    kind = pri["noise"]
+    K = st["C_mean"].shape[1]
+    E, HM = _residual_second_moment(S["Syy"], st["C_mean"], st["C_cov"], S["Sxx"], S["Syx"])
+    if kind == "diagonal_gamma":
+        st["R_b"] = pri["R_b0"][None] + 0.5 * np.einsum("nii->ni", E) - np.einsum("nii->ni", HM)
+    elif kind == "gamma":
+        st["R_b"] = pri["R_b0"] + 0.5 * np.einsum("nii->n", E) - np.einsum("nii->n", HM)
+    else:
+        st["R_b"] = pri["R_b0"][None] + 0.5 * E - HM
+    st["R_a"] = _bcast_a(noise_a(kind, pri["R_a0"], T, K), st["R_b"], kind)
+
+
+def _bcast_a(a, b, kind):
+    if kind == "wishart":
+        return np.broadcast_to(np.asarray(a, dtype=float), b.shape[:1]).copy()
+    return np.broadcast_to(np.asarray(a, dtype=float), b.shape).copy()
+
+
+def init_noise_a(st, pri, T):
+    """qa is fixed by the graph (update_a at construction / addChild)."""
+    D = st["A_mean"].shape[1]
+    K = st["C_mean"].shape[1]
+    kind = pri["noise"]
+    st["Q_a"] = _bcast_a(noise_a(kind, pri["Q_a0"], T - 1, D), st["Q_b"], kind)
+    st["R_a"] = _bcast_a(noise_a(kind, pri["R_a0"], T, K), st["R_b"], kind)
+
+
+# ----------------------------------------------------------------------------
+# evidence lower bound (reference mode)
+# ----------------------------------------------------------------------------
+def elbo_parts(st, pri, S, T):
+    """[L_X, L_Y, L_A, L_C, L_Q, L_R] per replicate = sums of log_lower_bound()
+    over the node classes (Network.learn network.py:49).
+    Gaussian.log_lower_bound gaussian.py:136-151 (with q_ln_det of quirk Q1 for the
+    unobserved nodes and nothing subtracted for the observed Y_t);
+    Gamma-family nodes_todo.py:149-157, :199-204."""
+    kind = pri["noise"]
+    N, D = st["A_mean"].shape[:2]
+    K = st["C_mean"].shape[1]
+    Qb = noise_expect(kind, st["Q_a"], st["Q_b"], D)
+    Rb = noise_expect(kind, st["R_a"], st["R_b"], K)
+    lndQ = noise_lndet(kind, st["Q_a"], st["Q_b"], D)
+    lndR = noise_lndet(kind, st["R_a"], st["R_b"], K)
+    qld = st["qld_x"]
+    nint = max(T - 2, 0)
+    # X_0: Constant parents (mean m0, precision L0; Constant.lndet node.py:301-302)
+    L0, m0 = pri["x0_prec"], pri["x0_mean"]
+    lnd0 = np.log(np.linalg.det(L0))
+    ex0 = S["x0x0"] + np.outer(m0, m0)[None] - 2 * np.einsum("ni,j->nij", st["X"][:, 0], m0)
+    LX = -0.5 * D * LN2PI + 0.5 * lnd0 - 0.5 * np.einsum("ij,nji->n", L0, ex0)
+    # X_t, t >= 1
+    E, HM = _residual_second_moment(S["Sxx_p"], st["A_mean"], st["A_cov"], S["Sxx_m"], S["Sx1x"])
+    LX = LX + (T - 1) * (-0.5 * D * LN2PI + 0.5 * lndQ) - 0.5 * np.einsum("nij,nji->n", Qb, E - 2 * HM)
+    ent = 0.5 * D * LN2PI + 0.5 * D
+    LX = LX + T * ent + 0.5 * (qld[:, 0] + nint * qld[:, 1] + (qld[:, 2] if T > 1 else 0.0))
+    # Y_t observed
+    E, HM = _residual_second_moment(S["Syy"], st["C_mean"], st["C_cov"], S["Sxx"], S["Syx"])
+    LY = T * (-0.5 * K * LN2PI + 0.5 * lndR) - 0.5 * np.einsum("nij,nji->n", Rb, E - 2 * HM)
+
+    def cols(M, Mcov, pm, pp, qldc, rows):
+        # column i: Constant mean pm[:,i], Constant precision diag(pp[i])
+        tot = np.zeros(N)
+        for i in range(D):
+            ex = np.einsum("nk,nl->nkl", M[:, :, i], M[:, :, i]) + Mcov[:, i] \
+                + np.outer(pm[:, i], pm[:, i])[None] - 2 * np.einsum("nk,l->nkl", M[:, :, i], pm[:, i])
+            tot += -0.5 * rows * LN2PI + 0.5 * np.log(np.linalg.det(np.diag(pp[i]))) \
+                - 0.5 * np.einsum("k,nkk->n", pp[i], ex)
+            tot += 0.5 * rows * LN2PI + 0.5 * qldc[:, i] + 0.5 * rows
+        return tot
+
+    LA = cols(st["A_mean"], st["A_cov"], pri["A_prior_mean"], pri["A_prior_prec"], st["qld_A"], D)
+    LC = cols(st["C_mean"], st["C_cov"], pri["C_prior_mean"], pri["C_prior_prec"], st["qld_C"], K)
+    LQ = noise_llb(kind, pri["Q_a0"], pri["Q_b0"], st["Q_a"], st["Q_b"])
+    LR = noise_llb(kind, pri["R_a0"], pri["R_b0"], st["R_a"], st["R_b"])
+    return np.stack([LX, LY, LA, LC, LQ, LR], axis=1)
+
+
+# ----------------------------------------------------------------------------
+# the driver loop
+# ----------------------------------------------------------------------------
+def expand_state(st0, pri, T):
+    """Turn the compact initial state of pyvb_amd.synth.initial_state (diagonal
+    column variances) into this module's dense layout; copies everything."""
+    st = {"X": st0["X"].copy(), "A_mean": st0["A_mean"].copy(), "C_mean": st0["C_mean"].copy(),
+          "Q_b": st0["Q_b"].copy(), "R_b": st0["R_b"].copy()}
+    st["A_cov"] = np.einsum("nik,kl->nikl", st0["A_colvar"], np.eye(st0["A_colvar"].shape[2]))
+    st["C_cov"] = np.einsum("nik,kl->nikl", st0["C_colvar"], np.eye(st0["C_colvar"].shape[2]))
+    if pri["noise"] == "gamma":
+        st["Q_b"] = st["Q_b"][:, 0].copy()
+        st["R_b"] = st["R_b"][:, 0].copy()
+    init_noise_a(st, pri, T)
+    return st
+
+
+def iterate(st, pri, Y, with_elbo=True):
+    """One pass of the example's loop body (Linear_Dynamic_System.py:69-77) followed by
+    the lower bound (network.py:49): forward sweep, backward sweep, A columns,
+    C columns, Q, R, ELBO."""
+    T = st["X"].shape[1]
+    post = state_posteriors(st, pri)
+    sweep(st, pri, Y, "forward", post)
+    sweep(st, pri, Y, "backward", post)
+    S = statistics(st, Y)
+    update_A(st, pri, S)
+    update_C(st, pri, S)
+    update_Q(st, pri, S, T)
+    update_R(st, pri, S, T)
+    return elbo_parts(st, pri, S, T) if with_elbo else None

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures tests/golden/lds_*.npz by running the REFERENCE.
+
+Runs only in the build container, where /root/reference exists.  The reference is
+Python 2 (implicit relative imports, print statements), so it is run from a
+scratch copy under /tmp translated by the standard library's lib2to3 -- a purely
+syntactic translation.  The copy never enters this repository;
+what is committed is this script and the .npz inputs/outputs it writes.
+
+For every case the script builds the graph of examples/Linear_Dynamic_System.py:46-66
+out of the reference's own node classes, overwrites the randomly drawn initial
+posteriors with an explicit seeded state, runs the example's loop
+body (:69-77) and records states, the three posterior-covariance classes of the
+X_t, q_ln_det values, parameter posteriors and the per-class lower bound.
+
+    python tests/golden/make_golden.py            # all cases
+    python tests/golden/make_golden.py small      # skip the slow D=64 case
+"""
+import os
+import shutil
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+SCRATCH = "/tmp/pyvb_oracle"
+REF_SRC = "/root/reference/src/pyvb"
+
+
+def load_reference():
+    if not os.path.isdir(REF_SRC):
+        raise SystemExit("reference tree not present; fixtures can only be regenerated in the build container")
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    sys.dont_write_bytecode = True
+    if not os.path.isdir(os.path.join(SCRATCH, "pyvb_ref")):
+        os.makedirs(SCRATCH, exist_ok=True)
+        dst = os.path.join(SCRATCH, "pyvb_ref")
+        shutil.copytree(REF_SRC, dst)
+        subprocess.check_call(["chmod", "-R", "u+w", SCRATCH])
+        os.remove(os.path.join(dst, "nodes", "discrete.py"))      # dead stub with a syntax error
+        files = [os.path.join(dst, "__init__.py"), os.path.join(dst, "network.py")]
+        files += [os.path.join(dst, "nodes", f) for f in os.listdir(os.path.join(dst, "nodes")) if f.endswith(".py")]
+        subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n"] + files,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, SCRATCH)
+    import pyvb_ref  # noqa
+    return pyvb_ref
+
+
+def build_graph(nodes, Y, pri, st0):
+    """Graph of Linear_Dynamic_System.py:46-66 with explicit initial posteriors."""
+    T, K = Y.shape
+    D = st0["A_mean"].shape[1]
+    kind = pri["noise"]
+    As = [nodes.Gaussian(D, pri["A_prior_mean"][:, [i]].copy(), np.diag(pri["A_prior_prec"][i])) for i in range(D)]
+    A = nodes.hstack(As)
+    Cs = [nodes.Gaussian(K, pri["C_prior_mean"][:, [i]].copy(), np.diag(pri["C_prior_prec"][i])) for i in range(D)]
+    C = nodes.hstack(Cs)
+    if kind == "diagonal_gamma":
+        Q = nodes.DiagonalGamma(D, pri["Q_a0"].copy(), pri["Q_b0"].copy())
+        R = nodes.DiagonalGamma(K, pri["R_a0"].copy(), pri["R_b0"].copy())
+    elif kind == "gamma":
+        Q = nodes.Gamma(D, float(pri["Q_a0"]), float(pri["Q_b0"]))
+        R = nodes.Gamma(K, float(pri["R_a0"]), float(pri["R_b0"]))
+    else:
+        Q = nodes.Wishart(D, float(pri["Q_a0"]), pri["Q_b0"].copy())
+        R = nodes.Wishart(K, float(pri["R_a0"]), pri["R_b0"].copy())
+    X0 = nodes.Gaussian(D, pri["x0_mean"].reshape(D, 1).copy(), pri["x0_prec"].copy())
+    Y0 = nodes.Gaussian(K, C * X0, R)
+    Y0.observe(Y[0].reshape(K, 1).copy())
+    Xs, Ys = [X0], [Y0]
+    for t in range(1, T):
+        Xs.append(nodes.Gaussian(D, A * Xs[-1], Q))
+        Ys.append(nodes.Gaussian(K, C * Xs[-1], R))
+        Ys[-1].observe(Y[t].reshape(K, 1).copy())
+    # explicit initial state
+    for t, x in enumerate(Xs):
+        x.qmu = st0["X"][0, t].reshape(D, 1).copy()
+    for i in range(D):
+        As[i].qmu = st0["A_mean"][0, :, [i]].reshape(D, 1).copy()
+        As[i].qcov = np.diag(st0["A_colvar"][0, i])
+        As[i].qprec = np.linalg.inv(As[i].qcov)
+        Cs[i].qmu = st0["C_mean"][0, :, [i]].reshape(K, 1).copy()
+        Cs[i].qcov = np.diag(st0["C_colvar"][0, i])
+        Cs[i].qprec = np.linalg.inv(Cs[i].qcov)
+    if kind == "diagonal_gamma":
+        Q.qb = st0["Q_b"][0].copy()
+        R.qb = st0["R_b"][0].copy()
+    elif kind == "gamma":
+        Q.qb = float(st0["Q_b"][0, 0])
+        R.qb = float(st0["R_b"][0, 0])
+    else:
+        Q.qw = np.diag(st0["Q_b"][0])
+        R.qw = np.diag(st0["R_b"][0])
+    return dict(As=As, Cs=Cs, A=A, C=C, Q=Q, R=R, Xs=Xs, Ys=Ys)
+
+
+def snapshot(g, out, tag, kind, with_elbo=True, dense_cov=False):
+    Xs, As, Cs, Q, R = g["Xs"], g["As"], g["Cs"], g["Q"], g["R"]
+    T = len(Xs)
+    out[tag + "X"] = np.hstack([x.qmu for x in Xs]).T.copy()
+    cls = [0, 1 if T > 2 else 0, T - 1]
+    out[tag + "Sigma"] = np.stack([Xs[t].qcov for t in cls])
+    out[tag + "qld_x"] = np.array([Xs[t].q_ln_det for t in cls])
+    if T > 3:  # the structural fact everything rests on: all interior covariances coincide
+        out[tag + "interior_cov_spread"] = np.max([np.abs(Xs[t].qcov - Xs[1].qcov).max() for t in range(2, T - 1)])
+        out[tag + "interior_qld_spread"] = np.max([abs(Xs[t].q_ln_det - Xs[1].q_ln_det) for t in range(2, T - 1)])
+    out[tag + "A_mean"] = np.hstack([a.qmu for a in As])
+    out[tag + "C_mean"] = np.hstack([c.qmu for c in Cs])
+    for nm, cols in (("A", As), ("C", Cs)):
+        cov = np.stack([c.qcov for c in cols])
+        if dense_cov:
+            out[tag + nm + "_cov"] = cov
+        else:
+            out[tag + nm + "_colvar"] = np.stack([np.diag(c) for c in cov])
+            out[tag + nm + "_cov_offdiag_max"] = np.max([np.abs(c - np.diag(np.diag(c))).max() for c in cov])
+        out[tag + "qld_" + nm] = np.array([c.q_ln_det for c in cols])
+    if kind == "wishart":
+        out[tag + "Q_a"], out[tag + "Q_b"] = np.float64(Q.qv), np.array(Q.qw)
+        out[tag + "R_a"], out[tag + "R_b"] = np.float64(R.qv), np.array(R.qw)
+    else:
+        out[tag + "Q_a"], out[tag + "Q_b"] = np.array(Q.qa, dtype=float), np.array(Q.qb, dtype=float)
+        out[tag + "R_a"], out[tag + "R_b"] = np.array(R.qa, dtype=float), np.array(R.qb, dtype=float)
+    if with_elbo:
+        parts = [np.sum([float(n.log_lower_bound()) for n in grp]) for grp in (Xs, g["Ys"], As, Cs)]
+        parts += [float(Q.log_lower_bound()), float(R.log_lower_bound())]
+        out[tag + "elbo_parts"] = np.array(parts)
+
+
+def run_case(ref, name, T, D, K, kind, iters, seed, dense_cov=False):
+    from pyvb_amd import synth
+    Y, st0, pri = synth.make_problem(T, D, K, 1, seed)
+    pri["noise"] = kind
+    if kind == "gamma":
+        for k in ("Q_a0", "Q_b0", "R_a0", "R_b0"):
+            pri[k] = np.float64(1e-3)
+    elif kind == "wishart":
+        pri["Q_a0"], pri["Q_b0"] = np.float64(1e-3), np.eye(D) * 1e-3
+        pri["R_a0"], pri["R_b0"] = np.float64(1e-3), np.eye(K) * 1e-3
+    out = {"T": T, "D": D, "K": K, "noise": kind, "Y": Y[0]}
+    for k, v in st0.items():
+        out["init_" + k] = v[0]
+    for k, v in pri.items():
+        if k != "noise":
+            out["prior_" + k] = v
+    g = build_graph(ref.nodes, Y[0], pri, st0)
+    Xs = g["Xs"]
+    for it in range(1, max(iters) + 1):
+        [x.update() for x in Xs]
+        if it == 1:
+            out["it1_fwd_X"] = np.hstack([x.qmu for x in Xs]).T.copy()
+        Xs.reverse()
+        [x.update() for x in Xs]
+        Xs.reverse()
+        [a.update() for a in g["As"]]
+        [c.update() for c in g["Cs"]]
+        g["Q"].update()
+        g["R"].update()
+        if it in iters:
+            snapshot(g, out, "it%d_" % it, kind, with_elbo=(kind != "wishart"), dense_cov=dense_cov)
+        print(name, "iteration", it, flush=True)
+    out["iters"] = np.array(sorted(iters))
+    path = os.path.join(HERE, "lds_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+CASES = [
+    # name, T, D, K, noise, checkpoints, seed, dense column covariances stored
+    ("example_d2k5_t200", 200, 2, 5, "diagonal_gamma", (1, 2, 5), 20240, True),
+    ("config1_d4k5_t200", 200, 4, 5, "diagonal_gamma", (1, 2, 5), 20241, True),
+    ("d8k8_t50", 50, 8, 8, "diagonal_gamma", (1, 3), 20242, False),
+    ("d16k16_t64", 64, 16, 16, "diagonal_gamma", (1, 2, 3), 20243, False),
+    ("d3k7_t3", 3, 3, 7, "diagonal_gamma", (1, 2), 20244, True),
+    ("d3k2_t2", 2, 3, 2, "diagonal_gamma", (1, 2), 20245, True),
+    ("gamma_d4k5_t60", 60, 4, 5, "gamma", (1, 3), 20246, True),
+    ("wishart_d3k4_t40", 40, 3, 4, "wishart", (1,), 20247, True),
+    ("d64k64_t4", 4, 64, 64, "diagonal_gamma", (1, 2), 20248, False),
+]
+
+
+if __name__ == "__main__":
+    warnings.simplefilter("ignore", DeprecationWarning)
+    ref = load_reference()
+    sel = sys.argv[1:]
+    for c in CASES:
+        if sel and sel != ["small"] and c[0] not in sel:
+            continue
+        if sel == ["small"] and c[2] >= 64:
+            continue
+        run_case(ref, *c)
