@@ -1,0 +1,128 @@
+/*
+ * pyvb_hip.h -- C ABI of libpyvb_hip.so: the MI355X (gfx950) implementation of pyvb's
+ * variational update loop for the linear-dynamical-system graph, batched over N
+ * independent replicates.
+ *
+ * The reference (jameshensman/pyvb) is pure Python and has no FFI layer; the boundary it
+ * exposes is the node/network Python API (the files under src/pyvb/nodes and src/pyvb/network.py).
+ * Each entry point below therefore names the reference METHODS whose work it performs for
+ * every node of one class at once.  pyvb_amd/ binds these symbols with ctypes
+ * (pyvb_amd/_capi.py) and re-exposes the node API on top of them; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, opaque handle, one handle per GPU, no global state besides the
+ *     thread-local error string; thread-compatible (one host thread per handle).
+ *   - every function returns 0 on success or a pyvb_status; pyvb_last_error() gives
+ *     the message of the last failure on the calling thread.
+ *   - all arrays are caller-owned HOST buffers of float64, C-contiguous, leading axis N
+ *     (replicate); a NULL array pointer means "skip this one".  Device memory is owned
+ *     by the handle.
+ *   - all work is queued on the handle's HIP stream; getters synchronise.
+ *
+ * Array shapes (D latent dim, K observed dim, T time steps, N replicates)
+ *   Y[N][T][K]  X[N][T][D]
+ *   A_mean[N][D][D]  (row, col)        A_colvar[N][D][D]  (column i, entry k): diagonal of
+ *   C_mean[N][K][D]  (row, col)        C_colvar[N][D][K]   the covariance of column i
+ *   Q_a,Q_b[N][D]   R_a,R_b[N][K]      (PYVB_NOISE_GAMMA: all entries of a row are equal)
+ *   Sigma[N][3][D][D], qld_x[N][3]     posterior covariance / q_ln_det of X_0, X_interior, X_{T-1}
+ *   elbo parts [N][6] = L_X, L_Y, L_A, L_C, L_Q, L_R
+ */
+#ifndef PYVB_HIP_H
+#define PYVB_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pyvb_lds pyvb_lds;
+
+typedef enum {
+    PYVB_OK = 0,
+    PYVB_E_ARG = 1,          /* bad argument (shape limits: 2 <= T, 1 <= D,K <= 64) */
+    PYVB_E_HIP = 2,          /* HIP runtime error */
+    PYVB_E_LINALG = 3,       /* a posterior precision was not positive definite (numpy LinAlgError in the reference) */
+    PYVB_E_STALE = 4,        /* statistics requested while the X_t were updated under different parameters */
+    PYVB_E_RCCL = 5,         /* RCCL error */
+    PYVB_E_UNSUPPORTED = 6
+} pyvb_status;
+
+enum { PYVB_NOISE_DIAGONAL_GAMMA = 0,   /* nodes_todo.py:159-204 DiagonalGamma */
+       PYVB_NOISE_GAMMA = 1 };          /* nodes_todo.py:88-157  Gamma (isotropic) */
+enum { PYVB_FORWARD = 0, PYVB_BACKWARD = 1 };
+
+/* which kernels pyvb_lds_timing_get() reports on */
+enum { PYVB_K_PREP = 0, PYVB_K_SWEEP = 1, PYVB_K_STATS = 2, PYVB_K_PARAMS = 3, PYVB_K_STEP = 4, PYVB_K_COUNT = 5 };
+
+const char* pyvb_last_error(void);
+int pyvb_version(void);
+int pyvb_device_count(int* count);
+
+/* Graph construction: Linear_Dynamic_System.py:46-66 for N replicates
+ * (2T Gaussian, 2 hstack of D Gaussian columns, 2 noise nodes per replicate). */
+int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int noise_kind);
+int pyvb_lds_destroy(pyvb_lds* h);
+
+/* Constant parents (node.py:279-311), shared by all replicates:
+ *   x0_mean[D], x0_prec[D][D]                     Gaussian(q, pmu, pprec) for X_0  (:58)
+ *   A_prior_mean[D][D] (row,col), A_prior_prec[D][D] (column i, diagonal entry k)   (:47)
+ *   C_prior_mean[K][D], C_prior_prec[D][K]                                          (:49)
+ *   Q_a0,Q_b0[D], R_a0,R_b0[K]                    DiagonalGamma / Gamma priors      (:51-54)
+ * Dense prior precisions for the columns are not supported (PYVB_E_UNSUPPORTED is the caller's check). */
+int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_prec,
+                        const double* A_prior_mean, const double* A_prior_prec,
+                        const double* C_prior_mean, const double* C_prior_prec,
+                        const double* Q_a0, const double* Q_b0, const double* R_a0, const double* R_b0);
+
+/* Gaussian.observe for every Y_t (gaussian.py:74-100, full observations only). */
+int pyvb_lds_set_observations(pyvb_lds* h, const double* Y);
+
+/* Explicit posterior state instead of the constructors' random initialisation
+ * (gaussian.py:70-72, nodes_todo.py:119,177). */
+int pyvb_lds_set_state(pyvb_lds* h, const double* X, const double* A_mean, const double* A_colvar,
+                       const double* C_mean, const double* C_colvar, const double* Q_b, const double* R_b);
+int pyvb_lds_get_state(pyvb_lds* h, double* X, double* A_mean, double* A_colvar, double* C_mean, double* C_colvar,
+                       double* Q_a, double* Q_b, double* R_a, double* R_b);
+/* qcov / q_ln_det of the X_t as of their last update (gaussian.py:119-120); qld of the columns. */
+int pyvb_lds_get_posterior_classes(pyvb_lds* h, double* Sigma, double* qld_x);
+int pyvb_lds_get_column_qld(pyvb_lds* h, double* qld_A, double* qld_C);
+
+/* [x.update() for x in Xs] in forward or reversed order (Linear_Dynamic_System.py:70-73):
+ * Gaussian.update gaussian.py:102-123 with Multiplication.pass_up_m1_m2 node.py:182-232 and
+ * pass_down_Ex :235-242 for all T nodes of all replicates in one launch. */
+int pyvb_lds_sweep(pyvb_lds* h, int direction);
+/* Xs[t].update() alone. */
+int pyvb_lds_update_x(pyvb_lds* h, int t);
+/* [a.update() for a in As] / Cs: Gaussian.update + hstack.pass_up_m1_m2 nodes_todo.py:43-62 */
+int pyvb_lds_update_A(pyvb_lds* h);
+int pyvb_lds_update_C(pyvb_lds* h);
+/* Q.update() / R.update(): nodes_todo.py:130-138, :187-190 with Multiplication.pass_down_ExxT node.py:244-276 */
+int pyvb_lds_update_Q(pyvb_lds* h);
+int pyvb_lds_update_R(pyvb_lds* h);
+/* sum of log_lower_bound() per node class (network.py:49; gaussian.py:136-151; nodes_todo.py:149-157,:199-204),
+ * reference mode (quirks Q1, Q2 of SURVEY.md reproduced). Leaves the parts on the device. */
+int pyvb_lds_elbo(pyvb_lds* h);
+int pyvb_lds_get_elbo(pyvb_lds* h, double* parts);
+/* parts summed over this handle's replicates, then over all ranks if a communicator is attached
+ * (one ncclAllReduce of 6 doubles). */
+int pyvb_lds_elbo_total(pyvb_lds* h, double out[6]);
+/* niters passes of: forward sweep, backward sweep, A, C, Q, R, ELBO (the example's loop body plus network.py:49). */
+int pyvb_lds_iterate(pyvb_lds* h, int niters);
+int pyvb_lds_sync(pyvb_lds* h);
+
+/* HIP-event timing of the kernels on the handle's stream (for bench.py's roofline figures). */
+int pyvb_lds_timing_enable(pyvb_lds* h, int on);
+int pyvb_lds_timing_reset(pyvb_lds* h);
+int pyvb_lds_timing_get(pyvb_lds* h, int kernel, double* total_ms, int* launches);
+/* device-side diagnostics: warm-up lengths chosen for the segmented sweeps [N][2] */
+int pyvb_lds_get_warmup(pyvb_lds* h, int* warm);
+
+/* Multi-GPU: replicates are sharded over ranks; the only exchange is the ELBO all-reduce. */
+int pyvb_comm_unique_id(char id[128]);
+int pyvb_lds_comm_init(pyvb_lds* h, const char id[128], int rank, int world);
+int pyvb_lds_comm_destroy(pyvb_lds* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

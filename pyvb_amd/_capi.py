@@ -1,0 +1,92 @@
+"""ctypes binding of libpyvb_hip.so (declared in include/pyvb_hip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load,
+importing this module raises, and so does every product path that needs it.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyvb_hip.so")
+
+OK, E_ARG, E_HIP, E_LINALG, E_STALE, E_RCCL, E_UNSUPPORTED = range(7)
+NOISE_DIAGONAL_GAMMA, NOISE_GAMMA = 0, 1
+FORWARD, BACKWARD = 0, 1
+K_PREP, K_SWEEP, K_STATS, K_PARAMS, K_STEP = range(5)
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_h = ctypes.c_void_p
+
+# name -> (restype, argtypes): every symbol include/pyvb_hip.h declares
+SIGNATURES = {
+    "pyvb_last_error": (ctypes.c_char_p, []),
+    "pyvb_version": (ctypes.c_int, []),
+    "pyvb_device_count": (ctypes.c_int, [_ip]),
+    "pyvb_lds_create": (ctypes.c_int, [ctypes.POINTER(_h)] + [ctypes.c_int] * 6),
+    "pyvb_lds_destroy": (ctypes.c_int, [_h]),
+    "pyvb_lds_set_priors": (ctypes.c_int, [_h] + [_dp] * 10),
+    "pyvb_lds_set_observations": (ctypes.c_int, [_h, _dp]),
+    "pyvb_lds_set_state": (ctypes.c_int, [_h] + [_dp] * 7),
+    "pyvb_lds_get_state": (ctypes.c_int, [_h] + [_dp] * 9),
+    "pyvb_lds_get_posterior_classes": (ctypes.c_int, [_h, _dp, _dp]),
+    "pyvb_lds_get_column_qld": (ctypes.c_int, [_h, _dp, _dp]),
+    "pyvb_lds_sweep": (ctypes.c_int, [_h, ctypes.c_int]),
+    "pyvb_lds_update_x": (ctypes.c_int, [_h, ctypes.c_int]),
+    "pyvb_lds_update_A": (ctypes.c_int, [_h]),
+    "pyvb_lds_update_C": (ctypes.c_int, [_h]),
+    "pyvb_lds_update_Q": (ctypes.c_int, [_h]),
+    "pyvb_lds_update_R": (ctypes.c_int, [_h]),
+    "pyvb_lds_elbo": (ctypes.c_int, [_h]),
+    "pyvb_lds_get_elbo": (ctypes.c_int, [_h, _dp]),
+    "pyvb_lds_elbo_total": (ctypes.c_int, [_h, _dp]),
+    "pyvb_lds_iterate": (ctypes.c_int, [_h, ctypes.c_int]),
+    "pyvb_lds_sync": (ctypes.c_int, [_h]),
+    "pyvb_lds_timing_enable": (ctypes.c_int, [_h, ctypes.c_int]),
+    "pyvb_lds_timing_reset": (ctypes.c_int, [_h]),
+    "pyvb_lds_timing_get": (ctypes.c_int, [_h, ctypes.c_int, _dp, _ip]),
+    "pyvb_lds_get_warmup": (ctypes.c_int, [_h, _ip]),
+    "pyvb_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "pyvb_lds_comm_init": (ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    "pyvb_lds_comm_destroy": (ctypes.c_int, [_h]),
+}
+
+
+class PyvbHipError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libpyvb_hip status %d: %s" % (code, message))
+        self.code = code
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `make -C pyvb_amd/csrc` (or __graft_entry__.build()); "
+            "pyvb_amd has no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+def check(rc):
+    if rc != OK:
+        msg = lib.pyvb_last_error().decode("utf-8", "replace")
+        if rc == E_LINALG:
+            raise np.linalg.LinAlgError(msg)
+        raise PyvbHipError(rc, msg)
+
+
+def dptr(a):
+    """numpy float64 C-contiguous array (or None) -> double*"""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)

@@ -1,0 +1,517 @@
+// Host side of libpyvb_hip.so: handle lifetime, host<->device copies, the dependency tracking that
+// decides which kernels a node-level call needs, timing, and the RCCL all-reduce of the lower bound.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <dlfcn.h>
+
+static thread_local char g_err[512] = "";
+
+void pyvb_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int pyvb_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    pyvb_set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return PYVB_E_HIP;
+}
+
+#define ARGCHK(cond, msg) do { if (!(cond)) { pyvb_set_error("%s", msg); return PYVB_E_ARG; } } while (0)
+
+extern "C" {
+
+const char* pyvb_last_error(void) { return g_err; }
+int pyvb_version(void) { return 100; }
+
+int pyvb_device_count(int* count) {
+    ARGCHK(count, "count is NULL");
+    HIPCHK(hipGetDeviceCount(count));
+    return PYVB_OK;
+}
+
+static int dev_alloc(double** p, size_t n) {
+    HIPCHK(hipMalloc((void**)p, n * sizeof(double)));
+    HIPCHK(hipMemset(*p, 0, n * sizeof(double)));
+    return PYVB_OK;
+}
+
+int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int noise_kind) {
+    ARGCHK(out, "out is NULL");
+    ARGCHK(N >= 1, "N must be >= 1");
+    ARGCHK(T >= 2, "T must be >= 2 (a chain needs X_0 and X_{T-1})");
+    ARGCHK(D >= 1 && D <= 64, "latent dimension D must be in 1..64");
+    ARGCHK(K >= 1 && K <= 64, "observed dimension K must be in 1..64");
+    ARGCHK(noise_kind == PYVB_NOISE_DIAGONAL_GAMMA || noise_kind == PYVB_NOISE_GAMMA, "unknown noise kind");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    ARGCHK(device >= 0 && device < ndev, "no such device");
+    HIPCHK(hipSetDevice(device));
+    pyvb_lds* h = new pyvb_lds();
+    memset(h, 0, sizeof(*h));
+    h->device = device; h->N = N; h->T = T; h->D = D; h->K = K; h->noise = noise_kind;
+    h->L = make_layout(D, K);
+    const Layout& L = h->L;
+    int rc = PYVB_OK;
+#define TRY(x) do { rc = (x); if (rc != PYVB_OK) { pyvb_lds_destroy(h); return rc; } } while (0)
+#define TRYHIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { rc = pyvb_hip_fail(_e, #x, __FILE__, __LINE__); pyvb_lds_destroy(h); return rc; } } while (0)
+    TRYHIP(hipStreamCreate(&h->stream));
+    TRYHIP(hipEventCreate(&h->ev0));
+    TRYHIP(hipEventCreate(&h->ev1));
+    const size_t n = (size_t)N;
+    TRY(dev_alloc(&h->Y, n * T * K));
+    TRY(dev_alloc(&h->Syy, n * K));
+    TRY(dev_alloc(&h->X[0], n * T * D));
+    TRY(dev_alloc(&h->X[1], n * T * D));
+    TRY(dev_alloc(&h->A_mean, n * D * D));
+    TRY(dev_alloc(&h->A_var, n * D * D));
+    TRY(dev_alloc(&h->C_mean, n * K * D));
+    TRY(dev_alloc(&h->C_var, n * D * K));
+    TRY(dev_alloc(&h->Q_a, n * D)); TRY(dev_alloc(&h->Q_b, n * D));
+    TRY(dev_alloc(&h->R_a, n * K)); TRY(dev_alloc(&h->R_b, n * K));
+    TRY(dev_alloc(&h->qld_A, n * D)); TRY(dev_alloc(&h->qld_C, n * D));
+    TRY(dev_alloc(&h->Sigma, n * 3 * D * D)); TRY(dev_alloc(&h->Sigma_new, n * 3 * D * D));
+    TRY(dev_alloc(&h->qld_x, n * 3)); TRY(dev_alloc(&h->qld_x_new, n * 3));
+    TRY(dev_alloc(&h->gains, n * L.gains_total));
+    TRY(dev_alloc(&h->scratch, n * 2 * D * D));
+    TRYHIP(hipMalloc((void**)&h->warm, n * 2 * sizeof(int)));
+    TRYHIP(hipMemset(h->warm, 0, n * 2 * sizeof(int)));
+    // time chunks of the statistics kernel: enough wavefronts to fill the chip when N is small
+    int nchunk = (1024 + N - 1) / N;
+    if (nchunk > 32) nchunk = 32;
+    if (nchunk > (T + 15) / 16) nchunk = (T + 15) / 16;
+    if (nchunk < 1) nchunk = 1;
+    int clen = (T + nchunk - 1) / nchunk;
+    clen = (clen + 3) & ~3;
+    nchunk = (T + clen - 1) / clen;
+    h->nchunk = nchunk; h->chunk_len = clen;
+    TRY(dev_alloc(&h->stats, n * nchunk * L.stats_total));
+    TRY(dev_alloc(&h->resQ, n * D)); TRY(dev_alloc(&h->resR, n * K));
+    TRY(dev_alloc(&h->elbo, n * 6)); TRY(dev_alloc(&h->elbo_sum, 8));
+    TRYHIP(hipMalloc((void**)&h->status, sizeof(int)));
+    TRYHIP(hipMemset(h->status, 0, sizeof(int)));
+    // priors block: x0_mean D, x0_prec D*D, A_pm D*D, A_pp D*D, C_pm K*D, C_pp D*K, Q_a0 D, Q_b0 D, R_a0 K, R_b0 K
+    size_t pn = (size_t)D + 3 * (size_t)D * D + 2 * (size_t)K * D + 2 * (size_t)D + 2 * (size_t)K;
+    TRY(dev_alloc(&h->pri_block, pn));
+    double* p = h->pri_block;
+    h->pri.x0_mean = p; p += D; h->pri.x0_prec = p; p += D * D;
+    h->pri.A_pm = p; p += D * D; h->pri.A_pp = p; p += D * D;
+    h->pri.C_pm = p; p += K * D; h->pri.C_pp = p; p += D * K;
+    h->pri.Q_a0 = p; p += D; h->pri.Q_b0 = p; p += D; h->pri.R_a0 = p; p += K; h->pri.R_b0 = p; p += K;
+    h->fresh = (unsigned char*)calloc(T, 1);
+    h->world = 1;
+    // q_ln_det is undefined until a node has been updated (the reference raises AttributeError)
+    {
+        std::vector<double> nanv(n * (size_t)(D > 3 ? D : 3), NAN);
+        TRYHIP(hipMemcpy(h->qld_x, nanv.data(), n * 3 * sizeof(double), hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy(h->qld_A, nanv.data(), n * D * sizeof(double), hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy(h->qld_C, nanv.data(), n * D * sizeof(double), hipMemcpyHostToDevice));
+    }
+#undef TRY
+#undef TRYHIP
+    *out = h;
+    return PYVB_OK;
+}
+
+int pyvb_lds_destroy(pyvb_lds* h) {
+    if (!h) return PYVB_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    pyvb_lds_comm_destroy(h);
+    double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
+                      h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
+                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block};
+    for (double* b : bufs) if (b) (void)hipFree(b);
+    if (h->warm) (void)hipFree(h->warm);
+    if (h->status) (void)hipFree(h->status);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    free(h->fresh);
+    delete h;
+    return PYVB_OK;
+}
+
+#define ENTER(h) do { ARGCHK(h, "handle is NULL"); HIPCHK(hipSetDevice((h)->device)); } while (0)
+
+static int h2d(pyvb_lds* h, double* dst, const double* src, size_t n) {
+    if (!src) return PYVB_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return PYVB_OK;
+}
+static int d2h(pyvb_lds* h, double* dst, const double* src, size_t n) {
+    if (!dst) return PYVB_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return PYVB_OK;
+}
+
+static void params_changed(pyvb_lds* h) {
+    if (h->gains_valid && h->fresh_count != 0 && h->fresh_count != h->T) h->mixed_cov = true;
+    h->gains_valid = false;
+}
+static void states_changed(pyvb_lds* h) { h->stats_valid = false; h->resQ_valid = false; h->resR_valid = false; }
+
+// ln det of a symmetric positive definite matrix (Constant.lndet, node.py:301-302)
+static int host_lndet(const double* Ain, int D, double* out) {
+    std::vector<double> A(Ain, Ain + (size_t)D * D);
+    double s = 0.0;
+    for (int j = 0; j < D; ++j) {
+        double piv = A[j * D + j];
+        for (int k = 0; k < j; ++k) piv -= A[j * D + k] * A[j * D + k];
+        if (!(piv > 0.0)) return PYVB_E_LINALG;
+        double d = sqrt(piv);
+        A[j * D + j] = d; s += log(d);
+        for (int i = j + 1; i < D; ++i) {
+            double v = A[i * D + j];
+            for (int k = 0; k < j; ++k) v -= A[i * D + k] * A[j * D + k];
+            A[i * D + j] = v / d;
+        }
+    }
+    *out = 2.0 * s;
+    return PYVB_OK;
+}
+
+int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_prec,
+                        const double* A_pm, const double* A_pp, const double* C_pm, const double* C_pp,
+                        const double* Q_a0, const double* Q_b0, const double* R_a0, const double* R_b0) {
+    ENTER(h);
+    ARGCHK(x0_mean && x0_prec && A_pm && A_pp && C_pm && C_pp && Q_a0 && Q_b0 && R_a0 && R_b0, "all prior arrays are required");
+    const int D = h->D, K = h->K, T = h->T, N = h->N;
+    for (int i = 0; i < D * D; ++i) ARGCHK(A_pp[i] > 0.0, "A_prior_prec must be positive");
+    for (int i = 0; i < D * K; ++i) ARGCHK(C_pp[i] > 0.0, "C_prior_prec must be positive");
+    if (host_lndet(x0_prec, D, &h->pri.x0_lndet) != PYVB_OK) { pyvb_set_error("x0_prec is not positive definite"); return PYVB_E_LINALG; }
+    int rc;
+    if ((rc = h2d(h, h->pri.x0_mean, x0_mean, D))) return rc;
+    if ((rc = h2d(h, h->pri.x0_prec, x0_prec, (size_t)D * D))) return rc;
+    if ((rc = h2d(h, h->pri.A_pm, A_pm, (size_t)D * D))) return rc;
+    if ((rc = h2d(h, h->pri.A_pp, A_pp, (size_t)D * D))) return rc;
+    if ((rc = h2d(h, h->pri.C_pm, C_pm, (size_t)K * D))) return rc;
+    if ((rc = h2d(h, h->pri.C_pp, C_pp, (size_t)D * K))) return rc;
+    if ((rc = h2d(h, h->pri.Q_a0, Q_a0, D))) return rc;
+    if ((rc = h2d(h, h->pri.Q_b0, Q_b0, D))) return rc;
+    if ((rc = h2d(h, h->pri.R_a0, R_a0, K))) return rc;
+    if ((rc = h2d(h, h->pri.R_b0, R_b0, K))) return rc;
+    // qa is fixed by the graph: update_a, nodes_todo.py:125-128 (Gamma: +0.5*child.shape[0] per child)
+    // and :183-186 (DiagonalGamma: +0.5 per child); Q has T-1 children X_1.., R has T children Y_t
+    std::vector<double> qa((size_t)N * D), ra((size_t)N * K);
+    for (int n = 0; n < N; ++n) {
+        for (int k = 0; k < D; ++k)
+            qa[(size_t)n * D + k] = (h->noise == PYVB_NOISE_GAMMA) ? Q_a0[0] + 0.5 * D * (T - 1) : Q_a0[k] + 0.5 * (T - 1);
+        for (int k = 0; k < K; ++k)
+            ra[(size_t)n * K + k] = (h->noise == PYVB_NOISE_GAMMA) ? R_a0[0] + 0.5 * K * T : R_a0[k] + 0.5 * T;
+    }
+    if ((rc = h2d(h, h->Q_a, qa.data(), qa.size()))) return rc;
+    if ((rc = h2d(h, h->R_a, ra.data(), ra.size()))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    params_changed(h);
+    h->resQ_valid = h->resR_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_lds_set_observations(pyvb_lds* h, const double* Y) {
+    ENTER(h);
+    ARGCHK(Y, "Y is NULL");
+    int rc;
+    if ((rc = h2d(h, h->Y, Y, (size_t)h->N * h->T * h->K))) return rc;
+    if ((rc = launch_syy(h))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    states_changed(h);
+    return PYVB_OK;
+}
+
+int pyvb_lds_set_state(pyvb_lds* h, const double* X, const double* A_mean, const double* A_colvar,
+                       const double* C_mean, const double* C_colvar, const double* Q_b, const double* R_b) {
+    ENTER(h);
+    const size_t N = h->N, T = h->T, D = h->D, K = h->K;
+    int rc;
+    if ((rc = h2d(h, h->X[h->cur], X, N * T * D))) return rc;
+    if ((rc = h2d(h, h->A_mean, A_mean, N * D * D))) return rc;
+    if ((rc = h2d(h, h->A_var, A_colvar, N * D * D))) return rc;
+    if ((rc = h2d(h, h->C_mean, C_mean, N * K * D))) return rc;
+    if ((rc = h2d(h, h->C_var, C_colvar, N * D * K))) return rc;
+    if ((rc = h2d(h, h->Q_b, Q_b, N * D))) return rc;
+    if ((rc = h2d(h, h->R_b, R_b, N * K))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (X) states_changed(h);
+    if (A_mean || A_colvar || C_mean || C_colvar || Q_b || R_b) { params_changed(h); h->resQ_valid = h->resR_valid = false; }
+    return PYVB_OK;
+}
+
+int pyvb_lds_get_state(pyvb_lds* h, double* X, double* A_mean, double* A_colvar, double* C_mean, double* C_colvar,
+                       double* Q_a, double* Q_b, double* R_a, double* R_b) {
+    ENTER(h);
+    const size_t N = h->N, T = h->T, D = h->D, K = h->K;
+    int rc;
+    if ((rc = d2h(h, X, h->X[h->cur], N * T * D))) return rc;
+    if ((rc = d2h(h, A_mean, h->A_mean, N * D * D))) return rc;
+    if ((rc = d2h(h, A_colvar, h->A_var, N * D * D))) return rc;
+    if ((rc = d2h(h, C_mean, h->C_mean, N * K * D))) return rc;
+    if ((rc = d2h(h, C_colvar, h->C_var, N * D * K))) return rc;
+    if ((rc = d2h(h, Q_a, h->Q_a, N * D))) return rc;
+    if ((rc = d2h(h, Q_b, h->Q_b, N * D))) return rc;
+    if ((rc = d2h(h, R_a, h->R_a, N * K))) return rc;
+    if ((rc = d2h(h, R_b, h->R_b, N * K))) return rc;
+    return pyvb_lds_sync(h);
+}
+
+int pyvb_lds_get_posterior_classes(pyvb_lds* h, double* Sigma, double* qld_x) {
+    ENTER(h);
+    const size_t N = h->N, D = h->D;
+    int rc;
+    if ((rc = d2h(h, Sigma, h->Sigma, N * 3 * D * D))) return rc;
+    if ((rc = d2h(h, qld_x, h->qld_x, N * 3))) return rc;
+    return pyvb_lds_sync(h);
+}
+
+int pyvb_lds_get_column_qld(pyvb_lds* h, double* qld_A, double* qld_C) {
+    ENTER(h);
+    int rc;
+    if ((rc = d2h(h, qld_A, h->qld_A, (size_t)h->N * h->D))) return rc;
+    if ((rc = d2h(h, qld_C, h->qld_C, (size_t)h->N * h->D))) return rc;
+    return pyvb_lds_sync(h);
+}
+
+int pyvb_lds_get_warmup(pyvb_lds* h, int* warm) {
+    ENTER(h);
+    ARGCHK(warm, "warm is NULL");
+    HIPCHK(hipMemcpyAsync(warm, h->warm, (size_t)h->N * 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    return pyvb_lds_sync(h);
+}
+
+// ---- dependency tracking -------------------------------------------------------------------
+// gains (k_prep) depend on the parameter posteriors.  The posterior covariance classes that the
+// statistics use are those of the X_t's LAST update; they switch to the freshly prepared ones
+// once every X_t has been updated under the current parameters.
+static int ensure_gains(pyvb_lds* h) {
+    if (h->gains_valid) return PYVB_OK;
+    int rc = launch_prep(h);
+    if (rc) return rc;
+    h->gains_valid = true;
+    memset(h->fresh, 0, h->T);
+    h->fresh_count = 0;
+    return PYVB_OK;
+}
+
+static void adopt_classes(pyvb_lds* h) {
+    double* t = h->Sigma; h->Sigma = h->Sigma_new; h->Sigma_new = t;
+    t = h->qld_x; h->qld_x = h->qld_x_new; h->qld_x_new = t;
+}
+
+static void mark_all_fresh(pyvb_lds* h) {
+    if (h->fresh_count < h->T) {
+        // Sigma_new holds the classes of the current parameters exactly when some node is not fresh yet
+        adopt_classes(h);
+        memset(h->fresh, 1, h->T);
+        h->fresh_count = h->T;
+    }
+    h->mixed_cov = false;
+}
+
+static int ensure_stats(pyvb_lds* h) {
+    if (h->stats_valid) return PYVB_OK;
+    if (h->mixed_cov || (h->gains_valid && h->fresh_count != 0 && h->fresh_count != h->T)) {
+        pyvb_set_error("%d of %d X_t were updated since the parameters changed: their covariances differ; sweep all states first",
+                       h->fresh_count, h->T);
+        return PYVB_E_STALE;
+    }
+    int rc = launch_stats(h);
+    if (rc) return rc;
+    h->stats_valid = true;
+    return PYVB_OK;
+}
+
+static int ensure_resid(pyvb_lds* h, int which) {
+    bool& valid = which == 0 ? h->resQ_valid : h->resR_valid;
+    if (valid) return PYVB_OK;
+    int rc = ensure_stats(h);
+    if (rc) return rc;
+    if ((rc = launch_resid(h, which))) return rc;
+    valid = true;
+    return PYVB_OK;
+}
+
+int pyvb_lds_sweep(pyvb_lds* h, int direction) {
+    ENTER(h);
+    ARGCHK(direction == PYVB_FORWARD || direction == PYVB_BACKWARD, "direction must be PYVB_FORWARD or PYVB_BACKWARD");
+    int rc = ensure_gains(h);
+    if (rc) return rc;
+    if ((rc = launch_sweep(h, direction))) return rc;
+    mark_all_fresh(h);
+    states_changed(h);
+    return PYVB_OK;
+}
+
+int pyvb_lds_update_x(pyvb_lds* h, int t) {
+    ENTER(h);
+    ARGCHK(t >= 0 && t < h->T, "t out of range");
+    int rc = ensure_gains(h);
+    if (rc) return rc;
+    if ((rc = launch_step(h, t))) return rc;
+    if (!h->fresh[t]) {
+        h->fresh[t] = 1;
+        if (++h->fresh_count == h->T) { adopt_classes(h); h->mixed_cov = false; }
+    }
+    states_changed(h);
+    return PYVB_OK;
+}
+
+int pyvb_lds_update_A(pyvb_lds* h) {
+    ENTER(h);
+    int rc = ensure_stats(h);
+    if (rc) return rc;
+    if ((rc = launch_cols(h, 0))) return rc;
+    params_changed(h); h->resQ_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_lds_update_C(pyvb_lds* h) {
+    ENTER(h);
+    int rc = ensure_stats(h);
+    if (rc) return rc;
+    if ((rc = launch_cols(h, 1))) return rc;
+    params_changed(h); h->resR_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_lds_update_Q(pyvb_lds* h) {
+    ENTER(h);
+    int rc = ensure_resid(h, 0);
+    if (rc) return rc;
+    if ((rc = launch_noise(h, 0))) return rc;
+    params_changed(h);
+    return PYVB_OK;
+}
+
+int pyvb_lds_update_R(pyvb_lds* h) {
+    ENTER(h);
+    int rc = ensure_resid(h, 1);
+    if (rc) return rc;
+    if ((rc = launch_noise(h, 1))) return rc;
+    params_changed(h);
+    return PYVB_OK;
+}
+
+int pyvb_lds_elbo(pyvb_lds* h) {
+    ENTER(h);
+    int rc;
+    if ((rc = ensure_resid(h, 0))) return rc;
+    if ((rc = ensure_resid(h, 1))) return rc;
+    return launch_elbo(h);
+}
+
+int pyvb_lds_get_elbo(pyvb_lds* h, double* parts) {
+    ENTER(h);
+    ARGCHK(parts, "parts is NULL");
+    int rc = d2h(h, parts, h->elbo, (size_t)h->N * 6);
+    if (rc) return rc;
+    return pyvb_lds_sync(h);
+}
+
+int pyvb_lds_iterate(pyvb_lds* h, int niters) {
+    ENTER(h);
+    ARGCHK(niters >= 0, "niters must be >= 0");
+    int rc;
+    for (int it = 0; it < niters; ++it) {
+        if ((rc = pyvb_lds_sweep(h, PYVB_FORWARD))) return rc;
+        if ((rc = pyvb_lds_sweep(h, PYVB_BACKWARD))) return rc;
+        if ((rc = pyvb_lds_update_A(h))) return rc;
+        if ((rc = pyvb_lds_update_C(h))) return rc;
+        if ((rc = pyvb_lds_update_Q(h))) return rc;
+        if ((rc = pyvb_lds_update_R(h))) return rc;
+        if ((rc = pyvb_lds_elbo(h))) return rc;
+    }
+    return PYVB_OK;
+}
+
+int pyvb_lds_sync(pyvb_lds* h) {
+    ENTER(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int st = 0;
+    HIPCHK(hipMemcpy(&st, h->status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        pyvb_set_error("a posterior precision was not positive definite (numpy.linalg.LinAlgError in the reference)");
+        HIPCHK(hipMemset(h->status, 0, sizeof(int)));
+        return PYVB_E_LINALG;
+    }
+    return PYVB_OK;
+}
+
+int pyvb_lds_timing_enable(pyvb_lds* h, int on) { ENTER(h); h->timing = on != 0; return PYVB_OK; }
+int pyvb_lds_timing_reset(pyvb_lds* h) { ENTER(h); memset(h->timers, 0, sizeof(h->timers)); return PYVB_OK; }
+int pyvb_lds_timing_get(pyvb_lds* h, int kernel, double* total_ms, int* launches) {
+    ENTER(h);
+    ARGCHK(kernel >= 0 && kernel < PYVB_K_COUNT, "no such kernel id");
+    if (total_ms) *total_ms = h->timers[kernel].total_ms;
+    if (launches) *launches = h->timers[kernel].launches;
+    return PYVB_OK;
+}
+
+// ---- RCCL (loaded on demand so that single-GPU use does not depend on it) -------------------
+typedef struct { char internal[128]; } nccl_uid;
+typedef int (*fn_getuid)(nccl_uid*);
+typedef int (*fn_initrank)(void**, int, nccl_uid, int);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+static struct { void* lib; fn_getuid getuid; fn_initrank initrank; fn_allreduce allreduce; fn_destroy destroy; fn_errstr errstr; } g_nccl;
+
+static int load_rccl() {
+    if (g_nccl.lib) return PYVB_OK;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { pyvb_set_error("cannot load librccl: %s", dlerror()); return PYVB_E_RCCL; }
+    g_nccl.getuid = (fn_getuid)dlsym(lib, "ncclGetUniqueId");
+    g_nccl.initrank = (fn_initrank)dlsym(lib, "ncclCommInitRank");
+    g_nccl.allreduce = (fn_allreduce)dlsym(lib, "ncclAllReduce");
+    g_nccl.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
+    g_nccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+    if (!g_nccl.getuid || !g_nccl.initrank || !g_nccl.allreduce || !g_nccl.destroy) { pyvb_set_error("librccl lacks a required symbol"); return PYVB_E_RCCL; }
+    g_nccl.lib = lib;
+    return PYVB_OK;
+}
+#define NCCLCHK(x) do { int _r = (x); if (_r != 0) { pyvb_set_error("RCCL error %d (%s) in %s", _r, g_nccl.errstr ? g_nccl.errstr(_r) : "?", #x); return PYVB_E_RCCL; } } while (0)
+
+int pyvb_comm_unique_id(char id[128]) {
+    ARGCHK(id, "id is NULL");
+    int rc = load_rccl();
+    if (rc) return rc;
+    nccl_uid u;
+    NCCLCHK(g_nccl.getuid(&u));
+    memcpy(id, u.internal, 128);
+    return PYVB_OK;
+}
+
+int pyvb_lds_comm_init(pyvb_lds* h, const char id[128], int rank, int world) {
+    ENTER(h);
+    ARGCHK(id && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+    int rc = load_rccl();
+    if (rc) return rc;
+    nccl_uid u;
+    memcpy(u.internal, id, 128);
+    NCCLCHK(g_nccl.initrank(&h->comm, world, u, rank));
+    h->rank = rank; h->world = world;
+    return PYVB_OK;
+}
+
+int pyvb_lds_comm_destroy(pyvb_lds* h) {
+    if (h && h->comm && g_nccl.destroy) { g_nccl.destroy(h->comm); h->comm = nullptr; h->world = 1; }
+    return PYVB_OK;
+}
+
+int pyvb_lds_elbo_total(pyvb_lds* h, double out[6]) {
+    ENTER(h);
+    ARGCHK(out, "out is NULL");
+    int rc = launch_elbo_sum(h);
+    if (rc) return rc;
+    if (h->comm)   // ncclDouble = 8, ncclSum = 0
+        NCCLCHK(g_nccl.allreduce(h->elbo_sum, h->elbo_sum, 6, 8, 0, h->comm, h->stream));
+    if ((rc = d2h(h, out, h->elbo_sum, 6))) return rc;
+    return pyvb_lds_sync(h);
+}
+
+}  // extern "C"

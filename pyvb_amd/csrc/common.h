@@ -1,0 +1,118 @@
+// Internal definitions shared by the translation units of libpyvb_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include "../../include/pyvb_hip.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// Per-replicate block of "gains": every matrix the state updates multiply by, written by
+// k_prep once per parameter change and read by the sweep / step kernels.
+//   Sigma_c = posterior covariance of class c (0: X_0, 1: interior, 2: X_{T-1})
+//   F  = Sigma_1 <Q><A>      B  = Sigma_1 <A>^T<Q>     G  = Sigma_1 <C>^T<R>
+//   B0 = Sigma_0 <A>^T<Q>    G0 = Sigma_0 <C>^T<R>     h0 = Sigma_0 L0 m0
+//   FL = Sigma_2 <Q><A>      GL = Sigma_2 <C>^T<R>
+// "n"/"p" blocks are laid out as v_mfma_f64_16x16x4 A-operands: element [(m*S+s)*64+lane]
+// = M[16m + (lane&15)][kidx(s, lane>>4)], kidx natural = 4s+q, permuted = 8(s>>1)+2q+(s&1).
+// "T" blocks are transposed plain matrices [col][DP] for the lane-per-row scalar code.
+struct Layout {
+    int D, K, DT, KT, DP, KP, DS, KS;
+    size_t oFn, oFp, oBn, oBp, oGp;
+    size_t oFT, oBT, oGT, oB0T, oG0T, oh0, oFLT, oGLT;
+    size_t gains_total;     // doubles per replicate
+    size_t stats_total;     // doubles per replicate per chunk: Sxx[DP][DP], Sx1x[DP][DP], Syx[KP][DP]
+    size_t oSxx, oSx1x, oSyx;
+};
+
+static inline int tiles16(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : 4); }
+
+static inline Layout make_layout(int D, int K) {
+    Layout L;
+    L.D = D; L.K = K;
+    L.DT = tiles16(D); L.KT = tiles16(K);
+    L.DP = 16 * L.DT; L.KP = 16 * L.KT;
+    L.DS = 4 * L.DT; L.KS = 4 * L.KT;
+    size_t o = 0;
+    size_t dd = (size_t)L.DT * L.DS * 64, dk = (size_t)L.DT * L.KS * 64;
+    L.oFn = o; o += dd; L.oFp = o; o += dd; L.oBn = o; o += dd; L.oBp = o; o += dd; L.oGp = o; o += dk;
+    size_t tdd = (size_t)L.DP * L.DP, tkd = (size_t)L.KP * L.DP;
+    L.oFT = o; o += tdd; L.oBT = o; o += tdd; L.oGT = o; o += tkd;
+    L.oB0T = o; o += tdd; L.oG0T = o; o += tkd; L.oh0 = o; o += L.DP;
+    L.oFLT = o; o += tdd; L.oGLT = o; o += tkd;
+    L.gains_total = o;
+    L.oSxx = 0; L.oSx1x = tdd; L.oSyx = 2 * tdd;
+    L.stats_total = 2 * tdd + tkd;
+    return L;
+}
+
+struct Priors {          // device pointers, shared by all replicates
+    double *x0_mean, *x0_prec, *A_pm, *A_pp, *C_pm, *C_pp, *Q_a0, *Q_b0, *R_a0, *R_b0;
+    double x0_lndet;     // ln det of x0_prec (Constant.lndet, node.py:301-302)
+};
+
+struct KernelTimer {
+    double total_ms; int launches;
+};
+
+struct pyvb_lds {
+    int device, N, T, D, K, noise;
+    Layout L;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    // state
+    double *Y, *Syy;                // [N][T][K], [N][K] (sum_t y^2)
+    double *X[2]; int cur;          // ping-pong [N][T][D]
+    double *A_mean, *A_var, *C_mean, *C_var;
+    double *Q_a, *Q_b, *R_a, *R_b;
+    double *qld_A, *qld_C;          // [N][D]
+    Priors pri;
+    double *pri_block;
+    // derived
+    double *Sigma, *qld_x;          // as of the last X update: [N][3][D][D], [N][3]
+    double *Sigma_new, *qld_x_new;  // written by k_prep for the current parameters
+    double *gains;                  // [N][L.gains_total]
+    double *scratch;                // [N][2][DP][DP] (M_C, M_A + M_C)
+    int *warm;                      // [N][2]
+    double *stats; int nchunk, chunk_len;   // [N][nchunk][L.stats_total]
+    double *resQ, *resR;            // [N][D], [N][K]
+    double *elbo, *elbo_sum;        // [N][6], [6]
+    int *status;                    // device flag: nonzero if a Cholesky failed
+    // host-side validity tracking
+    bool gains_valid, stats_valid, resQ_valid, resR_valid;
+    int fresh_count; unsigned char* fresh;  // X_t updated since the parameters last changed
+    bool mixed_cov;                         // the X_t hold covariances of different parameter generations
+    bool timing; KernelTimer timers[PYVB_K_COUNT];
+    void* comm; int rank, world;
+};
+
+// ---- launchers implemented in the kernel translation units ----
+int launch_prep(pyvb_lds* h);
+int launch_sweep(pyvb_lds* h, int direction);
+int launch_step(pyvb_lds* h, int t);
+int launch_syy(pyvb_lds* h);
+int launch_stats(pyvb_lds* h);
+int launch_cols(pyvb_lds* h, int which);      // 0 = A, 1 = C
+int launch_resid(pyvb_lds* h, int which);     // 0 = Q, 1 = R
+int launch_noise(pyvb_lds* h, int which);
+int launch_elbo(pyvb_lds* h);
+int launch_elbo_sum(pyvb_lds* h);
+
+void pyvb_set_error(const char* fmt, ...);
+int pyvb_hip_fail(hipError_t e, const char* what, const char* file, int line);
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return pyvb_hip_fail(_e, #x, __FILE__, __LINE__); } while (0)
+
+// timed launch bracket: records events on the handle's stream when timing is enabled
+struct TimedLaunch {
+    pyvb_lds* h; int k;
+    TimedLaunch(pyvb_lds* h_, int k_) : h(h_), k(k_) { if (h->timing) (void)hipEventRecord(h->ev0, h->stream); }
+    ~TimedLaunch() {
+        if (h->timing) {
+            (void)hipEventRecord(h->ev1, h->stream);
+            (void)hipEventSynchronize(h->ev1);
+            float ms = 0; (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+            h->timers[k].total_ms += ms; h->timers[k].launches += 1;
+        }
+    }
+};

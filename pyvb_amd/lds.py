@@ -1,0 +1,173 @@
+"""LDSBatch: N independent replicates of the linear-dynamical-system graph of the
+reference's examples/Linear_Dynamic_System.py:46-66, resident on one MI355X.
+
+Thin Python over the C ABI (include/pyvb_hip.h); every method is one or a few
+kernel launches.  The node classes in pyvb_amd.nodes bind to an LDSBatch with
+N = 1; bench.py and the parity tests drive it directly.
+"""
+import numpy as np
+
+from . import _capi as C
+
+__all__ = ["LDSBatch"]
+
+_NOISE = {"diagonal_gamma": C.NOISE_DIAGONAL_GAMMA, "gamma": C.NOISE_GAMMA}
+
+
+def _f64(a, shape, name):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != tuple(shape):
+        raise AssertionError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return a
+
+
+class LDSBatch(object):
+    ELBO_PARTS = ("X", "Y", "A", "C", "Q", "R")
+
+    def __init__(self, N, T, D, K, noise="diagonal_gamma", device=0):
+        if noise not in _NOISE:
+            raise NotImplementedError("noise precision %r has no HIP path (DiagonalGamma and Gamma do)" % (noise,))
+        self.N, self.T, self.D, self.K, self.noise, self.device = int(N), int(T), int(D), int(K), noise, int(device)
+        h = C.ctypes.c_void_p()
+        C.check(C.lib.pyvb_lds_create(C.ctypes.byref(h), self.device, self.N, self.T, self.D, self.K, _NOISE[noise]))
+        self._h = h
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            C.lib.pyvb_lds_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs -----------------------------------------------------------------------------
+    def set_priors(self, pri):
+        """pri: dict as pyvb_amd.synth.default_priors (Constant parents of X_0 and of the
+        columns, Gamma-family hyper-parameters).  Scalars are broadcast for the Gamma kind."""
+        D, K = self.D, self.K
+        bc = lambda v, n: np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)))
+        arrs = [
+            _f64(pri["x0_mean"], (D,), "x0_mean"), _f64(pri["x0_prec"], (D, D), "x0_prec"),
+            _f64(pri["A_prior_mean"], (D, D), "A_prior_mean"), _f64(pri["A_prior_prec"], (D, D), "A_prior_prec"),
+            _f64(pri["C_prior_mean"], (K, D), "C_prior_mean"), _f64(pri["C_prior_prec"], (D, K), "C_prior_prec"),
+            bc(pri["Q_a0"], D), bc(pri["Q_b0"], D), bc(pri["R_a0"], K), bc(pri["R_b0"], K),
+        ]
+        C.check(C.lib.pyvb_lds_set_priors(self._h, *[C.dptr(a) for a in arrs]))
+
+    def set_observations(self, Y):
+        Y = _f64(Y, (self.N, self.T, self.K), "Y")
+        if np.isnan(Y).any():
+            raise NotImplementedError("missing observations (NaN) have no HIP path yet")
+        C.check(C.lib.pyvb_lds_set_observations(self._h, C.dptr(Y)))
+
+    def set_state(self, X=None, A_mean=None, A_colvar=None, C_mean=None, C_colvar=None, Q_b=None, R_b=None):
+        N, T, D, K = self.N, self.T, self.D, self.K
+        shapes = [("X", X, (N, T, D)), ("A_mean", A_mean, (N, D, D)), ("A_colvar", A_colvar, (N, D, D)),
+                  ("C_mean", C_mean, (N, K, D)), ("C_colvar", C_colvar, (N, D, K)), ("Q_b", Q_b, (N, D)), ("R_b", R_b, (N, K))]
+        arrs = [None if a is None else _f64(a, s, nm) for nm, a, s in shapes]
+        C.check(C.lib.pyvb_lds_set_state(self._h, *[C.dptr(a) for a in arrs]))
+
+    # -- outputs ----------------------------------------------------------------------------
+    def get_state(self, what=("X", "A_mean", "A_colvar", "C_mean", "C_colvar", "Q_a", "Q_b", "R_a", "R_b")):
+        N, T, D, K = self.N, self.T, self.D, self.K
+        shapes = {"X": (N, T, D), "A_mean": (N, D, D), "A_colvar": (N, D, D), "C_mean": (N, K, D), "C_colvar": (N, D, K),
+                  "Q_a": (N, D), "Q_b": (N, D), "R_a": (N, K), "R_b": (N, K)}
+        order = ["X", "A_mean", "A_colvar", "C_mean", "C_colvar", "Q_a", "Q_b", "R_a", "R_b"]
+        out = {k: np.empty(shapes[k]) for k in order if k in what}
+        C.check(C.lib.pyvb_lds_get_state(self._h, *[C.dptr(out.get(k)) for k in order]))
+        return out
+
+    def get_posterior_classes(self):
+        """(Sigma[N,3,D,D], q_ln_det[N,3]) of X_0, the interior X_t and X_{T-1} as of their last update."""
+        S = np.empty((self.N, 3, self.D, self.D))
+        q = np.empty((self.N, 3))
+        C.check(C.lib.pyvb_lds_get_posterior_classes(self._h, C.dptr(S), C.dptr(q)))
+        return S, q
+
+    def get_column_qld(self):
+        qa, qc = np.empty((self.N, self.D)), np.empty((self.N, self.D))
+        C.check(C.lib.pyvb_lds_get_column_qld(self._h, C.dptr(qa), C.dptr(qc)))
+        return qa, qc
+
+    def get_warmup(self):
+        w = np.empty((self.N, 2), dtype=np.int32)
+        C.check(C.lib.pyvb_lds_get_warmup(self._h, w.ctypes.data_as(C._ip)))
+        return w
+
+    # -- updates ----------------------------------------------------------------------------
+    def sweep(self, direction="forward"):
+        C.check(C.lib.pyvb_lds_sweep(self._h, C.FORWARD if direction == "forward" else C.BACKWARD))
+
+    def update_x(self, t):
+        C.check(C.lib.pyvb_lds_update_x(self._h, int(t)))
+
+    def update_A(self):
+        C.check(C.lib.pyvb_lds_update_A(self._h))
+
+    def update_C(self):
+        C.check(C.lib.pyvb_lds_update_C(self._h))
+
+    def update_Q(self):
+        C.check(C.lib.pyvb_lds_update_Q(self._h))
+
+    def update_R(self):
+        C.check(C.lib.pyvb_lds_update_R(self._h))
+
+    def elbo(self):
+        """Per-replicate lower-bound parts [N,6] (X, Y, A, C, Q, R), reference mode."""
+        C.check(C.lib.pyvb_lds_elbo(self._h))
+        out = np.empty((self.N, 6))
+        C.check(C.lib.pyvb_lds_get_elbo(self._h, C.dptr(out)))
+        return out
+
+    def elbo_total(self):
+        """Parts summed over replicates (and over ranks when a communicator is attached)."""
+        out = np.empty(6)
+        C.check(C.lib.pyvb_lds_elbo_total(self._h, C.dptr(out)))
+        return out
+
+    def iterate(self, niters=1):
+        """niters x (forward sweep, backward sweep, A, C, Q, R, lower bound); asynchronous."""
+        C.check(C.lib.pyvb_lds_iterate(self._h, int(niters)))
+
+    def sync(self):
+        C.check(C.lib.pyvb_lds_sync(self._h))
+
+    # -- measurement ------------------------------------------------------------------------
+    def timing(self, on=True):
+        C.check(C.lib.pyvb_lds_timing_enable(self._h, 1 if on else 0))
+        C.check(C.lib.pyvb_lds_timing_reset(self._h))
+
+    def kernel_times(self):
+        names = {"prep": C.K_PREP, "sweep": C.K_SWEEP, "stats": C.K_STATS, "params": C.K_PARAMS, "step": C.K_STEP}
+        out = {}
+        for nm, k in names.items():
+            ms, cnt = C.ctypes.c_double(), C.ctypes.c_int()
+            C.check(C.lib.pyvb_lds_timing_get(self._h, k, C.ctypes.byref(ms), C.ctypes.byref(cnt)))
+            out[nm] = (ms.value, cnt.value)
+        return out
+
+    # -- multi-GPU --------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.ctypes.create_string_buffer(128)
+        C.check(C.lib.pyvb_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid, rank, world):
+        C.check(C.lib.pyvb_lds_comm_init(self._h, uid, int(rank), int(world)))
+
+    # -- convenience ------------------------------------------------------------------------
+    @classmethod
+    def from_problem(cls, Y, st0, pri, device=0):
+        N, T, K = Y.shape
+        D = st0["A_mean"].shape[1]
+        b = cls(N, T, D, K, pri.get("noise", "diagonal_gamma"), device)
+        b.set_priors(pri)
+        b.set_observations(Y)
+        b.set_state(**{k: st0[k] for k in ("X", "A_mean", "A_colvar", "C_mean", "C_colvar", "Q_b", "R_b")})
+        return b

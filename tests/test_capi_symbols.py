@@ -1,0 +1,35 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/pyvb_hip.h declares
+(no compute calls: there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(REPO, "include", "pyvb_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pyvb_[A-Za-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from pyvb_amd import _capi
+    names = _declared()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libpyvb_hip.so does not export %s" % n
+        assert n in _capi.SIGNATURES, "pyvb_amd._capi does not bind %s" % n
+    assert sorted(_capi.SIGNATURES) == names
+
+
+def test_error_string_and_argument_checks_without_gpu():
+    from pyvb_amd import _capi
+    assert _capi.lib.pyvb_version() >= 100
+    h = ctypes.c_void_p()
+    rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 1, 4, 4, 0)     # T = 1 is refused before any HIP call
+    assert rc == _capi.E_ARG
+    assert b"T must be" in _capi.lib.pyvb_last_error()
+    rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 10, 65, 4, 0)
+    assert rc == _capi.E_ARG

@@ -1,0 +1,279 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden fixtures produced by the
+reference and against the oracle on seeded inputs.  Run with `-m gpu` on an MI355X.
+
+Tolerances (north_star): posterior means/covariances 1e-8 relative (max-norm), lower bound 1e-8
+relative.  q_ln_det is compared through s = 0.5/q_ln_det (see tests/test_oracle_golden.py).
+"""
+import numpy as np
+import pytest
+
+from oracle import lds_closed_form as O
+from pyvb_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _close(a, b, what, rtol=RTOL):
+    assert np.all(np.isfinite(a)), what + ": non-finite values"
+    err = _rel(a, b)
+    assert err <= rtol, "%s: rel err %.3e" % (what, err)
+
+
+def _close_qld(a, b, what):
+    sa, sb = 0.5 / np.asarray(a, dtype=float), 0.5 / np.asarray(b, dtype=float)
+    assert np.all(np.abs(sa - sb) <= 1e-9 * np.maximum(1.0, np.abs(sb))), what
+
+
+def _batch(Y, st0, pri):
+    from pyvb_amd.lds import LDSBatch
+    return LDSBatch.from_problem(Y, st0, pri)
+
+
+def _compare_params(b, st, tag):
+    g = b.get_state()
+    _close(g["A_mean"], st["A_mean"], tag + "A_mean")
+    _close(g["C_mean"], st["C_mean"], tag + "C_mean")
+    _close(g["A_colvar"], np.einsum("nikk->nik", st["A_cov"]), tag + "A_colvar")
+    _close(g["C_colvar"], np.einsum("nikk->nik", st["C_cov"]), tag + "C_colvar")
+    for nm in ("Q_a", "Q_b", "R_a", "R_b"):
+        ref = st[nm] if st[nm].ndim == 2 else np.repeat(st[nm][:, None], g[nm].shape[1], axis=1)
+        _close(g[nm], ref, tag + nm)
+    qa, qc = b.get_column_qld()
+    _close_qld(qa, st["qld_A"], tag + "qld_A")
+    _close_qld(qc, st["qld_C"], tag + "qld_C")
+
+
+def _stagewise(Y, st0, pri, iters):
+    """Run the example's loop on the GPU and in the oracle, comparing after every stage."""
+    N, T, K = Y.shape
+    b = _batch(Y, st0, pri)
+    st = O.expand_state(st0, pri, T)
+    for it in range(iters):
+        tag = "it%d " % it
+        post = O.state_posteriors(st, pri)
+        O.sweep(st, pri, Y, "forward", post)
+        b.sweep("forward")
+        _close(b.get_state(("X",))["X"], st["X"], tag + "X after forward sweep")
+        O.sweep(st, pri, Y, "backward", post)
+        b.sweep("backward")
+        _close(b.get_state(("X",))["X"], st["X"], tag + "X after backward sweep")
+        Sig, qld = b.get_posterior_classes()
+        cls = [0, 1, 2] if T > 2 else [0, 2]
+        _close(Sig[:, cls], st["Sigma"][:, cls], tag + "Sigma")
+        _close_qld(qld[:, cls], st["qld_x"][:, cls], tag + "qld_x")
+        S = O.statistics(st, Y)
+        O.update_A(st, pri, S); b.update_A()
+        _close(b.get_state(("A_mean",))["A_mean"], st["A_mean"], tag + "A_mean after update_A")
+        O.update_C(st, pri, S); b.update_C()
+        _close(b.get_state(("C_mean",))["C_mean"], st["C_mean"], tag + "C_mean after update_C")
+        O.update_Q(st, pri, S, T); b.update_Q()
+        O.update_R(st, pri, S, T); b.update_R()
+        _compare_params(b, st, tag)
+        parts = O.elbo_parts(st, pri, S, T)
+        got = b.elbo()
+        scale = np.abs(parts).sum(axis=1, keepdims=True)
+        assert np.all(np.abs(got - parts) <= RTOL * scale), tag + "elbo parts\n%r\n%r" % (got, parts)
+        _close(got.sum(1), parts.sum(1), tag + "elbo total")
+    b.close()
+    return st
+
+
+def test_golden_fixtures(golden):
+    """The reference's own outputs (tests/golden/*.npz), reproduced by the HIP path."""
+    meta, Y, st0, pri, z = golden
+    if meta["noise"] == "wishart":
+        pytest.skip("Wishart noise has no HIP path (SURVEY.md §8f item 4); its reference ELBO does not exist (Q8)")
+    T = meta["T"]
+    b = _batch(Y, st0, pri)
+    b.sweep("forward")
+    _close(b.get_state(("X",))["X"][0], z["it1_fwd_X"], "forward sweep vs reference")
+    b.sweep("backward")
+    for it in range(1, max(meta["iters"]) + 1):
+        if it > 1:
+            b.sweep("forward"); b.sweep("backward")
+        b.update_A(); b.update_C(); b.update_Q(); b.update_R()
+        if it in meta["iters"]:
+            tag = "it%d_" % it
+            g = b.get_state()
+            _close(g["X"][0], z[tag + "X"], tag + "X")
+            Sig, qld = b.get_posterior_classes()
+            cls = [0, 1, 2] if T > 2 else [0, 2]
+            _close(Sig[0][cls], z[tag + "Sigma"][cls], tag + "Sigma")
+            _close_qld(qld[0][cls], z[tag + "qld_x"][cls], tag + "qld_x")
+            _close(g["A_mean"][0], z[tag + "A_mean"], tag + "A_mean")
+            _close(g["C_mean"][0], z[tag + "C_mean"], tag + "C_mean")
+            for nm in ("A", "C"):
+                ref = z[tag + nm + "_colvar"] if tag + nm + "_colvar" in z else np.einsum("ikk->ik", z[tag + nm + "_cov"])
+                _close(g[nm + "_colvar"][0], ref, tag + nm + "_colvar")
+            for nm in ("Q_a", "Q_b", "R_a", "R_b"):
+                _close(g[nm][0], np.broadcast_to(z[tag + nm], g[nm][0].shape), tag + nm)
+            parts = b.elbo()[0]
+            ref = z[tag + "elbo_parts"]
+            assert np.all(np.abs(parts - ref) <= RTOL * np.abs(ref).sum()), "%s elbo parts %r vs %r" % (tag, parts, ref)
+            assert abs(parts.sum() - ref.sum()) <= RTOL * abs(ref.sum())
+    b.close()
+
+
+@pytest.mark.parametrize("T,D,K,N", [
+    (300, 16, 16, 3), (120, 64, 64, 2), (1000, 5, 3, 2), (77, 33, 17, 2), (64, 20, 40, 2), (50, 64, 7, 1), (40, 2, 64, 2)])
+def test_stagewise_vs_oracle(T, D, K, N):
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=100 + T + D)
+    _stagewise(Y, st0, pri, iters=3)
+
+
+@pytest.mark.parametrize("T", [2, 3, 4, 5, 16, 17, 18, 19, 33, 34, 129])
+def test_short_and_ragged_chains(T):
+    """Segment bookkeeping: chains shorter than, equal to and just above multiples of 16 interior nodes."""
+    Y, st0, pri = synth.make_problem(T, 6, 4, 2, seed=500 + T)
+    _stagewise(Y, st0, pri, iters=2)
+
+
+def test_gamma_noise():
+    Y, st0, pri = synth.make_problem(90, 7, 9, 2, seed=77)
+    pri["noise"] = "gamma"
+    for k in ("Q_a0", "Q_b0", "R_a0", "R_b0"):
+        pri[k] = np.float64(1e-3)
+    _stagewise(Y, st0, pri, iters=3)
+
+
+def test_nondefault_priors():
+    """Non-zero prior means and non-trivial prior precisions for X_0 and the columns."""
+    T, D, K, N = 60, 5, 6, 2
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=31)
+    rng = np.random.default_rng(5)
+    W = rng.standard_normal((D, D))
+    pri["x0_prec"] = W @ W.T + D * np.eye(D)
+    pri["x0_mean"] = rng.standard_normal(D)
+    pri["A_prior_mean"] = 0.3 * rng.standard_normal((D, D))
+    pri["C_prior_mean"] = 0.3 * rng.standard_normal((K, D))
+    pri["A_prior_prec"] = 0.01 + rng.random((D, D))
+    pri["C_prior_prec"] = 0.01 + rng.random((D, K))
+    pri["Q_a0"], pri["Q_b0"] = 0.1 + rng.random(D), 0.1 + rng.random(D)
+    pri["R_a0"], pri["R_b0"] = 0.1 + rng.random(K), 0.1 + rng.random(K)
+    _stagewise(Y, st0, pri, iters=2)
+
+
+def test_single_updates_equal_sweep():
+    """[x.update() for x in Xs] node by node == the fused sweep (both directions)."""
+    T, D, K, N = 37, 8, 5, 2
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=9)
+    a, b = _batch(Y, st0, pri), _batch(Y, st0, pri)
+    a.sweep("forward")
+    for t in range(T):
+        b.update_x(t)
+    _close(b.get_state(("X",))["X"], a.get_state(("X",))["X"], "stepwise forward", 1e-12)
+    a.sweep("backward")
+    for t in range(T - 1, -1, -1):
+        b.update_x(t)
+    _close(b.get_state(("X",))["X"], a.get_state(("X",))["X"], "stepwise backward", 1e-12)
+    a.update_A(); b.update_A()
+    _close(b.get_state(("A_mean",))["A_mean"], a.get_state(("A_mean",))["A_mean"], "A after stepwise", 1e-12)
+    a.close(); b.close()
+
+
+def test_partial_state_updates_are_refused():
+    """Statistics while only some X_t were updated under new parameters: the three-class
+    covariance structure does not hold, the library must say so (PYVB_E_STALE)."""
+    from pyvb_amd import _capi
+    Y, st0, pri = synth.make_problem(20, 4, 4, 1, seed=3)
+    b = _batch(Y, st0, pri)
+    b.iterate(1)
+    b.update_x(3)
+    with pytest.raises(_capi.PyvbHipError) as e:
+        b.update_A()
+    assert e.value.code == _capi.E_STALE
+    b.close()
+
+
+def test_not_positive_definite_raises():
+    Y, st0, pri = synth.make_problem(20, 4, 4, 1, seed=3)
+    st0["Q_b"] = -np.abs(st0["Q_b"]) * 1e-9        # hugely negative expected precision
+    b = _batch(Y, st0, pri)
+    b.sweep("forward")
+    with pytest.raises(np.linalg.LinAlgError):
+        b.sync()
+    b.close()
+
+
+def test_iterate_equals_individual_calls_and_is_deterministic():
+    T, D, K, N = 200, 16, 16, 5
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=12)
+    a, b, c = _batch(Y, st0, pri), _batch(Y, st0, pri), _batch(Y, st0, pri)
+    a.iterate(3)
+    c.iterate(3)
+    for _ in range(3):
+        b.sweep("forward"); b.sweep("backward"); b.update_A(); b.update_C(); b.update_Q(); b.update_R()
+    ea, eb, ec = a.elbo(), b.elbo(), c.elbo()
+    assert np.array_equal(ea, eb) and np.array_equal(ea, ec)
+    assert np.array_equal(a.get_state(("X",))["X"], c.get_state(("X",))["X"])
+    tot = a.elbo_total()
+    assert np.allclose(tot, ea.sum(0), rtol=1e-13)
+    for x in (a, b, c):
+        x.close()
+
+
+def test_replicates_are_independent():
+    """Replicate r of a batch gives bit-identical results to the same problem run alone."""
+    T, D, K, N = 150, 16, 8, 4
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=21)
+    full = _batch(Y, st0, pri)
+    full.iterate(2)
+    Xf, ef = full.get_state(("X",))["X"], full.elbo()
+    for r in (0, 3):
+        one = _batch(Y[r:r + 1], {k: v[r:r + 1] for k, v in st0.items()}, pri)
+        one.iterate(2)
+        assert np.array_equal(one.get_state(("X",))["X"][0], Xf[r])
+        assert np.array_equal(one.elbo()[0], ef[r])
+        one.close()
+    full.close()
+
+
+def test_warmup_is_data_driven_and_exact_fallback():
+    """Slowly contracting recurrences must lengthen the warm-up; with warm-up >= chain length the
+    segmented sweep degenerates to the sequential chain and is still right."""
+    T, D, K, N = 400, 4, 4, 2
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=2)
+    # tiny observation precision and huge process precision => F close to its spectral bound
+    st0["R_b"] = st0["R_b"] * 1e8
+    st0["Q_b"] = st0["Q_b"] * 1e-6
+    st = _stagewise(Y, st0, pri, iters=1)
+    b = _batch(Y, st0, pri)
+    b.sweep("forward")
+    w = b.get_warmup()
+    assert np.all(w >= 8)
+    b.close()
+
+
+def test_headline_shape_against_oracle():
+    """BASELINE config 3 shape (T = 10^4, D = K = 64) on a few replicates: one full iteration
+    against the oracle, plus the size-independent checks at N = 64."""
+    T, D, K = 10000, 64, 64
+    Y, st0, pri = synth.make_problem(T, D, K, 2, seed=4242)
+    st = O.expand_state(st0, pri, T)
+    parts = O.iterate(st, pri, Y)
+    b = _batch(Y, st0, pri)
+    b.iterate(1)
+    got = b.elbo()
+    _close(b.get_state(("X",))["X"], st["X"], "X (T=10^4, D=64)")
+    _compare_params(b, st, "headline ")
+    _close(got.sum(1), parts.sum(1), "elbo (T=10^4, D=64)")
+    b.close()
+    # N = 64 replicas of the two problems: every copy must agree bitwise with the first
+    rep = 32
+    Yb = np.concatenate([Y] * rep)
+    stb = {k: np.concatenate([v] * rep) for k, v in st0.items()}
+    big = _batch(Yb, stb, pri)
+    big.iterate(1)
+    e = big.elbo()
+    assert np.array_equal(e[0::2], np.repeat(e[0:1], rep, 0)) and np.array_equal(e[1::2], np.repeat(e[1:2], rep, 0))
+    # a different batch size may split the time axis of the statistics kernel differently:
+    # same values up to summation order
+    assert np.all(np.abs(e[:2] - got) <= 1e-12 * np.abs(got).sum(axis=1, keepdims=True))
+    big.close()
