@@ -22,6 +22,27 @@ int pyvb_hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return PYVB_E_HIP;
 }
 
+TimedLaunch::TimedLaunch(pyvb_lds* h_, int k_) : h(h_), slot(-1) {
+    if (!h->timing) return;
+    if (h->pool_used == PYVB_EVENT_POOL) pyvb_timing_resolve(h);     // pool exhausted: drain (synchronises)
+    slot = h->pool_used++;
+    h->pool[slot].kernel = k_;
+    (void)hipEventRecord(h->pool[slot].e0, h->stream);
+}
+TimedLaunch::~TimedLaunch() { if (slot >= 0) (void)hipEventRecord(h->pool[slot].e1, h->stream); }
+
+void pyvb_timing_resolve(pyvb_lds* h) {
+    for (int i = 0; i < h->pool_used; ++i) {
+        float ms = 0;
+        (void)hipEventSynchronize(h->pool[i].e1);
+        if (hipEventElapsedTime(&ms, h->pool[i].e0, h->pool[i].e1) == hipSuccess) {
+            h->timers[h->pool[i].kernel].total_ms += ms;
+            h->timers[h->pool[i].kernel].launches += 1;
+        }
+    }
+    h->pool_used = 0;
+}
+
 #define ARGCHK(cond, msg) do { if (!(cond)) { pyvb_set_error("%s", msg); return PYVB_E_ARG; } } while (0)
 
 extern "C" {
@@ -61,8 +82,8 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
 #define TRY(x) do { rc = (x); if (rc != PYVB_OK) { pyvb_lds_destroy(h); return rc; } } while (0)
 #define TRYHIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { rc = pyvb_hip_fail(_e, #x, __FILE__, __LINE__); pyvb_lds_destroy(h); return rc; } } while (0)
     TRYHIP(hipStreamCreate(&h->stream));
-    TRYHIP(hipEventCreate(&h->ev0));
-    TRYHIP(hipEventCreate(&h->ev1));
+    h->pool = (EventPair*)calloc(PYVB_EVENT_POOL, sizeof(EventPair));
+    for (int i = 0; i < PYVB_EVENT_POOL; ++i) { TRYHIP(hipEventCreate(&h->pool[i].e0)); TRYHIP(hipEventCreate(&h->pool[i].e1)); }
     const size_t n = (size_t)N;
     TRY(dev_alloc(&h->Y, n * T * K));
     TRY(dev_alloc(&h->Syy, n * K));
@@ -129,8 +150,10 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
     if (h->status) (void)hipFree(h->status);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->pool) {
+        for (int i = 0; i < PYVB_EVENT_POOL; ++i) { if (h->pool[i].e0) (void)hipEventDestroy(h->pool[i].e0); if (h->pool[i].e1) (void)hipEventDestroy(h->pool[i].e1); }
+        free(h->pool);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     free(h->fresh);
     delete h;
@@ -442,10 +465,11 @@ int pyvb_lds_sync(pyvb_lds* h) {
 }
 
 int pyvb_lds_timing_enable(pyvb_lds* h, int on) { ENTER(h); h->timing = on != 0; return PYVB_OK; }
-int pyvb_lds_timing_reset(pyvb_lds* h) { ENTER(h); memset(h->timers, 0, sizeof(h->timers)); return PYVB_OK; }
+int pyvb_lds_timing_reset(pyvb_lds* h) { ENTER(h); pyvb_timing_resolve(h); memset(h->timers, 0, sizeof(h->timers)); return PYVB_OK; }
 int pyvb_lds_timing_get(pyvb_lds* h, int kernel, double* total_ms, int* launches) {
     ENTER(h);
     ARGCHK(kernel >= 0 && kernel < PYVB_K_COUNT, "no such kernel id");
+    pyvb_timing_resolve(h);
     if (total_ms) *total_ms = h->timers[kernel].total_ms;
     if (launches) *launches = h->timers[kernel].launches;
     return PYVB_OK;

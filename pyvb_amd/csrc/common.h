@@ -52,6 +52,7 @@ struct Priors {          // device pointers, shared by all replicates
     double x0_lndet;     // ln det of x0_prec (Constant.lndet, node.py:301-302)
 };
 
+struct EventPair;
 struct KernelTimer {
     double total_ms; int launches;
 };
@@ -60,7 +61,7 @@ struct pyvb_lds {
     int device, N, T, D, K, noise;
     Layout L;
     hipStream_t stream;
-    hipEvent_t ev0, ev1;
+    struct EventPair* pool; int pool_used;
     // state
     double *Y, *Syy;                // [N][T][K], [N][K] (sum_t y^2)
     double *X[2]; int cur;          // ping-pong [N][T][D]
@@ -103,16 +104,14 @@ void pyvb_set_error(const char* fmt, ...);
 int pyvb_hip_fail(hipError_t e, const char* what, const char* file, int line);
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return pyvb_hip_fail(_e, #x, __FILE__, __LINE__); } while (0)
 
-// timed launch bracket: records events on the handle's stream when timing is enabled
+// Timed launch bracket.  When timing is on, an event pair from the handle's pool is recorded
+// around the launch on the handle's stream; nothing synchronises until pyvb_lds_timing_get(),
+// so timing can stay on inside a measured region.
+#define PYVB_EVENT_POOL 2048
+struct EventPair { hipEvent_t e0, e1; int kernel; };
 struct TimedLaunch {
-    pyvb_lds* h; int k;
-    TimedLaunch(pyvb_lds* h_, int k_) : h(h_), k(k_) { if (h->timing) (void)hipEventRecord(h->ev0, h->stream); }
-    ~TimedLaunch() {
-        if (h->timing) {
-            (void)hipEventRecord(h->ev1, h->stream);
-            (void)hipEventSynchronize(h->ev1);
-            float ms = 0; (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
-            h->timers[k].total_ms += ms; h->timers[k].launches += 1;
-        }
-    }
+    pyvb_lds* h; int slot;
+    TimedLaunch(pyvb_lds* h_, int k_);
+    ~TimedLaunch();
 };
+void pyvb_timing_resolve(pyvb_lds* h);
