@@ -76,6 +76,7 @@ struct pyvb_lds {
     double *gains;                  // [N][L.gains_total]
     double *scratch;                // [N][2][DP][DP] (M_C, M_A + M_C)
     int *warm;                      // [N][2]
+    double *trash;                  // [N][64] dump row for masked-out stores of the sweep
     double *stats; int nchunk, chunk_len;   // [N][nchunk][L.stats_total]
     double *resQ, *resR;            // [N][D], [N][K]
     double *elbo, *elbo_sum;        // [N][6], [6]

@@ -1,13 +1,17 @@
 // k_prep: everything that depends only on the parameter posteriors and is shared by all
 // X_t of one replicate: <A^T Q A>, <C^T R C>, the three posterior precisions of the states,
-// their Cholesky factors / inverses / q_ln_det, the gain matrices, and the warm-up length
-// of the segmented sweeps.
+// their inverses / q_ln_det, the gain matrices, and the warm-up length of the segmented sweeps.
 //
 // Reference work replaced (per X_t.update(), 2T times per iteration in the reference):
 //   Multiplication.pass_up_m1_m2, hstack branch    node.py:213-227   (<A^T Q A>, the D^4 tensor)
 //   qprec = pprec + sum m1 ; cho_factor ; cho_solve gaussian.py:117-119
 //   q_ln_det (quirk Q1)                             gaussian.py:120
-// One workgroup per replicate; all D x D work stays in LDS.
+//
+// One 256-thread workgroup per replicate, every matrix in LDS (row stride DP+2 doubles, which
+// makes the MFMA A-operand reads bank-conflict free).  All D x D products run on
+// v_mfma_f64_16x16x4_f64, one row tile per wavefront.  The posterior precisions are inverted in
+// place by Gauss-Jordan elimination without pivoting (they are symmetric positive definite); its
+// pivots are the squares of the Cholesky diagonal, which gives the reference's q_ln_det.
 #include "common.h"
 
 struct PrepArgs {
@@ -19,43 +23,9 @@ struct PrepArgs {
 };
 
 #define PREP_THREADS 256
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-__device__ static void chol_lower(double* W, int D, int tid, int* status, int n) {
-    for (int j = 0; j < D; ++j) {
-        if (tid == 0) {
-            double piv = W[j * D + j];
-            if (!(piv > 0.0)) atomicOr(status, 1);
-            W[j * D + j] = sqrt(piv);
-        }
-        __syncthreads();
-        double d = W[j * D + j];
-        for (int i = j + 1 + tid; i < D; i += PREP_THREADS) W[i * D + j] /= d;
-        __syncthreads();
-        int rem = D - j - 1;
-        for (int idx = tid; idx < rem * rem; idx += PREP_THREADS) {
-            int i = j + 1 + idx / rem, k = j + 1 + idx % rem;
-            if (k <= i) W[i * D + k] -= W[i * D + j] * W[k * D + j];
-        }
-        __syncthreads();
-    }
-}
-
-// Z = L^{-1} (lower triangular), one thread per column
-__device__ static void tri_inverse(const double* Lw, double* Z, int D, int tid) {
-    if (tid < D) {
-        int j = tid;
-        for (int i = 0; i < j; ++i) Z[i * D + j] = 0.0;
-        Z[j * D + j] = 1.0 / Lw[j * D + j];
-        for (int i = j + 1; i < D; ++i) {
-            double s = 0.0;
-            for (int k = j; k < i; ++k) s += Lw[i * D + k] * Z[k * D + j];
-            Z[i * D + j] = -s / Lw[i * D + i];
-        }
-    }
-    __syncthreads();
-}
-
-// position of matrix element (i, j) in an MFMA A-operand block with S k-steps
+// position of matrix element (i, j) in an MFMA A-operand block with S k-steps (see common.h)
 __device__ __forceinline__ size_t pos_nat(int i, int j, int S) {
     return ((size_t)((i >> 4) * S + (j >> 2)) * 64) + (j & 3) * 16 + (i & 15);
 }
@@ -64,21 +34,59 @@ __device__ __forceinline__ size_t pos_perm(int i, int j, int S) {
     return ((size_t)((i >> 4) * S + s) * 64) + q * 16 + (i & 15);
 }
 
-// C = A * A for D x D matrices in LDS
-__device__ static void mat_square(const double* A, double* C, int D, int tid) {
-    for (int idx = tid; idx < D * D; idx += PREP_THREADS) {
-        int i = idx / D, j = idx % D;
-        double s = 0.0;
-        for (int k = 0; k < D; ++k) s += A[i * D + k] * A[k * D + j];
-        C[idx] = s;
+// C = A * B on the matrix cores: C is [16*MT x 16*NT], the contraction runs over 4*KS.
+// a_at(i, k) / b_at(k, j) fetch operand elements (from LDS), store(i, j, v) consumes results.
+// Wavefront w owns row tiles w, w+4, ...
+template <int MT, int NT, int KS, class FA, class FB, class FS>
+__device__ __forceinline__ void mm(int wave, int lane, FA a_at, FB b_at, FS store) {
+    const int r = lane & 15, q = lane >> 4;
+    for (int m = wave; m < MT; m += 4) {
+        d4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = d4{0, 0, 0, 0};
+        for (int s = 0; s < KS; ++s) {
+            const double av = a_at(16 * m + r, 4 * s + q);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = MFMA(av, b_at(4 * s + q, 16 * n + r), acc[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store(16 * m + 4 * e + q, 16 * n + r, acc[n][e]);
     }
-    __syncthreads();
 }
 
-__device__ static double inf_norm(const double* A, int D, int tid, double* red) {
+// In-place inverse of the leading D x D block of the SPD matrix P (row stride LD) by Gauss-Jordan
+// elimination; returns sum_p log(pivot_p) = 2 * sum log diag(chol(P)).  rowp/colp: scratch [64].
+__device__ static double gj_inverse(double* P, int LD, int D, int tid, double* rowp, double* colp, int* status) {
+    const int tj = tid & 63, ti = tid >> 6;
+    double logdet = 0.0;
+    for (int p = 0; p < D; ++p) {
+        if (tid < D) { rowp[tid] = P[p * LD + tid]; colp[tid] = P[tid * LD + p]; }
+        __syncthreads();
+        const double piv = rowp[p];
+        if (tid == 0 && !(piv > 0.0)) atomicOr(status, 1);
+        logdet += log(piv);
+        const double d = 1.0 / piv;
+        if (tj < D) {
+            const double rj = rowp[tj] * d;
+            for (int i = ti; i < D; i += 4) {
+                double v;
+                if (i == p) v = (tj == p) ? d : rj;
+                else if (tj == p) v = -colp[i] * d;
+                else v = P[i * LD + tj] - colp[i] * rj;
+                P[i * LD + tj] = v;
+            }
+        }
+        __syncthreads();
+    }
+    return logdet;
+}
+
+__device__ static double inf_norm(const double* A, int LD, int D, int tid, double* red) {
     if (tid < D) {
         double s = 0.0;
-        for (int j = 0; j < D; ++j) s += fabs(A[tid * D + j]);
+        for (int j = 0; j < D; ++j) s += fabs(A[tid * LD + j]);
         red[tid] = s;
     }
     __syncthreads();
@@ -89,40 +97,45 @@ __device__ static double inf_norm(const double* A, int D, int tid, double* red) 
 }
 
 // Number of recurrence steps after which the influence of the starting state of
-// x_t = M x_{t-1} + c_t is below 1e-18 relative: ||M^J|| <= ||M^(2^k)||^(J/2^k).
-// M is in W1 on entry; W1/W2 are clobbered.
-__device__ static int warmup_length(double* W1, double* W2, int D, int tid, double* red) {
+// x_t = M x_{t-1} + c_t is below 1e-18 relative: ||M^J|| <= ||M^(2^k)||^(J/2^k) (any induced norm).
+// M is in W1 (padded with zeros) on entry; W1/W2 are clobbered.
+template <int DT>
+__device__ static int warmup_length(double* W1, double* W2, int LD, int D, int tid, double* red) {
+    constexpr int DS = 4 * DT;
     const double lntol = -41.4465316738928;   // ln(1e-18)
+    const int wave = tid >> 6, lane = tid & 63;
     int best = 1 << 30;
-    mat_square(W1, W2, D, tid);   // M^2
-    mat_square(W2, W1, D, tid);   // M^4
     double* src = W1; double* dst = W2;
-    for (int k = 3; k <= 5; ++k) {
-        mat_square(src, dst, D, tid);         // M^(2^k)
-        double nrm = inf_norm(dst, D, tid, red);
-        if (nrm < 1.0) {
-            double steps = (nrm > 0.0) ? ceil(lntol / log(nrm)) : 1.0;
-            double J = (double)(1 << k) * steps;
-            if (J < (double)best) best = (int)J;
+    for (int k = 1; k <= 5; ++k) {
+        mm<DT, DT, DS>(wave, lane,
+                       [&](int i, int kk) { return src[i * LD + kk]; },
+                       [&](int kk, int j) { return src[kk * LD + j]; },
+                       [&](int i, int j, double v) { dst[i * LD + j] = v; });      // M^(2^k)
+        __syncthreads();
+        if (k >= 3) {
+            const double nrm = inf_norm(dst, LD, D, tid, red);
+            if (nrm < 1.0) {
+                const double steps = (nrm > 0.0) ? ceil(lntol / log(nrm)) : 1.0;
+                const double J = (double)(1 << k) * steps;
+                if (J < (double)best) best = (int)J;
+            }
         }
         double* t = src; src = dst; dst = t;
     }
     return best;
 }
 
-template <int DMAX>
+template <int DT, int KT>
 __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
-    __shared__ double sm[4 * DMAX * DMAX + 256];   // static: up to 133 KB of the CU's 160 KB at DMAX = 64
+    constexpr int DP = 16 * DT, KP = 16 * KT, DS = 4 * DT, KS = 4 * KT, LD = DP + 2;
+    __shared__ double sA[DP * LD];       // <A>  [row k][col i], zero padded
+    __shared__ double sC[KP * LD];       // <C>  [row k][col i], zero padded
+    __shared__ double P[DP * LD];        // posterior precision -> covariance
+    __shared__ double W[DP * LD];        // work
+    __shared__ double qbar[64], rbar[64], rowp[64], colp[64], vec[64];
     const int n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
+    const int wave = tid >> 6, lane = tid & 63, tj = tid & 63, ti = tid >> 6;
     const Layout& L = a.L;
-    double* sA = sm;                 // [D][D]   <A> row-major
-    double* W1 = sA + D * D;
-    double* W2 = W1 + D * D;
-    double* W3 = W2 + D * D;
-    double* qbar = W3 + D * D;       // [64]
-    double* rbar = qbar + 64;        // [64]
-    double* red = rbar + 64;         // [64]
-    double* vec = red + 64;          // [64]
     const double* Am = a.A_mean + (size_t)n * D * D;
     const double* Av = a.A_var + (size_t)n * D * D;
     const double* Cm = a.C_mean + (size_t)n * K * D;
@@ -130,85 +143,92 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     double* g = a.gains + (size_t)n * L.gains_total;
     double* sc = a.scratch + (size_t)n * 2 * D * D;
 
-    if (tid < D) qbar[tid] = a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid];
-    if (tid < K) rbar[tid] = a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid];
-    for (int idx = tid; idx < D * D; idx += PREP_THREADS) sA[idx] = Am[idx];
-    __syncthreads();
-
-    // <C^T R C> and <A^T Q A> (node.py:213-227): mean part + trace of the column covariances on the diagonal
-    for (int idx = tid; idx < D * D; idx += PREP_THREADS) {
-        int i = idx / D, j = idx % D;
-        double mc = 0.0, ma = 0.0;
-        for (int k = 0; k < K; ++k) mc += Cm[k * D + i] * rbar[k] * Cm[k * D + j];
-        for (int k = 0; k < D; ++k) ma += sA[k * D + i] * qbar[k] * sA[k * D + j];
-        if (i == j) {
-            double tc = 0.0, ta = 0.0;
-            for (int k = 0; k < K; ++k) tc += Cv[i * K + k] * rbar[k];
-            for (int k = 0; k < D; ++k) ta += Av[i * D + k] * qbar[k];
-            mc += tc; ma += ta;
-        }
-        sc[idx] = mc;
-        sc[D * D + idx] = mc + ma;
+    if (tid < 64) {
+        qbar[tid] = (tid < D) ? a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid] : 0.0;
+        rbar[tid] = (tid < K) ? a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid] : 0.0;
     }
+    for (int idx = tid; idx < DP * LD; idx += PREP_THREADS) {
+        const int i = idx / LD, j = idx % LD;
+        sA[idx] = (i < D && j < D) ? Am[i * D + j] : 0.0;
+        W[idx] = 0.0;
+        P[idx] = 0.0;
+    }
+    for (int idx = tid; idx < KP * LD; idx += PREP_THREADS) {
+        const int i = idx / LD, j = idx % LD;
+        sC[idx] = (i < K && j < D) ? Cm[i * D + j] : 0.0;
+    }
+    __syncthreads();
+    // traces of the column covariances against the noise expectations (diagonal of node.py:223-227)
+    if (tid < D) {
+        double tc = 0.0, ta = 0.0;
+        for (int k = 0; k < K; ++k) tc += Cv[tid * K + k] * rbar[k];
+        for (int k = 0; k < D; ++k) ta += Av[tid * D + k] * qbar[k];
+        rowp[tid] = tc; colp[tid] = ta;
+    }
+    __syncthreads();
+    // <C^T R C> -> scratch[0];  <C^T R C> + <A^T Q A> -> scratch[1]     (node.py:213-227)
+    mm<DT, DT, KS>(wave, lane,
+                   [&](int i, int k) { return sC[k * LD + i] * rbar[k]; },
+                   [&](int k, int j) { return sC[k * LD + j]; },
+                   [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += rowp[i]; sc[i * D + j] = v; W[i * LD + j] = v; } });
+    __syncthreads();
+    mm<DT, DT, DS>(wave, lane,
+                   [&](int i, int k) { return sA[k * LD + i] * qbar[k]; },
+                   [&](int k, int j) { return sA[k * LD + j]; },
+                   [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += colp[i]; sc[D * D + i * D + j] = W[i * LD + j] + v; } });
     __syncthreads();
 
     const int order[3] = {0, 2, 1};
     for (int oi = 0; oi < 3; ++oi) {
         const int cls = order[oi];
         // qprec = pprec + (m1 from Mult(C,.) + m1 from Mult(A,.))   gaussian.py:117
-        for (int idx = tid; idx < D * D; idx += PREP_THREADS) {
-            int i = idx / D, j = idx % D;
-            double base = (cls == 2) ? sc[idx] : sc[D * D + idx];
-            double prior = (cls == 0) ? a.x0_prec[idx] : (i == j ? qbar[i] : 0.0);
-            W1[idx] = prior + base;
-        }
+        if (tj < D)
+            for (int i = ti; i < D; i += 4) {
+                const double base = (cls == 2) ? sc[i * D + tj] : sc[D * D + i * D + tj];
+                const double prior = (cls == 0) ? a.x0_prec[i * D + tj] : (i == tj ? qbar[i] : 0.0);
+                P[i * LD + tj] = prior + base;
+            }
         __syncthreads();
-        chol_lower(W1, D, tid, a.status, n);
-        if (tid == 0) {
-            double s = 0.0;
-            for (int j = 0; j < D; ++j) s += log(W1[j * D + j]);
-            a.qld[(size_t)n * 3 + cls] = 0.5 / s;              // gaussian.py:120 (quirk Q1)
-        }
-        tri_inverse(W1, W2, D, tid);
-        for (int idx = tid; idx < D * D; idx += PREP_THREADS) {
-            int i = idx / D, j = idx % D;
-            int k0 = i > j ? i : j;
-            double s = 0.0;
-            for (int k = k0; k < D; ++k) s += W2[k * D + i] * W2[k * D + j];
-            W3[idx] = s;                                        // qcov = qprec^{-1}   gaussian.py:119
-            a.Sigma[((size_t)n * 3 + cls) * D * D + idx] = s;
-        }
-        __syncthreads();
+        const double logdet = gj_inverse(P, LD, D, tid, rowp, colp, a.status);        // qcov, gaussian.py:118-119
+        if (tid == 0) a.qld[(size_t)n * 3 + cls] = 0.5 / (0.5 * logdet);             // gaussian.py:120 (quirk Q1)
+        if (tj < D)
+            for (int i = ti; i < D; i += 4) a.Sigma[((size_t)n * 3 + cls) * D * D + i * D + tj] = P[i * LD + tj];
 
         // gains of this class
         double* FT = g + (cls == 1 ? L.oFT : L.oFLT);
         double* BT = g + (cls == 1 ? L.oBT : L.oB0T);
         double* GT = g + (cls == 1 ? L.oGT : (cls == 0 ? L.oG0T : L.oGLT));
-        for (int idx = tid; idx < D * D; idx += PREP_THREADS) {
-            int i = idx / D, j = idx % D;
-            if (cls != 0) {         // Sigma <Q><A>: multiplies the mean of X_{t-1}
-                double s = 0.0;
-                for (int k = 0; k < D; ++k) s += W3[i * D + k] * (qbar[k] * sA[k * D + j]);
-                FT[(size_t)j * L.DP + i] = s;
-                if (cls == 1) { g[L.oFn + pos_nat(i, j, L.DS)] = s; g[L.oFp + pos_perm(i, j, L.DS)] = s; }
-            }
-            if (cls != 2) {         // Sigma <A>^T<Q>: multiplies the mean of X_{t+1}
-                double s = 0.0;
-                for (int k = 0; k < D; ++k) s += W3[i * D + k] * sA[j * D + k];
-                s *= qbar[j];
-                BT[(size_t)j * L.DP + i] = s;
-                if (cls == 1) { g[L.oBn + pos_nat(i, j, L.DS)] = s; g[L.oBp + pos_perm(i, j, L.DS)] = s; }
-            }
-        }
-        for (int idx = tid; idx < D * K; idx += PREP_THREADS) {
-            int i = idx / K, l = idx % K;   // Sigma <C>^T<R>: multiplies y_t
-            double s = 0.0;
-            for (int k = 0; k < D; ++k) s += W3[i * D + k] * Cm[l * D + k];
-            s *= rbar[l];
-            GT[(size_t)l * L.DP + i] = s;
-            if (cls == 1) g[L.oGp + pos_perm(i, l, L.KS)] = s;
-        }
-        if (cls == 0) {             // h0 = Sigma_0 (L0 m0): the Constant mean parent of X_0
+        if (cls != 0)       // Sigma <Q><A>: multiplies the mean of X_{t-1}
+            mm<DT, DT, DS>(wave, lane,
+                           [&](int i, int k) { return P[i * LD + k]; },
+                           [&](int k, int j) { return qbar[k] * sA[k * LD + j]; },
+                           [&](int i, int j, double v) {
+                               if (i < D && j < D) {
+                                   FT[(size_t)j * DP + i] = v;
+                                   if (cls == 1) { g[L.oFn + pos_nat(i, j, DS)] = v; g[L.oFp + pos_perm(i, j, DS)] = v; W[i * LD + j] = v; }
+                               }
+                           });
+        if (cls != 2)       // Sigma <A>^T<Q>: multiplies the mean of X_{t+1}
+            mm<DT, DT, DS>(wave, lane,
+                           [&](int i, int k) { return P[i * LD + k]; },
+                           [&](int k, int j) { return sA[j * LD + k] * qbar[j]; },
+                           [&](int i, int j, double v) {
+                               if (i < D && j < D) {
+                                   BT[(size_t)j * DP + i] = v;
+                                   if (cls == 1) { g[L.oBn + pos_nat(i, j, DS)] = v; g[L.oBp + pos_perm(i, j, DS)] = v; }
+                               }
+                           });
+        // Sigma <C>^T<R>: multiplies y_t
+        mm<DT, KT, DS>(wave, lane,
+                       [&](int i, int k) { return P[i * LD + k]; },
+                       [&](int k, int l) { return sC[l * LD + k] * rbar[l]; },
+                       [&](int i, int l, double v) {
+                           if (i < D && l < K) {
+                               GT[(size_t)l * DP + i] = v;
+                               if (cls == 1) g[L.oGp + pos_perm(i, l, KS)] = v;
+                           }
+                       });
+        if (cls == 0) {     // h0 = Sigma_0 (L0 m0): the Constant mean parent of X_0
             if (tid < D) {
                 double s = 0.0;
                 for (int j = 0; j < D; ++j) s += a.x0_prec[tid * D + j] * a.x0_mean[j];
@@ -217,27 +237,30 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
             __syncthreads();
             if (tid < D) {
                 double s = 0.0;
-                for (int k = 0; k < D; ++k) s += W3[tid * D + k] * vec[k];
+                for (int k = 0; k < D; ++k) s += P[tid * LD + k] * vec[k];
                 g[L.oh0 + tid] = s;
             }
         }
         __syncthreads();
     }
 
-    // warm-up lengths of the segmented sweeps: forward recurrence matrix F, backward B (W3 = Sigma_1)
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int idx = tid; idx < D * D; idx += PREP_THREADS) {
-            int i = idx / D, j = idx % D;
-            double s = 0.0;
-            if (pass == 0) { for (int k = 0; k < D; ++k) s += W3[i * D + k] * (qbar[k] * sA[k * D + j]); }
-            else { for (int k = 0; k < D; ++k) s += W3[i * D + k] * sA[j * D + k]; s *= qbar[j]; }
-            W1[idx] = s;
-        }
-        __syncthreads();
-        int J = warmup_length(W1, W2, D, tid, red);
-        if (tid == 0) a.warm[n * 2 + pass] = J;
-        __syncthreads();
+    // warm-up lengths of the segmented sweeps.  W holds F (forward recurrence matrix); the backward
+    // one, B, is read back transposed (powers of B^T in the inf-norm = powers of B in the 1-norm).
+    int J = warmup_length<DT>(W, P, LD, D, tid, rowp);
+    if (tid == 0) a.warm[n * 2 + 0] = J;
+    __syncthreads();
+    for (int idx = tid; idx < DP * LD; idx += PREP_THREADS) {
+        const int i = idx / LD, j = idx % LD;
+        W[idx] = (i < D && j < D) ? g[L.oBT + (size_t)i * DP + j] : 0.0;
     }
+    __syncthreads();
+    J = warmup_length<DT>(W, P, LD, D, tid, rowp);
+    if (tid == 0) a.warm[n * 2 + 1] = J;
+}
+
+template <int DT, int KT>
+static void launch_prep_t(pyvb_lds* h, const PrepArgs& a) {
+    hipLaunchKernelGGL((k_prep<DT, KT>), dim3(h->N), dim3(PREP_THREADS), 0, h->stream, a);
 }
 
 int launch_prep(pyvb_lds* h) {
@@ -248,10 +271,21 @@ int launch_prep(pyvb_lds* h) {
     a.Sigma = h->Sigma_new; a.qld = h->qld_x_new; a.gains = h->gains; a.scratch = h->scratch;
     a.warm = h->warm; a.status = h->status;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.L = h->L;
-    TimedLaunch tl(h, PYVB_K_PREP);
-    if (h->D <= 16) hipLaunchKernelGGL(k_prep<16>, dim3(h->N), dim3(PREP_THREADS), 0, h->stream, a);
-    else if (h->D <= 32) hipLaunchKernelGGL(k_prep<32>, dim3(h->N), dim3(PREP_THREADS), 0, h->stream, a);
-    else hipLaunchKernelGGL(k_prep<64>, dim3(h->N), dim3(PREP_THREADS), 0, h->stream, a);
+    {
+        TimedLaunch tl(h, PYVB_K_PREP);
+        switch (h->L.DT * 10 + h->L.KT) {
+            case 11: launch_prep_t<1, 1>(h, a); break;
+            case 12: launch_prep_t<1, 2>(h, a); break;
+            case 14: launch_prep_t<1, 4>(h, a); break;
+            case 21: launch_prep_t<2, 1>(h, a); break;
+            case 22: launch_prep_t<2, 2>(h, a); break;
+            case 24: launch_prep_t<2, 4>(h, a); break;
+            case 41: launch_prep_t<4, 1>(h, a); break;
+            case 42: launch_prep_t<4, 2>(h, a); break;
+            case 44: launch_prep_t<4, 4>(h, a); break;
+            default: pyvb_set_error("unsupported tile shape"); return PYVB_E_ARG;
+        }
+    }
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

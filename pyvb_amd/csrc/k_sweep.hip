@@ -19,13 +19,15 @@
 
 struct SweepArgs {
     const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
+    double* trash;      // [N][64]: where lanes of inactive columns aim their (unconditional) stores
     int N, T, D, K, dir;
     Layout L;
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-template <int DT, int KT>
+// FULL: D == 16*DT and K == 16*KT (no padded rows/columns, 16-byte aligned rows)
+template <int DT, int KT, bool FULL>
 __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     constexpr int DS = 4 * DT, KS = 4 * KT, DP = 16 * DT;
     __shared__ double gl[DT * KS * 64];     // G as MFMA A operands
@@ -90,70 +92,98 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
 
         // time index of this column at loop index j:  t = tbase + sgn * j
         const int tbase = fwd ? (1 + cL) : (T - 2 - cL);
+        const int tsafe = fwd ? 1 : T - 2;      // an interior row that always exists: what inactive columns read
         auto active = [&](int j) { int tt = cL + j; return j >= jc && tt < Tint; };
-        // input registers: y_t and the old neighbour mean, as B operands in permuted k order
+        // input registers: y_t and the old neighbour mean, as B operands in permuted k order.
+        // Loads are unconditional and unmasked: an inactive column reads a valid row and computes
+        // a value that the select after the step discards (MFMA columns do not mix), and padded
+        // k positions meet zero matrix entries.  So a step's loads issue back to back with no
+        // branch and no use until the next step.
         d2 yv[KS / 2], mo[DS / 2];
         auto load_y = [&](int j, d2* dst) {
-            const bool act = active(j);
-            const double* p = Yn + (size_t)(tbase + sgn * j) * K;
+            const double* p = Yn + (size_t)(active(j) ? tbase + sgn * j : tsafe) * K;
 #pragma unroll
             for (int i = 0; i < KS / 2; ++i) {
-                int d0 = 8 * i + 2 * q;
-                dst[i][0] = (act && d0 < K) ? p[d0] : 0.0;
-                dst[i][1] = (act && d0 + 1 < K) ? p[d0 + 1] : 0.0;
+                const int d0 = 8 * i + 2 * q;
+                if constexpr (FULL) {
+                    dst[i] = *reinterpret_cast<const d2*>(p + d0);
+                } else {
+                    dst[i][0] = p[d0 < K ? d0 : K - 1];
+                    dst[i][1] = p[d0 + 1 < K ? d0 + 1 : K - 1];
+                }
             }
         };
         auto load_o = [&](int j, d2* dst) {
-            const bool act = active(j);
-            const double* p = Xo + (size_t)(tbase + sgn * j + sgn) * D;
+            const double* p = Xo + (size_t)((active(j) ? tbase + sgn * j : tsafe) + sgn) * D;
 #pragma unroll
             for (int i = 0; i < DS / 2; ++i) {
-                int d0 = 8 * i + 2 * q;
-                dst[i][0] = (act && d0 < D) ? p[d0] : 0.0;
-                dst[i][1] = (act && d0 + 1 < D) ? p[d0 + 1] : 0.0;
+                const int d0 = 8 * i + 2 * q;
+                if constexpr (FULL) {
+                    dst[i] = *reinterpret_cast<const d2*>(p + d0);
+                } else {
+                    dst[i][0] = p[d0 < D ? d0 : D - 1];
+                    dst[i][1] = p[d0 + 1 < D ? d0 + 1 : D - 1];
+                }
             }
         };
+        auto store_x = [&](double* out) {
+#pragma unroll
+            for (int m = 0; m < DT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dim = 16 * m + 4 * r + q;
+                    if (FULL || dim < D) out[dim] = x[m][r];
+                }
+        };
+        // Stores are unconditional too (a branch around them would make the compiler's in-order
+        // vmcnt bookkeeping conservative and stall on loads just issued): lanes with nothing to
+        // store write to a per-replicate trash row.
+        double* const trash = a.trash + (size_t)n * 64;
+        double* out_pending = trash;
         load_y(jstart, yv);
         load_o(jstart, mo);
         for (int j = jstart; j < Lseg; ++j) {
             d4 acc[DT];
 #pragma unroll
             for (int m = 0; m < DT; ++m) acc[m] = d4{0.0, 0.0, 0.0, 0.0};
-            // G y_t
+            // G y_t.  The LDS offset is made opaque per iteration: G is loop invariant and the
+            // compiler would otherwise hoist all of it into registers that R and I already fill.
+            int goff = lane;
+            asm volatile("" : "+v"(goff));
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int m = 0; m < DT; ++m) acc[m] = MFMA(gl[(m * KS + s) * 64 + lane], yv[s >> 1][s & 1], acc[m]);
-            d2 yv_n[KS / 2];
-            load_y(j + 1, yv_n);
+                for (int m = 0; m < DT; ++m) acc[m] = MFMA(gl[(m * KS + s) * 64 + goff], yv[s >> 1][s & 1], acc[m]);
+            // Store the PREVIOUS step's state here, ahead of the loads: vector-memory operations
+            // retire in order, so this keeps the wait for y at the top of the next step from also
+            // waiting on stores issued just before it.
+            __builtin_amdgcn_sched_barrier(0);
+            store_x(out_pending);
+            // y of the next step goes into the registers just consumed; it has the I and R blocks
+            // (>= 2/3 of a step) to arrive.  The scheduling barriers keep the issue point here.
+            load_y(j + 1, yv);
+            __builtin_amdgcn_sched_barrier(0);
             // I mu_{t+dir} (old)
 #pragma unroll
             for (int s = 0; s < DS; ++s)
 #pragma unroll
                 for (int m = 0; m < DT; ++m) acc[m] = MFMA(ip[m][s], mo[s >> 1][s & 1], acc[m]);
-            d2 mo_n[DS / 2];
-            load_o(j + 1, mo_n);
+            __builtin_amdgcn_sched_barrier(0);
+            load_o(j + 1, mo);
+            __builtin_amdgcn_sched_barrier(0);
             // R mu_{t-dir} (new): the previous accumulators are the B operands
 #pragma unroll
             for (int s = 0; s < DS; ++s)
 #pragma unroll
                 for (int m = 0; m < DT; ++m) acc[m] = MFMA(rn[m][s], x[s >> 2][s & 3], acc[m]);
             const bool act = active(j);
-            double* out = Xn + (size_t)(tbase + sgn * j) * D;
 #pragma unroll
             for (int m = 0; m < DT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double v = act ? acc[m][r] : x[m][r];
-                    x[m][r] = v;
-                    int dim = 16 * m + 4 * r + q;
-                    if (act && j >= 0 && dim < D) out[dim] = v;
-                }
-#pragma unroll
-            for (int i = 0; i < KS / 2; ++i) yv[i] = yv_n[i];
-#pragma unroll
-            for (int i = 0; i < DS / 2; ++i) mo[i] = mo_n[i];
+                for (int r = 0; r < 4; ++r) x[m][r] = act ? acc[m][r] : x[m][r];
+            out_pending = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * D : trash;
         }
+        store_x(out_pending);
         // the column that holds the last interior node hands its state to the closing boundary step
         const int clast = (Tint - 1) / Lseg;
         __builtin_amdgcn_s_barrier();
@@ -208,13 +238,15 @@ __global__ void __launch_bounds__(64) k_step(StepArgs a) {
 
 template <int DT, int KT>
 static int launch_sweep_t(pyvb_lds* h, const SweepArgs& a) {
-    hipLaunchKernelGGL((k_sweep<DT, KT>), dim3(h->N), dim3(64), 0, h->stream, a);
+    if (h->D == 16 * DT && h->K == 16 * KT) hipLaunchKernelGGL((k_sweep<DT, KT, true>), dim3(h->N), dim3(64), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_sweep<DT, KT, false>), dim3(h->N), dim3(64), 0, h->stream, a);
     return PYVB_OK;
 }
 
 int launch_sweep(pyvb_lds* h, int direction) {
     SweepArgs a;
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
+    a.trash = h->trash;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
     {
         TimedLaunch tl(h, PYVB_K_SWEEP);
