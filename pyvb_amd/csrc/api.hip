@@ -113,6 +113,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     nchunk = (T + clen - 1) / clen;
     h->nchunk = nchunk; h->chunk_len = clen;
     TRY(dev_alloc(&h->stats, n * nchunk * L.stats_total));
+    TRY(dev_alloc(&h->mom, n * ((size_t)3 * D * D + (size_t)K * D + D)));
     TRY(dev_alloc(&h->resQ, n * D)); TRY(dev_alloc(&h->resR, n * K));
     TRY(dev_alloc(&h->elbo, n * 6)); TRY(dev_alloc(&h->elbo_sum, 8));
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int)));
@@ -147,7 +148,7 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     pyvb_lds_comm_destroy(h);
     double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
-                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash};
+                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->mom};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
     if (h->status) (void)hipFree(h->status);
@@ -345,6 +346,7 @@ static int ensure_stats(pyvb_lds* h) {
     }
     int rc = launch_stats(h);
     if (rc) return rc;
+    if ((rc = launch_moments(h))) return rc;
     h->stats_valid = true;
     return PYVB_OK;
 }

@@ -78,6 +78,7 @@ struct pyvb_lds {
     int *warm;                      // [N][2]
     double *trash;                  // [N][64] dump row for masked-out stores of the sweep
     double *stats; int nchunk, chunk_len;   // [N][nchunk][L.stats_total]
+    double *mom;                    // [N][3 D^2 + K D + D] second moments (k_moments)
     double *resQ, *resR;            // [N][D], [N][K]
     double *elbo, *elbo_sum;        // [N][6], [6]
     int *status;                    // device flag: nonzero if a Cholesky failed
@@ -95,6 +96,7 @@ int launch_sweep(pyvb_lds* h, int direction);
 int launch_step(pyvb_lds* h, int t);
 int launch_syy(pyvb_lds* h);
 int launch_stats(pyvb_lds* h);
+int launch_moments(pyvb_lds* h);
 int launch_cols(pyvb_lds* h, int which);      // 0 = A, 1 = C
 int launch_resid(pyvb_lds* h, int which);     // 0 = Q, 1 = R
 int launch_noise(pyvb_lds* h, int which);

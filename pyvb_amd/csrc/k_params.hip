@@ -15,6 +15,7 @@
 struct ParamArgs {
     // statistics
     const double* part; int nchunk; const double* Sigma; const double* qld_x; const double* X; const double* Syy;
+    double* mom;            // [N][mom_total]: see k_moments
     // parameters
     double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *qld_A, *qld_C;
     double *resQ, *resR, *elbo;
@@ -23,115 +24,173 @@ struct ParamArgs {
     Layout L;
 };
 
+// layout of the per-replicate moment block written by k_moments (all row-major, no padding)
+//   GA [D][D]  = sum_{t=0}^{T-2} <x x^T>      (children of hstack A: Mult(A, X_t))
+//   GC [D][D]  = sum_{t=0}^{T-1} <x x^T>      (children of hstack C)
+//   HA [D][D]  = sum_t mu_{t+1} mu_t^T        HC [K][D] = sum_t y_t mu_t^T
+//   dp [D]     = diag sum_{t=1}^{T-1} <x x^T> (children of Q)
+__host__ __device__ static inline size_t mom_total(int D, int K) { return (size_t)3 * D * D + (size_t)K * D + D; }
+#define MOM_GA(D, K) ((size_t)0)
+#define MOM_GC(D, K) ((size_t)(D) * (D))
+#define MOM_HA(D, K) ((size_t)2 * (D) * (D))
+#define MOM_HC(D, K) ((size_t)3 * (D) * (D))
+#define MOM_DP(D, K) ((size_t)3 * (D) * (D) + (size_t)(K) * (D))
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-// second-moment matrix of the states over a range of t, into LDS Gm[D][D]
-//   which = 0: t = 0..T-2 (children of hstack A)   1: t = 0..T-1 (children of hstack C)
-__device__ static void build_G(const ParamArgs& a, int n, int which, double* Gm, int lane) {
-    const int D = a.D, T = a.T, DP = a.L.DP;
+// value of v in lane j (j wave-uniform) for every lane: two v_readlane_b32, no LDS
+__device__ __forceinline__ double bcast(double v, int j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    return __hiloint2double(hi, lo);
+}
+
+// k_moments: reduce the chunk partials of k_stats and add the covariance classes
+// (<x x^T> = qmu qmu^T + qcov, gaussian.py:162-168), once per statistics pass, fully parallel.
+__global__ void __launch_bounds__(256) k_moments(ParamArgs a) {
+    const int n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K, T = a.T, DP = a.L.DP;
     const double* P = a.part + (size_t)n * a.nchunk * a.L.stats_total;
     const double* S = a.Sigma + (size_t)n * 3 * D * D;
-    const double* xL = a.X + ((size_t)n * T + (T - 1)) * D;
+    const double* x0 = a.X + (size_t)n * T * D;
+    const double* xL = x0 + (size_t)(T - 1) * D;
+    double* mo = a.mom + (size_t)n * mom_total(D, K);
     const double nint = (double)(T - 2);
-    for (int idx = lane; idx < D * D; idx += 64) {
-        int i = idx / D, j = idx % D;
-        double s = 0.0;
-        for (int ch = 0; ch < a.nchunk; ++ch) s += P[(size_t)ch * a.L.stats_total + a.L.oSxx + (size_t)i * DP + j];
-        s += S[idx] + nint * S[D * D + idx];
-        if (which == 0) s -= xL[i] * xL[j]; else s += S[2 * D * D + idx];
-        Gm[idx] = s;
+    for (int idx = tid; idx < D * D; idx += 256) {
+        const int i = idx / D, j = idx % D;
+        double xx = 0.0, h = 0.0;
+        for (int ch = 0; ch < a.nchunk; ++ch) {
+            const double* Pc = P + (size_t)ch * a.L.stats_total;
+            xx += Pc[a.L.oSxx + (size_t)i * DP + j];
+            h += Pc[a.L.oSx1x + (size_t)i * DP + j];
+        }
+        const double s0 = S[idx], s1 = S[D * D + idx], s2 = S[2 * D * D + idx];
+        mo[MOM_GA(D, K) + idx] = xx - xL[i] * xL[j] + s0 + nint * s1;
+        mo[MOM_GC(D, K) + idx] = xx + s0 + nint * s1 + s2;
+        mo[MOM_HA(D, K) + idx] = h;
+        if (i == j) mo[MOM_DP(D, K) + i] = xx - x0[i] * x0[i] + nint * s1 + s2;
+    }
+    for (int idx = tid; idx < K * D; idx += 256) {
+        const int k = idx / D, j = idx % D;
+        double h = 0.0;
+        for (int ch = 0; ch < a.nchunk; ++ch) h += P[(size_t)ch * a.L.stats_total + a.L.oSyx + (size_t)k * DP + j];
+        mo[MOM_HC(D, K) + idx] = h;
     }
 }
 
-// H[row][col] summed over chunks (Sx1x for A, Syx for C)
-__device__ __forceinline__ double stat_H(const ParamArgs& a, int n, int which, int row, int col) {
-    const double* P = a.part + (size_t)n * a.nchunk * a.L.stats_total + (which == 0 ? a.L.oSx1x : a.L.oSyx);
-    double s = 0.0;
-    for (int ch = 0; ch < a.nchunk; ++ch) s += P[(size_t)ch * a.L.stats_total + (size_t)row * a.L.DP + col];
-    return s;
-}
-
+// [a.update() for a in As] (WHICH = 0) / [c.update() for c in Cs] (WHICH = 1).
+// Lane k owns row k of the matrix; its row lives in LDS (Mb[col][lane]) together with its row of
+// H.  Row i of G is fetched one column ahead with one coalesced load and broadcast by readlane.
 template <int WHICH>
 __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
-    __shared__ double Gm[64 * 64];
     __shared__ double Mb[64 * 64];     // Mb[col * 64 + row]
-    const int n = blockIdx.x, lane = threadIdx.x, D = a.D;
-    const int rows = WHICH == 0 ? a.D : a.K;
+    __shared__ double Hb[64 * 64];
+    const int n = blockIdx.x, lane = threadIdx.x, D = a.D, K = a.K;
+    const int rows = WHICH == 0 ? D : K;
     double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
     double* V = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
     double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
     const double* pm = WHICH == 0 ? a.pri.A_pm : a.pri.C_pm;    // [row][col]
     const double* pp = WHICH == 0 ? a.pri.A_pp : a.pri.C_pp;    // [col][row]
+    const double* mo = a.mom + (size_t)n * mom_total(D, K);
+    const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
+    const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
     const bool live = lane < rows;
-    build_G(a, n, WHICH, Gm, lane);
-    double lam = 0.0;
-    if (live) {
-        lam = WHICH == 0 ? a.Q_a[(size_t)n * D + lane] / a.Q_b[(size_t)n * D + lane]
-                         : a.R_a[(size_t)n * a.K + lane] / a.R_b[(size_t)n * a.K + lane];
-        for (int j = 0; j < D; ++j) Mb[j * 64 + lane] = M[(size_t)lane * D + j];
+    const int lc = lane < D ? lane : D - 1;         // clamped column for the coalesced row loads
+    for (int k0 = 0; k0 < rows; k0 += 8) {          // transpose rows of M and H into LDS, 8 rows of loads in flight
+        double m[8], hh[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u < rows ? k0 + u : rows - 1;
+            m[u] = M[(size_t)k * D + lc];
+            hh[u] = H[(size_t)k * D + lc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < rows) { Mb[lc * 64 + k0 + u] = m[u]; Hb[lc * 64 + k0 + u] = hh[u]; }
     }
+    const double lam = live ? (WHICH == 0 ? a.Q_a[(size_t)n * D + lane] / a.Q_b[(size_t)n * D + lane]
+                                          : a.R_a[(size_t)n * K + lane] / a.R_b[(size_t)n * K + lane]) : 0.0;
+    const int lr = live ? lane : 0;                 // clamped row for the per-lane prior loads
+    double grow_n = G[lc], p0_n = pp[lr], pm_n = pm[(size_t)lr * D];
     __syncthreads();
     for (int i = 0; i < D; ++i) {
+        const double grow = grow_n, p0 = p0_n, m0 = pm_n;
+        const int in = i + 1 < D ? i + 1 : i;
+        grow_n = G[(size_t)in * D + lc];
+        p0_n = pp[(size_t)in * rows + lr];
+        pm_n = pm[(size_t)lr * D + in];
+        double acc = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < D; ++j) acc += Mb[j * 64 + lane] * bcast(grow, j);
+        const double gii = bcast(grow, i);
+        acc -= Mb[i * 64 + lane] * gii;                                        // j != i only
+        const double prec = p0 + lam * gii;                                    // qprec  gaussian.py:117
+        const double num = p0 * m0 + lam * (Hb[i * 64 + lane] - acc);
+        const double val = num / prec;                                         // qmu    gaussian.py:122-123
         double lp = 0.0;
         if (live) {
-            const double* Gi = Gm + i * D;
-            double acc = 0.0;
-            for (int j = 0; j < D; ++j) acc += (j == i) ? 0.0 : Mb[j * 64 + lane] * Gi[j];
-            const double p0 = pp[(size_t)i * rows + lane];
-            const double prec = p0 + lam * Gi[i];                                  // qprec  gaussian.py:117
-            const double num = p0 * pm[(size_t)lane * D + i] + lam * (stat_H(a, n, WHICH, lane, i) - acc);
-            const double val = num / prec;                                          // qmu    gaussian.py:122-123
             Mb[i * 64 + lane] = val;
-            M[(size_t)lane * D + i] = val;
-            V[(size_t)i * rows + lane] = 1.0 / prec;                                // qcov (diagonal)
-            lp = 0.5 * log(prec);                                                   // log of the Cholesky diagonal
+            V[(size_t)i * rows + lane] = 1.0 / prec;                           // qcov (diagonal)
+            lp = 0.5 * log(prec);                                              // log of the Cholesky diagonal
         }
         lp = wave_sum(lp);
-        if (lane == 0) qld[i] = 0.5 / lp;                                           // gaussian.py:120 (quirk Q1)
+        if (lane == 0) qld[i] = 0.5 / lp;                                      // gaussian.py:120 (quirk Q1)
     }
+    __syncthreads();
+    if (lane < D)
+        for (int k = 0; k < rows; ++k) M[(size_t)k * D + lane] = Mb[lane * 64 + k];
 }
 
+// res[k] = 1/2 own[k] + 1/2 <mu mu^T>[k,k] - (H M^T)[k,k]  for the children of Q (WHICH = 0) / R (1)
 template <int WHICH>
 __global__ void __launch_bounds__(64) k_resid(ParamArgs a) {
-    __shared__ double Gm[64 * 64];
     __shared__ double Mb[64 * 64];
-    const int n = blockIdx.x, lane = threadIdx.x, D = a.D, T = a.T;
-    const int rows = WHICH == 0 ? a.D : a.K;
+    const int n = blockIdx.x, lane = threadIdx.x, D = a.D, K = a.K;
+    const int rows = WHICH == 0 ? D : K;
     const double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
     const double* V = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
+    const double* mo = a.mom + (size_t)n * mom_total(D, K);
+    const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
+    const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
     const bool live = lane < rows;
-    build_G(a, n, WHICH, Gm, lane);
-    if (live) for (int j = 0; j < D; ++j) Mb[j * 64 + lane] = M[(size_t)lane * D + j];
+    const int lc = lane < D ? lane : D - 1, lr = live ? lane : 0;
+    double hm = 0.0;                                // (H M^T)[k,k] ends up in lane k
+    for (int k0 = 0; k0 < rows; k0 += 8) {
+        double m[8], hh[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u < rows ? k0 + u : rows - 1;
+            m[u] = M[(size_t)k * D + lc];
+            hh[u] = H[(size_t)k * D + lc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u;
+            if (k < rows) Mb[lc * 64 + k] = m[u];
+            const double s = wave_sum(lane < D ? m[u] * hh[u] : 0.0);
+            hm = (lane == k) ? s : hm;
+        }
+    }
+    const double own = WHICH == 0 ? mo[MOM_DP(D, K) + lr] : a.Syy[(size_t)n * K + lr];
+    double grow_n = G[lc], v_n = V[lr];
     __syncthreads();
-    if (!live) return;
-    // own second moment of the children: X_t, t = 1..T-1 (Q) or the observed Y_t (R)
-    double own;
-    if (WHICH == 0) {
-        const double* S = a.Sigma + (size_t)n * 3 * D * D;
-        const double* x0 = a.X + (size_t)n * T * D;
-        double s = 0.0;
-        const double* P = a.part + (size_t)n * a.nchunk * a.L.stats_total + a.L.oSxx;
-        for (int ch = 0; ch < a.nchunk; ++ch) s += P[(size_t)ch * a.L.stats_total + (size_t)lane * a.L.DP + lane];
-        own = s - x0[lane] * x0[lane] + (double)(T - 2) * S[D * D + lane * D + lane] + S[2 * D * D + lane * D + lane];
-    } else {
-        own = a.Syy[(size_t)n * a.K + lane];
-    }
     // <mu mu^T>[k,k] = sum_ij M[k,i] G[i,j] M[k,j] + sum_i var_i[k] G[i,i]      node.py:260-271
-    double e = 0.0, hm = 0.0;
+    double e = 0.0;
     for (int i = 0; i < D; ++i) {
-        const double* Gi = Gm + i * D;
+        const double grow = grow_n, vi = v_n;
+        const int in = i + 1 < D ? i + 1 : i;
+        grow_n = G[(size_t)in * D + lc];
+        v_n = V[(size_t)in * rows + lr];
         double t = 0.0;
-        for (int j = 0; j < D; ++j) t += Gi[j] * Mb[j * 64 + lane];
-        const double mi = Mb[i * 64 + lane];
-        e += mi * t + V[(size_t)i * rows + lane] * Gi[i];
-        hm += stat_H(a, n, WHICH, lane, i) * mi;
+#pragma unroll 8
+        for (int j = 0; j < D; ++j) t += bcast(grow, j) * Mb[j * 64 + lane];
+        e += Mb[i * 64 + lane] * t + vi * bcast(grow, i);
     }
-    double* res = (WHICH == 0 ? a.resQ : a.resR) + (size_t)n * rows;
-    res[lane] = 0.5 * own + 0.5 * e - hm;
+    if (live) (WHICH == 0 ? a.resQ : a.resR)[(size_t)n * rows + lane] = 0.5 * own + 0.5 * e - hm;
 }
 
 template <int WHICH>
@@ -193,6 +252,7 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
     double e0 = 0.0;
     if (lane < D) {
         const int i = lane;
+#pragma unroll 8
         for (int j = 0; j < D; ++j) {
             const double ex = x0[j] * x0[i] + S0[j * D + i] + a.pri.x0_mean[j] * a.pri.x0_mean[i] - 2.0 * x0[j] * a.pri.x0_mean[i];
             e0 += a.pri.x0_prec[i * D + j] * ex;
@@ -209,6 +269,7 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
     if (lane < D) {
         const int i = lane;   // column i
         double lndet = 0.0, tr = 0.0;
+#pragma unroll 8
         for (int k = 0; k < D; ++k) {
             const double p = a.pri.A_pp[(size_t)i * D + k], m = a.A_mean[((size_t)n * D + k) * D + i], m0 = a.pri.A_pm[(size_t)k * D + i];
             lndet += log(p);
@@ -216,6 +277,7 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
         }
         la = -0.5 * D * LN2PI + 0.5 * lndet - 0.5 * tr + 0.5 * D * LN2PI + 0.5 * a.qld_A[(size_t)n * D + i] + 0.5 * D;
         lndet = 0.0; tr = 0.0;
+#pragma unroll 8
         for (int k = 0; k < K; ++k) {
             const double p = a.pri.C_pp[(size_t)i * K + k], m = a.C_mean[((size_t)n * K + k) * D + i], m0 = a.pri.C_pm[(size_t)k * D + i];
             lndet += log(p);
@@ -248,12 +310,20 @@ __global__ void __launch_bounds__(256) k_elbo_sum(SumArgs a) {
 
 static ParamArgs make_args(pyvb_lds* h) {
     ParamArgs a;
-    a.part = h->stats; a.nchunk = h->nchunk; a.Sigma = h->Sigma; a.qld_x = h->qld_x; a.X = h->X[h->cur]; a.Syy = h->Syy;
+    a.part = h->stats; a.nchunk = h->nchunk; a.mom = h->mom; a.Sigma = h->Sigma; a.qld_x = h->qld_x; a.X = h->X[h->cur]; a.Syy = h->Syy;
     a.A_mean = h->A_mean; a.A_var = h->A_var; a.C_mean = h->C_mean; a.C_var = h->C_var;
     a.Q_a = h->Q_a; a.Q_b = h->Q_b; a.R_a = h->R_a; a.R_b = h->R_b; a.qld_A = h->qld_A; a.qld_C = h->qld_C;
     a.resQ = h->resQ; a.resR = h->resR; a.elbo = h->elbo; a.pri = h->pri;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L;
     return a;
+}
+
+int launch_moments(pyvb_lds* h) {
+    ParamArgs a = make_args(h);
+    TimedLaunch tl(h, PYVB_K_PARAMS);
+    hipLaunchKernelGGL(k_moments, dim3(h->N), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
 }
 
 int launch_cols(pyvb_lds* h, int which) {

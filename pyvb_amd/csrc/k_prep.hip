@@ -13,12 +13,13 @@
 // place by Gauss-Jordan elimination without pivoting (they are symmetric positive definite); its
 // pivots are the squares of the Cholesky diagonal, which gives the reference's q_ln_det.
 #include "common.h"
+#include <cstdlib>
 
 struct PrepArgs {
     const double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *x0_mean, *x0_prec;
     double *Sigma, *qld, *gains, *scratch;
     int *warm, *status;
-    int N, T, D, K;
+    int N, T, D, K, skip;   // skip: debug bits (1 = products of the classes, 2 = inversion, 4 = warm-up powers); results are then invalid
     Layout L;
 };
 
@@ -56,31 +57,65 @@ __device__ __forceinline__ void mm(int wave, int lane, FA a_at, FB b_at, FS stor
     }
 }
 
-// In-place inverse of the leading D x D block of the SPD matrix P (row stride LD) by Gauss-Jordan
-// elimination; returns sum_p log(pivot_p) = 2 * sum log diag(chol(P)).  rowp/colp: scratch [64].
-__device__ static double gj_inverse(double* P, int LD, int D, int tid, double* rowp, double* colp, int* status) {
+// Inverses of NP symmetric positive definite D x D matrices at once, by Gauss-Jordan elimination
+// without pivoting, entirely in registers: thread (ti = tid/64, tj = tid%64) owns elements
+// (ti + 4u, tj), u < 4*DT, of every matrix.  Step p of each:  P_ij -= P_ip P_pj / piv  off row and
+// column p, row p *= 1/piv, column p *= -1/piv, pivot -> 1/piv.  The general update is one FMA per
+// element; row p and column p are then overwritten by the few threads that own them.  Row p+1 and
+// column p+1 are stashed into double-buffered LDS vectors as they are produced, so a step costs one
+// barrier, and the NP independent eliminations interleave to cover its latency.
+// rc: scratch [NP][2][128] + pivots [NP][64].  On return v holds the inverses and pivs the pivots,
+// whose logs sum to 2 * sum log diag(chol(P)).
+template <int DT, int NP>
+__device__ static void gj_inverse(double (&v)[NP][4 * DT], int D, int tid, double* rc, double* pivs) {
+    constexpr int NU = 4 * DT;
     const int tj = tid & 63, ti = tid >> 6;
-    double logdet = 0.0;
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = ti + 4 * u;
+            if (i == 0) rc[c * 256 + tj] = v[c][u];              // row 0
+            if (tj == 0) rc[c * 256 + 64 + i] = v[c][u];         // column 0
+        }
+    int cur = 0;
     for (int p = 0; p < D; ++p) {
-        if (tid < D) { rowp[tid] = P[p * LD + tid]; colp[tid] = P[tid * LD + p]; }
         __syncthreads();
-        const double piv = rowp[p];
-        if (tid == 0 && !(piv > 0.0)) atomicOr(status, 1);
-        logdet += log(piv);
-        const double d = 1.0 / piv;
-        if (tj < D) {
-            const double rj = rowp[tj] * d;
-            for (int i = ti; i < D; i += 4) {
-                double v;
-                if (i == p) v = (tj == p) ? d : rj;
-                else if (tj == p) v = -colp[i] * d;
-                else v = P[i * LD + tj] - colp[i] * rj;
-                P[i * LD + tj] = v;
+        const int u0 = p >> 2, t0 = p & 3, u1 = (p + 1) >> 2, t1 = (p + 1) & 3;     // wave-uniform
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            const double* row = rc + c * 256 + cur * 128;
+            const double* col = row + 64;
+            double* nrow = rc + c * 256 + (cur ^ 1) * 128;
+            double* ncol = nrow + 64;
+            const double piv = row[p];
+            if (tid == 0) pivs[c * 64 + p] = piv;
+            const double d = 1.0 / piv;
+            const double rj = row[tj] * d;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) v[c][u] -= col[ti + 4 * u] * rj;
+            if (tj == p) {                              // column p (4 threads)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) v[c][u] = -col[ti + 4 * u] * d;
+            }
+            if (ti == t0) {                             // row p (one wavefront)
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+                    if (u == u0) v[c][u] = (tj == p) ? d : rj;
+            }
+            if (tj == p + 1) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ncol[ti + 4 * u] = v[c][u];
+            }
+            if (ti == t1) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+                    if (u == u1) nrow[tj] = v[c][u];
             }
         }
-        __syncthreads();
+        cur ^= 1;
     }
-    return logdet;
+    __syncthreads();
 }
 
 __device__ static double inf_norm(const double* A, int LD, int D, int tid, double* red) {
@@ -132,7 +167,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     __shared__ double sC[KP * LD];       // <C>  [row k][col i], zero padded
     __shared__ double P[DP * LD];        // posterior precision -> covariance
     __shared__ double W[DP * LD];        // work
-    __shared__ double qbar[64], rbar[64], rowp[64], colp[64], vec[64];
+    __shared__ double qbar[64], rbar[64], rowp[64], colp[64], vec[64], gjbuf[768 + 192];
     const int n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
     const int wave = tid >> 6, lane = tid & 63, tj = tid & 63, ti = tid >> 6;
     const Layout& L = a.L;
@@ -166,38 +201,76 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
         rowp[tid] = tc; colp[tid] = ta;
     }
     __syncthreads();
-    // <C^T R C> -> scratch[0];  <C^T R C> + <A^T Q A> -> scratch[1]     (node.py:213-227)
+    // <C^T R C> -> W;  <C^T R C> + <A^T Q A> -> P     (node.py:213-227)
     mm<DT, DT, KS>(wave, lane,
                    [&](int i, int k) { return sC[k * LD + i] * rbar[k]; },
                    [&](int k, int j) { return sC[k * LD + j]; },
-                   [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += rowp[i]; sc[i * D + j] = v; W[i * LD + j] = v; } });
+                   [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += rowp[i]; W[i * LD + j] = v; } });
     __syncthreads();
     mm<DT, DT, DS>(wave, lane,
                    [&](int i, int k) { return sA[k * LD + i] * qbar[k]; },
                    [&](int k, int j) { return sA[k * LD + j]; },
-                   [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += colp[i]; sc[D * D + i * D + j] = W[i * LD + j] + v; } });
+                   [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += colp[i]; P[i * LD + j] = W[i * LD + j] + v; } });
     __syncthreads();
+
+    // the three posterior precisions, qprec = pprec + (m1 from Mult(C,.) + m1 from Mult(A,.))  gaussian.py:117,
+    // inverted together in registers (qcov, gaussian.py:118-119)
+    constexpr int NU = 4 * DT;
+    double sig[3][NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = ti + 4 * u;
+        const bool in = i < D && tj < D;
+        const double mc = in ? W[i * LD + tj] : 0.0, mac = in ? P[i * LD + tj] : 0.0;
+        const double qd = (in && i == tj) ? qbar[i] : 0.0;
+        const double pad = (!in && i == tj) ? 1.0 : 0.0;            // identity in the padding keeps pivots finite
+        sig[0][u] = (in ? a.x0_prec[i * D + tj] : 0.0) + mac + pad;
+        sig[1][u] = qd + mac + pad;
+        sig[2][u] = qd + mc + pad;
+    }
+    __syncthreads();
+    if (!(a.skip & 2)) gj_inverse<DT, 3>(sig, D, tid, gjbuf, gjbuf + 768);
+    if (tid < 64) {                                                 // q_ln_det, gaussian.py:120 (quirk Q1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double lp = 0.0;
+            if (tid < D) {
+                const double piv = gjbuf[768 + c * 64 + tid];
+                if (!(piv > 0.0)) atomicOr(a.status, 1);
+                lp = log(piv);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) lp += __shfl_xor(lp, o, 64);
+            if (tid == 0) a.qld[(size_t)n * 3 + c] = 0.5 / (0.5 * lp);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = ti + 4 * u;
+            if (i < D && tj < D) a.Sigma[((size_t)n * 3 + c) * D * D + i * D + tj] = sig[c][u];
+        }
 
     const int order[3] = {0, 2, 1};
     for (int oi = 0; oi < 3; ++oi) {
         const int cls = order[oi];
-        // qprec = pprec + (m1 from Mult(C,.) + m1 from Mult(A,.))   gaussian.py:117
-        if (tj < D)
-            for (int i = ti; i < D; i += 4) {
-                const double base = (cls == 2) ? sc[i * D + tj] : sc[D * D + i * D + tj];
-                const double prior = (cls == 0) ? a.x0_prec[i * D + tj] : (i == tj ? qbar[i] : 0.0);
-                P[i * LD + tj] = prior + base;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c == cls) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int i = ti + 4 * u;
+                    if (i < D && tj < D) P[i * LD + tj] = sig[c][u];
+                }
             }
         __syncthreads();
-        const double logdet = gj_inverse(P, LD, D, tid, rowp, colp, a.status);        // qcov, gaussian.py:118-119
-        if (tid == 0) a.qld[(size_t)n * 3 + cls] = 0.5 / (0.5 * logdet);             // gaussian.py:120 (quirk Q1)
-        if (tj < D)
-            for (int i = ti; i < D; i += 4) a.Sigma[((size_t)n * 3 + cls) * D * D + i * D + tj] = P[i * LD + tj];
 
         // gains of this class
         double* FT = g + (cls == 1 ? L.oFT : L.oFLT);
         double* BT = g + (cls == 1 ? L.oBT : L.oB0T);
         double* GT = g + (cls == 1 ? L.oGT : (cls == 0 ? L.oG0T : L.oGLT));
+        if (!(a.skip & 1)) {
         if (cls != 0)       // Sigma <Q><A>: multiplies the mean of X_{t-1}
             mm<DT, DT, DS>(wave, lane,
                            [&](int i, int k) { return P[i * LD + k]; },
@@ -228,6 +301,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
                                if (cls == 1) g[L.oGp + pos_perm(i, l, KS)] = v;
                            }
                        });
+        }
         if (cls == 0) {     // h0 = Sigma_0 (L0 m0): the Constant mean parent of X_0
             if (tid < D) {
                 double s = 0.0;
@@ -246,6 +320,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
 
     // warm-up lengths of the segmented sweeps.  W holds F (forward recurrence matrix); the backward
     // one, B, is read back transposed (powers of B^T in the inf-norm = powers of B in the 1-norm).
+    if (a.skip & 4) { if (tid == 0) { a.warm[n * 2] = 48; a.warm[n * 2 + 1] = 48; } return; }
     int J = warmup_length<DT>(W, P, LD, D, tid, rowp);
     if (tid == 0) a.warm[n * 2 + 0] = J;
     __syncthreads();
@@ -271,6 +346,7 @@ int launch_prep(pyvb_lds* h) {
     a.Sigma = h->Sigma_new; a.qld = h->qld_x_new; a.gains = h->gains; a.scratch = h->scratch;
     a.warm = h->warm; a.status = h->status;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.L = h->L;
+    { const char* e = getenv("PYVB_PREP_SKIP"); a.skip = e ? atoi(e) : 0; }
     {
         TimedLaunch tl(h, PYVB_K_PREP);
         switch (h->L.DT * 10 + h->L.KT) {
