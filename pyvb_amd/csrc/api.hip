@@ -101,6 +101,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRY(dev_alloc(&h->gains, n * L.gains_total));
     TRY(dev_alloc(&h->scratch, n * 2 * D * D));
     TRY(dev_alloc(&h->trash, n * 64));
+    TRY(dev_alloc(&h->U, n * T * L.DP));
     TRYHIP(hipMalloc((void**)&h->warm, n * 2 * sizeof(int)));
     TRYHIP(hipMemset(h->warm, 0, n * 2 * sizeof(int)));
     // time chunks of the statistics kernel: enough wavefronts to fill the chip when N is small
@@ -148,7 +149,7 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     pyvb_lds_comm_destroy(h);
     double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
-                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->mom};
+                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->mom, h->U};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
     if (h->status) (void)hipFree(h->status);
@@ -178,6 +179,7 @@ static int d2h(pyvb_lds* h, double* dst, const double* src, size_t n) {
 static void params_changed(pyvb_lds* h) {
     if (h->gains_valid && h->fresh_count != 0 && h->fresh_count != h->T) h->mixed_cov = true;
     h->gains_valid = false;
+    h->u_valid = false;
 }
 static void states_changed(pyvb_lds* h) { h->stats_valid = false; h->resQ_valid = false; h->resR_valid = false; }
 
@@ -243,6 +245,7 @@ int pyvb_lds_set_observations(pyvb_lds* h, const double* Y) {
     ARGCHK(Y, "Y is NULL");
     int rc;
     if ((rc = h2d(h, h->Y, Y, (size_t)h->N * h->T * h->K))) return rc;
+    h->u_valid = false;
     if ((rc = launch_syy(h))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     states_changed(h);

@@ -20,6 +20,7 @@
 struct SweepArgs {
     const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
     double* trash;      // [N][64]: where lanes of inactive columns aim their (unconditional) stores
+    double* U;          // [N][T][DP]: u_t = G y_t of the interior nodes, in accumulator order (see MODE)
     int N, T, D, K, dir;
     Layout L;
 };
@@ -27,10 +28,15 @@ struct SweepArgs {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 // FULL: D == 16*DT and K == 16*KT (no padded rows/columns, 16-byte aligned rows)
-template <int DT, int KT, bool FULL>
+// MODE: G y_t does not depend on the direction, and the parameters are frozen between the two
+// sweeps of an iteration.  MODE 1 (forward) stores u_t = G y_t after computing it, MODE 2 (the
+// backward sweep that follows) reads it back instead of y_t and skips a third of the MFMAs at the
+// price of one extra [N][T][D] write.  MODE 0 computes it and keeps nothing.  U rows are stored in
+// accumulator order, [tile m][lane group q][register r], so a lane moves 32 contiguous bytes per tile.
+template <int DT, int KT, bool FULL, int MODE>
 __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     constexpr int DS = 4 * DT, KS = 4 * KT, DP = 16 * DT;
-    __shared__ double gl[DT * KS * 64];     // G as MFMA A operands
+    __shared__ double gl[MODE == 2 ? 64 : DT * KS * 64];     // G as MFMA A operands
     __shared__ double xs[64];               // boundary state exchange
     const int n = blockIdx.x, lane = threadIdx.x, c = lane & 15, q = lane >> 4;
     const int T = a.T, D = a.D, K = a.K;
@@ -54,8 +60,10 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                 rn[m][s] = Rn[(m * DS + s) * 64 + lane];
                 ip[m][s] = Ip[(m * DS + s) * 64 + lane];
             }
-        const double* Gp = g + L.oGp;
-        for (int i = 0; i < DT * KS; ++i) gl[i * 64 + lane] = Gp[i * 64 + lane];
+        if constexpr (MODE != 2) {
+            const double* Gp = g + L.oGp;
+            for (int i = 0; i < DT * KS; ++i) gl[i * 64 + lane] = Gp[i * 64 + lane];
+        }
     }
 
     // ---- first boundary node (t = 0 forward, T-1 backward): only the old neighbour
@@ -140,29 +148,52 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
         // store write to a per-replicate trash row.
         double* const trash = a.trash + (size_t)n * 64;
         double* out_pending = trash;
-        load_y(jstart, yv);
+        // u_t rows (MODE 1 writes, MODE 2 reads), in accumulator order
+        double* const Un = a.U + (size_t)n * T * DP;
+        auto u_row = [&](int j) { return (active(j) && j >= 0) ? Un + (size_t)(tbase + sgn * j) * DP : trash; };
+        d4 uv[DT];
+        auto load_u = [&](int j) {
+            const double* p = Un + (size_t)(active(j) ? tbase + sgn * j : tsafe) * DP;
+#pragma unroll
+            for (int m = 0; m < DT; ++m) uv[m] = *reinterpret_cast<const d4*>(p + (m * 4 + q) * 4);
+        };
+        if constexpr (MODE == 2) load_u(jstart); else load_y(jstart, yv);
         load_o(jstart, mo);
         for (int j = jstart; j < Lseg; ++j) {
             d4 acc[DT];
+            if constexpr (MODE == 2) {
 #pragma unroll
-            for (int m = 0; m < DT; ++m) acc[m] = d4{0.0, 0.0, 0.0, 0.0};
-            // G y_t.  The LDS offset is made opaque per iteration: G is loop invariant and the
-            // compiler would otherwise hoist all of it into registers that R and I already fill.
-            int goff = lane;
-            asm volatile("" : "+v"(goff));
+                for (int m = 0; m < DT; ++m) acc[m] = uv[m];                 // G y_t from the forward sweep
+                __builtin_amdgcn_sched_barrier(0);
+                store_x(out_pending);
+                load_u(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+                for (int m = 0; m < DT; ++m) acc[m] = d4{0.0, 0.0, 0.0, 0.0};
+                // G y_t.  The LDS offset is made opaque per iteration: G is loop invariant and the
+                // compiler would otherwise hoist all of it into registers that R and I already fill.
+                int goff = lane;
+                asm volatile("" : "+v"(goff));
 #pragma unroll
-                for (int m = 0; m < DT; ++m) acc[m] = MFMA(gl[(m * KS + s) * 64 + goff], yv[s >> 1][s & 1], acc[m]);
-            // Store the PREVIOUS step's state here, ahead of the loads: vector-memory operations
-            // retire in order, so this keeps the wait for y at the top of the next step from also
-            // waiting on stores issued just before it.
-            __builtin_amdgcn_sched_barrier(0);
-            store_x(out_pending);
-            // y of the next step goes into the registers just consumed; it has the I and R blocks
-            // (>= 2/3 of a step) to arrive.  The scheduling barriers keep the issue point here.
-            load_y(j + 1, yv);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int m = 0; m < DT; ++m) acc[m] = MFMA(gl[(m * KS + s) * 64 + goff], yv[s >> 1][s & 1], acc[m]);
+                // Store the PREVIOUS step's state here, ahead of the loads: vector-memory operations
+                // retire in order, so this keeps the wait for y at the top of the next step from also
+                // waiting on stores issued just before it.
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MODE == 1) {
+                    double* ur = u_row(j);
+#pragma unroll
+                    for (int m = 0; m < DT; ++m) *reinterpret_cast<d4*>(ur + (m * 4 + q) * 4) = acc[m];
+                }
+                store_x(out_pending);
+                // y of the next step goes into the registers just consumed; it has the I and R blocks
+                // (>= 2/3 of a step) to arrive.  The scheduling barriers keep the issue point here.
+                load_y(j + 1, yv);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // I mu_{t+dir} (old)
 #pragma unroll
             for (int s = 0; s < DS; ++s)
@@ -238,15 +269,19 @@ __global__ void __launch_bounds__(64) k_step(StepArgs a) {
 
 template <int DT, int KT>
 static int launch_sweep_t(pyvb_lds* h, const SweepArgs& a) {
-    if (h->D == 16 * DT && h->K == 16 * KT) hipLaunchKernelGGL((k_sweep<DT, KT, true>), dim3(h->N), dim3(64), 0, h->stream, a);
-    else hipLaunchKernelGGL((k_sweep<DT, KT, false>), dim3(h->N), dim3(64), 0, h->stream, a);
+    const bool full = h->D == 16 * DT && h->K == 16 * KT;
+    const int mode = a.dir == PYVB_FORWARD ? 1 : (h->u_valid ? 2 : 0);
+#define PYVB_SWEEP_CASE(F, M) hipLaunchKernelGGL((k_sweep<DT, KT, F, M>), dim3(h->N), dim3(64), 0, h->stream, a)
+    if (full) { if (mode == 1) PYVB_SWEEP_CASE(true, 1); else if (mode == 2) PYVB_SWEEP_CASE(true, 2); else PYVB_SWEEP_CASE(true, 0); }
+    else { if (mode == 1) PYVB_SWEEP_CASE(false, 1); else if (mode == 2) PYVB_SWEEP_CASE(false, 2); else PYVB_SWEEP_CASE(false, 0); }
+#undef PYVB_SWEEP_CASE
     return PYVB_OK;
 }
 
 int launch_sweep(pyvb_lds* h, int direction) {
     SweepArgs a;
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
-    a.trash = h->trash;
+    a.trash = h->trash; a.U = h->U;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
     {
         TimedLaunch tl(h, PYVB_K_SWEEP);
@@ -265,6 +300,7 @@ int launch_sweep(pyvb_lds* h, int direction) {
     }
     HIPCHK(hipGetLastError());
     h->cur = 1 - h->cur;
+    if (direction == PYVB_FORWARD) h->u_valid = true;      // U now holds G y_t for the current gains
     return PYVB_OK;
 }
 

@@ -178,6 +178,27 @@ def test_single_updates_equal_sweep():
     a.close(); b.close()
 
 
+def test_backward_sweep_without_forward():
+    """A backward sweep that does not follow a forward sweep under the same parameters cannot reuse
+    the forward sweep's G y_t and must compute it itself."""
+    T, D, K, N = 90, 16, 16, 2
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=17)
+    b = _batch(Y, st0, pri)
+    st = O.expand_state(st0, pri, T)
+    O.sweep(st, pri, Y, "backward"); b.sweep("backward")
+    _close(b.get_state(("X",))["X"], st["X"], "backward sweep first")
+    O.sweep(st, pri, Y, "backward"); b.sweep("backward")
+    _close(b.get_state(("X",))["X"], st["X"], "backward sweep twice")
+    S = O.statistics(st, Y)
+    O.update_A(st, pri, S); b.update_A()
+    O.sweep(st, pri, Y, "backward"); b.sweep("backward")      # parameters changed: again no cached G y_t
+    _close(b.get_state(("X",))["X"], st["X"], "backward sweep after a parameter update")
+    O.sweep(st, pri, Y, "forward"); b.sweep("forward")
+    O.sweep(st, pri, Y, "backward"); b.sweep("backward")
+    _close(b.get_state(("X",))["X"], st["X"], "forward then backward")
+    b.close()
+
+
 def test_partial_state_updates_are_refused():
     """Statistics while only some X_t were updated under new parameters: the three-class
     covariance structure does not hold, the library must say so (PYVB_E_STALE)."""
