@@ -87,8 +87,8 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     const size_t n = (size_t)N;
     TRY(dev_alloc(&h->Y, n * T * K));
     TRY(dev_alloc(&h->Syy, n * K));
-    TRY(dev_alloc(&h->X[0], n * T * D));
-    TRY(dev_alloc(&h->X[1], n * T * D));
+    TRY(dev_alloc(&h->X[0], n * T * L.DP));
+    TRY(dev_alloc(&h->X[1], n * T * L.DP));
     TRY(dev_alloc(&h->A_mean, n * D * D));
     TRY(dev_alloc(&h->A_var, n * D * D));
     TRY(dev_alloc(&h->C_mean, n * K * D));
@@ -100,7 +100,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRY(dev_alloc(&h->qld_x, n * 3)); TRY(dev_alloc(&h->qld_x_new, n * 3));
     TRY(dev_alloc(&h->gains, n * L.gains_total));
     TRY(dev_alloc(&h->scratch, n * 2 * D * D));
-    TRY(dev_alloc(&h->trash, n * 64));
+    TRY(dev_alloc(&h->trash, n * 128));
     TRY(dev_alloc(&h->U, n * T * L.DP));
     TRYHIP(hipMalloc((void**)&h->warm, n * 2 * sizeof(int)));
     TRYHIP(hipMemset(h->warm, 0, n * 2 * sizeof(int)));
@@ -257,7 +257,10 @@ int pyvb_lds_set_state(pyvb_lds* h, const double* X, const double* A_mean, const
     ENTER(h);
     const size_t N = h->N, T = h->T, D = h->D, K = h->K;
     int rc;
-    if ((rc = h2d(h, h->X[h->cur], X, N * T * D))) return rc;
+    if (X) {    // the other buffer is free between sweeps: stage the API layout there, then permute
+        if ((rc = h2d(h, h->X[1 - h->cur], X, N * T * D))) return rc;
+        if ((rc = launch_permute(h, h->X[1 - h->cur], h->X[h->cur], 1))) return rc;
+    }
     if ((rc = h2d(h, h->A_mean, A_mean, N * D * D))) return rc;
     if ((rc = h2d(h, h->A_var, A_colvar, N * D * D))) return rc;
     if ((rc = h2d(h, h->C_mean, C_mean, N * K * D))) return rc;
@@ -275,7 +278,10 @@ int pyvb_lds_get_state(pyvb_lds* h, double* X, double* A_mean, double* A_colvar,
     ENTER(h);
     const size_t N = h->N, T = h->T, D = h->D, K = h->K;
     int rc;
-    if ((rc = d2h(h, X, h->X[h->cur], N * T * D))) return rc;
+    if (X) {
+        if ((rc = launch_permute(h, h->X[h->cur], h->X[1 - h->cur], 0))) return rc;
+        if ((rc = d2h(h, X, h->X[1 - h->cur], N * T * D))) return rc;
+    }
     if ((rc = d2h(h, A_mean, h->A_mean, N * D * D))) return rc;
     if ((rc = d2h(h, A_colvar, h->A_var, N * D * D))) return rc;
     if ((rc = d2h(h, C_mean, h->C_mean, N * K * D))) return rc;

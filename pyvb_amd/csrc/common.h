@@ -15,16 +15,23 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 //   B0 = Sigma_0 <A>^T<Q>    G0 = Sigma_0 <C>^T<R>     h0 = Sigma_0 L0 m0
 //   FL = Sigma_2 <Q><A>      GL = Sigma_2 <C>^T<R>
 // "n"/"p" blocks are laid out as v_mfma_f64_16x16x4 A-operands: element [(m*S+s)*64+lane]
-// = M[16m + (lane&15)][kidx(s, lane>>4)], kidx natural = 4s+q, permuted = 8(s>>1)+2q+(s&1).
+// = M[16m + (lane&15)][kidx(s, lane>>4)], kidx natural = 4s+q (F, B: they meet states, which come in
+// accumulator order), permuted = 8(s>>1)+2q+(s&1) (G: it meets rows of Y read 16 bytes per lane).
 // "T" blocks are transposed plain matrices [col][DP] for the lane-per-row scalar code.
 struct Layout {
     int D, K, DT, KT, DP, KP, DS, KS;
-    size_t oFn, oFp, oBn, oBp, oGp;
+    size_t oFn, oBn, oGp;
     size_t oFT, oBT, oGT, oB0T, oG0T, oh0, oFLT, oGLT;
     size_t gains_total;     // doubles per replicate
     size_t stats_total;     // doubles per replicate per chunk: Sxx[DP][DP], Sx1x[DP][DP], Syx[KP][DP]
     size_t oSxx, oSx1x, oSyx;
 };
+
+// Internal layout of a state row (X buffers, stride DP): "accumulator order".  Dimension
+// d = 16m + 4r + q sits at 16m + 4q + r, which is where lane group q keeps register r of tile m of a
+// v_mfma_f64_16x16x4 accumulator -- and also its B operand of k-step 4m + r.  A lane therefore moves
+// four contiguous doubles per tile, for the state stores as well as for the neighbour loads.
+__host__ __device__ static inline int xpos(int d) { return (d & ~15) | ((d & 3) << 2) | ((d >> 2) & 3); }
 
 static inline int tiles16(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : 4); }
 
@@ -36,7 +43,7 @@ static inline Layout make_layout(int D, int K) {
     L.DS = 4 * L.DT; L.KS = 4 * L.KT;
     size_t o = 0;
     size_t dd = (size_t)L.DT * L.DS * 64, dk = (size_t)L.DT * L.KS * 64;
-    L.oFn = o; o += dd; L.oFp = o; o += dd; L.oBn = o; o += dd; L.oBp = o; o += dd; L.oGp = o; o += dk;
+    L.oFn = o; o += dd; L.oBn = o; o += dd; L.oGp = o; o += dk;
     size_t tdd = (size_t)L.DP * L.DP, tkd = (size_t)L.KP * L.DP;
     L.oFT = o; o += tdd; L.oBT = o; o += tdd; L.oGT = o; o += tkd;
     L.oB0T = o; o += tdd; L.oG0T = o; o += tkd; L.oh0 = o; o += L.DP;
@@ -64,7 +71,7 @@ struct pyvb_lds {
     struct EventPair* pool; int pool_used;
     // state
     double *Y, *Syy;                // [N][T][K], [N][K] (sum_t y^2)
-    double *X[2]; int cur;          // ping-pong [N][T][D]
+    double *X[2]; int cur;          // ping-pong [N][T][DP], rows in accumulator order (xpos)
     double *A_mean, *A_var, *C_mean, *C_var;
     double *Q_a, *Q_b, *R_a, *R_b;
     double *qld_A, *qld_C;          // [N][D]
@@ -76,7 +83,7 @@ struct pyvb_lds {
     double *gains;                  // [N][L.gains_total]
     double *scratch;                // [N][2][DP][DP] (M_C, M_A + M_C)
     int *warm;                      // [N][2]
-    double *trash;                  // [N][64] dump row for masked-out stores of the sweep
+    double *trash;                  // [N][128] dump rows for masked-out stores of the sweep
     double *U; bool u_valid;        // [N][T][DP] G y_t written by the forward sweep for the backward one
     double *stats; int nchunk, chunk_len;   // [N][nchunk][L.stats_total]
     double *mom;                    // [N][3 D^2 + K D + D] second moments (k_moments)
@@ -96,6 +103,7 @@ int launch_prep(pyvb_lds* h);
 int launch_sweep(pyvb_lds* h, int direction);
 int launch_step(pyvb_lds* h, int t);
 int launch_syy(pyvb_lds* h);
+int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal);
 int launch_stats(pyvb_lds* h);
 int launch_moments(pyvb_lds* h);
 int launch_cols(pyvb_lds* h, int which);      // 0 = A, 1 = C

@@ -55,8 +55,8 @@ __global__ void __launch_bounds__(256) k_moments(ParamArgs a) {
     const int n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K, T = a.T, DP = a.L.DP;
     const double* P = a.part + (size_t)n * a.nchunk * a.L.stats_total;
     const double* S = a.Sigma + (size_t)n * 3 * D * D;
-    const double* x0 = a.X + (size_t)n * T * D;
-    const double* xL = x0 + (size_t)(T - 1) * D;
+    const double* x0 = a.X + (size_t)n * T * DP;       // state rows: stride DP, accumulator order (xpos)
+    const double* xL = x0 + (size_t)(T - 1) * DP;
     double* mo = a.mom + (size_t)n * mom_total(D, K);
     const double nint = (double)(T - 2);
     for (int idx = tid; idx < D * D; idx += 256) {
@@ -68,10 +68,10 @@ __global__ void __launch_bounds__(256) k_moments(ParamArgs a) {
             h += Pc[a.L.oSx1x + (size_t)i * DP + j];
         }
         const double s0 = S[idx], s1 = S[D * D + idx], s2 = S[2 * D * D + idx];
-        mo[MOM_GA(D, K) + idx] = xx - xL[i] * xL[j] + s0 + nint * s1;
+        mo[MOM_GA(D, K) + idx] = xx - xL[xpos(i)] * xL[xpos(j)] + s0 + nint * s1;
         mo[MOM_GC(D, K) + idx] = xx + s0 + nint * s1 + s2;
         mo[MOM_HA(D, K) + idx] = h;
-        if (i == j) mo[MOM_DP(D, K) + i] = xx - x0[i] * x0[i] + nint * s1 + s2;
+        if (i == j) mo[MOM_DP(D, K) + i] = xx - x0[xpos(i)] * x0[xpos(i)] + nint * s1 + s2;
     }
     for (int idx = tid; idx < K * D; idx += 256) {
         const int k = idx / D, j = idx % D;
@@ -229,7 +229,7 @@ __device__ static double gamma_llb(double a0, double b0, double qa, double qb) {
 __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
     const int n = blockIdx.x, lane = threadIdx.x, D = a.D, K = a.K, T = a.T;
     const double* S0 = a.Sigma + (size_t)n * 3 * D * D;
-    const double* x0 = a.X + (size_t)n * T * D;
+    const double* x0 = a.X + (size_t)n * T * a.L.DP;
     const double* qx = a.qld_x + (size_t)n * 3;
     // --- noise expectations
     double qbar = 0.0, rbar = 0.0, lnq = 0.0, lnr = 0.0, rq = 0.0, rr = 0.0, lq = 0.0, lr = 0.0;
@@ -254,7 +254,8 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
         const int i = lane;
 #pragma unroll 8
         for (int j = 0; j < D; ++j) {
-            const double ex = x0[j] * x0[i] + S0[j * D + i] + a.pri.x0_mean[j] * a.pri.x0_mean[i] - 2.0 * x0[j] * a.pri.x0_mean[i];
+            const double xj = x0[xpos(j)];
+            const double ex = xj * x0[xpos(i)] + S0[j * D + i] + a.pri.x0_mean[j] * a.pri.x0_mean[i] - 2.0 * xj * a.pri.x0_mean[i];
             e0 += a.pri.x0_prec[i * D + j] * ex;
         }
     }

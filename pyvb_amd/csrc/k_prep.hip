@@ -176,7 +176,6 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     const double* Cm = a.C_mean + (size_t)n * K * D;
     const double* Cv = a.C_var + (size_t)n * D * K;
     double* g = a.gains + (size_t)n * L.gains_total;
-    double* sc = a.scratch + (size_t)n * 2 * D * D;
 
     if (tid < 64) {
         qbar[tid] = (tid < D) ? a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid] : 0.0;
@@ -278,7 +277,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
                            [&](int i, int j, double v) {
                                if (i < D && j < D) {
                                    FT[(size_t)j * DP + i] = v;
-                                   if (cls == 1) { g[L.oFn + pos_nat(i, j, DS)] = v; g[L.oFp + pos_perm(i, j, DS)] = v; W[i * LD + j] = v; }
+                                   if (cls == 1) { g[L.oFn + pos_nat(i, j, DS)] = v; W[i * LD + j] = v; }
                                }
                            });
         if (cls != 2)       // Sigma <A>^T<Q>: multiplies the mean of X_{t+1}
@@ -288,7 +287,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
                            [&](int i, int j, double v) {
                                if (i < D && j < D) {
                                    BT[(size_t)j * DP + i] = v;
-                                   if (cls == 1) { g[L.oBn + pos_nat(i, j, DS)] = v; g[L.oBp + pos_perm(i, j, DS)] = v; }
+                                   if (cls == 1) { g[L.oBn + pos_nat(i, j, DS)] = v; }
                                }
                            });
         // Sigma <C>^T<R>: multiplies y_t

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(128, 2) k_stats(StatsArgs a) {
     constexpr int KA = StatsSplit<DT, KT>::KA, KB = KT - KA;
     const int ch = blockIdx.x, n = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int T = a.T, D = a.D, K = a.K;
-    const double* X = a.X + (size_t)n * T * D;
+    const double* X = a.X + (size_t)n * T * DP;        // rows: stride DP, accumulator order
     const double* Y = a.Y + (size_t)n * T * K;
     const int t0 = ch * a.chunk_len;
     const int t1 = (t0 + a.chunk_len < T) ? t0 + a.chunk_len : T;
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(128, 2) k_stats(StatsArgs a) {
 #pragma unroll
         for (int m = 0; m < DT; ++m) {
             const int dim = 16 * m + r;
-            dst[m] = X[(size_t)tc * D + (dim < D ? dim : D - 1)];
+            dst[m] = X[(size_t)tc * DP + xpos(dim)];      // padded positions hold zeros
         }
     };
     auto row_y = [&](int t, bool valid, int m0, int cnt, double* dst) {

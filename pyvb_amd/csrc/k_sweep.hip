@@ -19,7 +19,7 @@
 
 struct SweepArgs {
     const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
-    double* trash;      // [N][64]: where lanes of inactive columns aim their (unconditional) stores
+    double* trash;      // [N][128]: where lanes of inactive columns aim their (unconditional) stores
     double* U;          // [N][T][DP]: u_t = G y_t of the interior nodes, in accumulator order (see MODE)
     int N, T, D, K, dir;
     Layout L;
@@ -44,15 +44,15 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     const int sgn = fwd ? 1 : -1;
     const Layout& L = a.L;
     const double* g = a.gains + (size_t)n * L.gains_total;
-    const double* Xo = a.Xold + (size_t)n * T * D;
-    double* Xn = a.Xnew + (size_t)n * T * D;
+    const double* Xo = a.Xold + (size_t)n * T * DP;      // state rows: stride DP, accumulator order
+    double* Xn = a.Xnew + (size_t)n * T * DP;
     const double* Yn = a.Y + (size_t)n * T * K;
 
     // ---- operands that live for the whole sweep
     double rn[DT][DS], ip[DT][DS];
     {
         const double* Rn = g + (fwd ? L.oFn : L.oBn);
-        const double* Ip = g + (fwd ? L.oBp : L.oFp);
+        const double* Ip = g + (fwd ? L.oBn : L.oFn);
 #pragma unroll
         for (int m = 0; m < DT; ++m)
 #pragma unroll
@@ -71,12 +71,12 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     {
         const double* E1 = g + (fwd ? L.oB0T : L.oFLT);
         const double* G1 = g + (fwd ? L.oG0T : L.oGLT);
-        const double* xo = Xo + (size_t)(t_first + sgn) * D;
+        const double* xo = Xo + (size_t)(t_first + sgn) * DP;
         const double* y = Yn + (size_t)t_first * K;
         double s = fwd ? g[L.oh0 + lane % DP] : 0.0;
-        for (int j = 0; j < D; ++j) s += E1[j * DP + lane % DP] * xo[j];
+        for (int j = 0; j < D; ++j) s += E1[j * DP + lane % DP] * xo[xpos(j)];
         for (int k = 0; k < K; ++k) s += G1[k * DP + lane % DP] * y[k];
-        if (lane < D) Xn[(size_t)t_first * D + lane] = s;
+        if (lane < DP) Xn[(size_t)t_first * DP + xpos(lane)] = (lane < D) ? s : 0.0;
         xs[lane] = (lane < D) ? s : 0.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
         // a value that the select after the step discards (MFMA columns do not mix), and padded
         // k positions meet zero matrix entries.  So a step's loads issue back to back with no
         // branch and no use until the next step.
-        d2 yv[KS / 2], mo[DS / 2];
+        d2 yv[KS / 2];
+        d4 mo[DT];
         auto load_y = [&](int j, d2* dst) {
             const double* p = Yn + (size_t)(active(j) ? tbase + sgn * j : tsafe) * K;
 #pragma unroll
@@ -121,32 +122,19 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                 }
             }
         };
-        auto load_o = [&](int j, d2* dst) {
-            const double* p = Xo + (size_t)((active(j) ? tbase + sgn * j : tsafe) + sgn) * D;
+        auto load_o = [&](int j, d4* dst) {
+            const double* p = Xo + (size_t)((active(j) ? tbase + sgn * j : tsafe) + sgn) * DP;
 #pragma unroll
-            for (int i = 0; i < DS / 2; ++i) {
-                const int d0 = 8 * i + 2 * q;
-                if constexpr (FULL) {
-                    dst[i] = *reinterpret_cast<const d2*>(p + d0);
-                } else {
-                    dst[i][0] = p[d0 < D ? d0 : D - 1];
-                    dst[i][1] = p[d0 + 1 < D ? d0 + 1 : D - 1];
-                }
-            }
+            for (int m = 0; m < DT; ++m) dst[m] = *reinterpret_cast<const d4*>(p + (m * 4 + q) * 4);
         };
         auto store_x = [&](double* out) {
 #pragma unroll
-            for (int m = 0; m < DT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int dim = 16 * m + 4 * r + q;
-                    if (FULL || dim < D) out[dim] = x[m][r];
-                }
+            for (int m = 0; m < DT; ++m) *reinterpret_cast<d4*>(out + (m * 4 + q) * 4) = x[m];
         };
         // Stores are unconditional too (a branch around them would make the compiler's in-order
         // vmcnt bookkeeping conservative and stall on loads just issued): lanes with nothing to
         // store write to a per-replicate trash row.
-        double* const trash = a.trash + (size_t)n * 64;
+        double* const trash = a.trash + (size_t)n * 128;
         double* out_pending = trash;
         // u_t rows (MODE 1 writes, MODE 2 reads), in accumulator order
         double* const Un = a.U + (size_t)n * T * DP;
@@ -157,7 +145,13 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
 #pragma unroll
             for (int m = 0; m < DT; ++m) uv[m] = *reinterpret_cast<const d4*>(p + (m * 4 + q) * 4);
         };
+        // Prologue: the same sequence of vector-memory operations as one loop iteration (loads, stores
+        // -- into the trash row -- , loads), so that the compiler's in-order vmcnt bookkeeping at the
+        // loop head sees the same number of younger operations on both incoming edges and the wait
+        // for the first loads does not also cover the stores behind them.
         if constexpr (MODE == 2) load_u(jstart); else load_y(jstart, yv);
+        if constexpr (MODE == 1) store_x(trash + 64);  // stands for the u_t store
+        store_x(trash);
         load_o(jstart, mo);
         for (int j = jstart; j < Lseg; ++j) {
             d4 acc[DT];
@@ -165,8 +159,8 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
 #pragma unroll
                 for (int m = 0; m < DT; ++m) acc[m] = uv[m];                 // G y_t from the forward sweep
                 __builtin_amdgcn_sched_barrier(0);
-                store_x(out_pending);
                 load_u(j + 1);
+                store_x(out_pending);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
 #pragma unroll
@@ -179,26 +173,26 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
                     for (int m = 0; m < DT; ++m) acc[m] = MFMA(gl[(m * KS + s) * 64 + goff], yv[s >> 1][s & 1], acc[m]);
-                // Store the PREVIOUS step's state here, ahead of the loads: vector-memory operations
-                // retire in order, so this keeps the wait for y at the top of the next step from also
-                // waiting on stores issued just before it.
+                // Next step's y goes into the registers just consumed; it has the I and R blocks
+                // (2/3 of a step) to arrive.  The stores of the PREVIOUS step's state (and of u_t)
+                // are issued right behind those loads: vector-memory operations retire in order, so
+                // a wait for the loads never includes the stores, and the stores get a whole step
+                // to drain before the next loads queue up behind them.
                 __builtin_amdgcn_sched_barrier(0);
+                load_y(j + 1, yv);
                 if constexpr (MODE == 1) {
                     double* ur = u_row(j);
 #pragma unroll
                     for (int m = 0; m < DT; ++m) *reinterpret_cast<d4*>(ur + (m * 4 + q) * 4) = acc[m];
                 }
                 store_x(out_pending);
-                // y of the next step goes into the registers just consumed; it has the I and R blocks
-                // (>= 2/3 of a step) to arrive.  The scheduling barriers keep the issue point here.
-                load_y(j + 1, yv);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // I mu_{t+dir} (old)
 #pragma unroll
             for (int s = 0; s < DS; ++s)
 #pragma unroll
-                for (int m = 0; m < DT; ++m) acc[m] = MFMA(ip[m][s], mo[s >> 1][s & 1], acc[m]);
+                for (int m = 0; m < DT; ++m) acc[m] = MFMA(ip[m][s], mo[s >> 2][s & 3], acc[m]);
             __builtin_amdgcn_sched_barrier(0);
             load_o(j + 1, mo);
             __builtin_amdgcn_sched_barrier(0);
@@ -212,7 +206,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
             for (int m = 0; m < DT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[m][r] = act ? acc[m][r] : x[m][r];
-            out_pending = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * D : trash;
+            out_pending = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * DP : trash;
         }
         store_x(out_pending);
         // the column that holds the last interior node hands its state to the closing boundary step
@@ -237,7 +231,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
         double s = fwd ? 0.0 : g[L.oh0 + lane % DP];
         for (int j = 0; j < D; ++j) s += E2[j * DP + lane % DP] * xs[j];
         for (int k = 0; k < K; ++k) s += G2[k * DP + lane % DP] * y[k];
-        if (lane < D) Xn[(size_t)t_last * D + lane] = s;
+        if (lane < DP) Xn[(size_t)t_last * DP + xpos(lane)] = (lane < D) ? s : 0.0;
     }
 }
 
@@ -253,7 +247,7 @@ __global__ void __launch_bounds__(64) k_step(StepArgs a) {
     const int T = a.T, D = a.D, K = a.K, t = a.t, DP = a.L.DP;
     const Layout& L = a.L;
     const double* g = a.gains + (size_t)n * L.gains_total;
-    double* X = a.X + (size_t)n * T * D;
+    double* X = a.X + (size_t)n * T * DP;
     const double* y = a.Y + ((size_t)n * T + t) * K;
     const int cls = (t == 0) ? 0 : (t == T - 1 ? 2 : 1);
     const double* FT = g + (cls == 1 ? L.oFT : L.oFLT);
@@ -261,10 +255,10 @@ __global__ void __launch_bounds__(64) k_step(StepArgs a) {
     const double* GT = g + (cls == 1 ? L.oGT : (cls == 0 ? L.oG0T : L.oGLT));
     const int row = lane % DP;
     double s = (cls == 0) ? g[L.oh0 + row] : 0.0;
-    if (t > 0) for (int j = 0; j < D; ++j) s += FT[j * DP + row] * X[(size_t)(t - 1) * D + j];
-    if (t < T - 1) for (int j = 0; j < D; ++j) s += BT[j * DP + row] * X[(size_t)(t + 1) * D + j];
+    if (t > 0) for (int j = 0; j < D; ++j) s += FT[j * DP + row] * X[(size_t)(t - 1) * DP + xpos(j)];
+    if (t < T - 1) for (int j = 0; j < D; ++j) s += BT[j * DP + row] * X[(size_t)(t + 1) * DP + xpos(j)];
     for (int k = 0; k < K; ++k) s += GT[k * DP + row] * y[k];
-    if (lane < D) X[(size_t)t * D + lane] = s;
+    if (lane < DP) X[(size_t)t * DP + xpos(lane)] = (lane < D) ? s : 0.0;
 }
 
 template <int DT, int KT>
@@ -301,6 +295,23 @@ int launch_sweep(pyvb_lds* h, int direction) {
     HIPCHK(hipGetLastError());
     h->cur = 1 - h->cur;
     if (direction == PYVB_FORWARD) h->u_valid = true;      // U now holds G y_t for the current gains
+    return PYVB_OK;
+}
+
+// API layout [N][T][D] <-> internal layout [N][T][DP] (accumulator order, zero padded)
+struct PermArgs { const double* src; double* dst; size_t rows; int D, DP, to_internal; };
+__global__ void __launch_bounds__(256) k_permute(PermArgs a) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int d = threadIdx.x & 63;
+    if (row >= a.rows || d >= a.DP) return;
+    if (a.to_internal) a.dst[row * a.DP + xpos(d)] = (d < a.D) ? a.src[row * a.D + d] : 0.0;
+    else if (d < a.D) a.dst[row * a.D + d] = a.src[row * a.DP + xpos(d)];
+}
+
+int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal) {
+    PermArgs a; a.src = src; a.dst = dst; a.rows = (size_t)h->N * h->T; a.D = h->D; a.DP = h->L.DP; a.to_internal = to_internal;
+    hipLaunchKernelGGL(k_permute, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
 
