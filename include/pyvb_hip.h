@@ -96,6 +96,8 @@ int pyvb_lds_update_x(pyvb_lds* h, int t);
 /* [a.update() for a in As] / Cs: Gaussian.update + hstack.pass_up_m1_m2 nodes_todo.py:43-62 */
 int pyvb_lds_update_A(pyvb_lds* h);
 int pyvb_lds_update_C(pyvb_lds* h);
+/* As[i].update() for i in [col_begin, col_end) in order (which = 0), or the same for Cs (which = 1) */
+int pyvb_lds_update_columns(pyvb_lds* h, int which, int col_begin, int col_end);
 /* Q.update() / R.update(): nodes_todo.py:130-138, :187-190 with Multiplication.pass_down_ExxT node.py:244-276 */
 int pyvb_lds_update_Q(pyvb_lds* h);
 int pyvb_lds_update_R(pyvb_lds* h);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "pyvb_lds_update_x": (ctypes.c_int, [_h, ctypes.c_int]),
     "pyvb_lds_update_A": (ctypes.c_int, [_h]),
     "pyvb_lds_update_C": (ctypes.c_int, [_h]),
+    "pyvb_lds_update_columns": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "pyvb_lds_update_Q": (ctypes.c_int, [_h]),
     "pyvb_lds_update_R": (ctypes.c_int, [_h]),
     "pyvb_lds_elbo": (ctypes.c_int, [_h]),

@@ -1,0 +1,278 @@
+"""Graph recogniser and execution plan behind pyvb_amd.nodes.
+
+`bind(node)` walks the graph a node belongs to.  If it is the linear-dynamical-system graph of
+the reference's examples/Linear_Dynamic_System.py:46-66 --
+
+    A = hstack(D Gaussian columns, Constant parents)      C = hstack(D Gaussian columns)
+    X_0 ~ N(Constant, Constant)      X_t ~ N(A * X_{t-1}, Q)      Y_t ~ N(C * X_t, R), observed
+    Q, R both DiagonalGamma or both Gamma
+
+-- it builds an `LDSPlan`: the posterior state is uploaded into a one-replicate LDSBatch and every
+node of the graph is pointed at the plan.  Anything else raises NotImplementedError (there is no
+CPU execution path).
+"""
+import numpy as np
+
+from . import nodes as N
+
+
+class LDSPlan(object):
+    def __init__(self, Xs, Ys, As, Cs, A, C, Q, R, pri):
+        from .lds import LDSBatch
+        self.Xs, self.Ys, self.As, self.Cs, self.A, self.C, self.Q, self.R = Xs, Ys, As, Cs, A, C, Q, R
+        self.T, self.D, self.K = len(Xs), As[0].shape[0], Cs[0].shape[0]
+        T, D, K = self.T, self.D, self.K
+        self.kind = pri["noise"]
+        self.batch = LDSBatch(1, T, D, K, self.kind)
+        self.batch.set_priors(pri)
+        self.batch.set_observations(np.hstack([y.__dict__["_h_qmu"] for y in Ys]).T.reshape(1, T, K))
+        diag = lambda nodes_: np.stack([np.diag(n.__dict__["_h_qcov"]) for n in nodes_])
+        qb = lambda nd, dim: np.broadcast_to(np.asarray(nd.__dict__["_h_qb"], dtype=float), (dim,)).reshape(1, dim)
+        self.batch.set_state(
+            X=np.hstack([x.__dict__["_h_qmu"] for x in Xs]).T.reshape(1, T, D),
+            A_mean=np.hstack([a.__dict__["_h_qmu"] for a in As]).reshape(1, D, D),
+            A_colvar=diag(As).reshape(1, D, D),
+            C_mean=np.hstack([c.__dict__["_h_qmu"] for c in Cs]).reshape(1, K, D),
+            C_colvar=diag(Cs).reshape(1, D, K),
+            Q_b=qb(Q, D), R_b=qb(R, K))
+        self.index = {}
+        for t, x in enumerate(Xs):
+            self.index[id(x)] = ("x", t)
+        for t, y in enumerate(Ys):
+            self.index[id(y)] = ("y", t)
+        for i, a in enumerate(As):
+            self.index[id(a)] = ("a", i)
+        for i, c in enumerate(Cs):
+            self.index[id(c)] = ("c", i)
+        self.index[id(Q)] = ("q", 0)
+        self.index[id(R)] = ("r", 0)
+        self.pending = []
+        self.cache = None
+        self.x_updated = False
+        for n in Xs + Ys + As + Cs + [A, C, Q, R]:
+            n._plan = self
+
+    # -- queue -----------------------------------------------------------------------------------
+    def enqueue(self, node):
+        self.pending.append(self.index[id(node)])
+
+    def flush(self):
+        """Run the queued update() requests, turning whole-sweep runs into single launches."""
+        ops, self.pending = self.pending, []
+        if not ops:
+            return
+        self.cache = None
+        b, T, D = self.batch, self.T, self.D
+        i = 0
+        while i < len(ops):
+            kind, idx = ops[i]
+            if kind == "x":
+                run = [o[1] for o in ops[i:i + T] if o[0] == "x"]
+                if len(run) == T and run == list(range(T)):
+                    b.sweep("forward"); i += T
+                elif len(run) == T and run == list(range(T - 1, -1, -1)):
+                    b.sweep("backward"); i += T
+                else:
+                    b.update_x(idx); i += 1
+                self.x_updated = True
+            elif kind in ("a", "c"):
+                j = i
+                while j + 1 < len(ops) and ops[j + 1] == (kind, ops[j][1] + 1):
+                    j += 1
+                b.update_columns("A" if kind == "a" else "C", idx, ops[j][1] + 1)
+                i = j + 1
+            elif kind == "q":
+                b.update_Q(); i += 1
+            elif kind == "r":
+                b.update_R(); i += 1
+            else:
+                i += 1          # observed nodes never update (gaussian.py:109-110)
+
+    # -- attribute traffic -----------------------------------------------------------------------
+    def _pull(self):
+        self.flush()
+        if self.cache is None:
+            st = self.batch.get_state()
+            Sig, qld = self.batch.get_posterior_classes()
+            qa, qc = self.batch.get_column_qld()
+            self.cache = {"st": st, "Sigma": Sig[0], "qld_x": qld[0], "qld_A": qa[0], "qld_C": qc[0]}
+        return self.cache
+
+    def read(self, node, name):
+        kind, i = self.index[id(node)]
+        if kind == "y" or (kind == "x" and name != "qmu" and not self.x_updated):
+            return node.__dict__.get("_h_" + name)          # observations / not yet updated: host copy
+        c = self._pull()
+        st, T = c["st"], self.T
+        if kind == "x":
+            cls = 0 if i == 0 else (2 if i == T - 1 else 1)
+            if name == "qmu":
+                return st["X"][0, i].reshape(-1, 1).copy()
+            return c["Sigma"][cls].copy() if name == "qcov" else float(c["qld_x"][cls])
+        if kind in ("a", "c"):
+            M, V, q = ("A_mean", "A_colvar", "qld_A") if kind == "a" else ("C_mean", "C_colvar", "qld_C")
+            if name == "qmu":
+                return st[M][0][:, [i]].copy()
+            return np.diag(st[V][0, i]) if name == "qcov" else float(c[q][i])
+        if name == "qb":
+            v = st["Q_b" if kind == "q" else "R_b"][0]
+            return float(v[0]) if self.kind == "gamma" else v.copy()
+        raise AttributeError(name)
+
+    def write(self, node, name, value):
+        """A user assignment to a posterior attribute after binding: push it to the device."""
+        self.flush()
+        self.cache = None
+        kind, i = self.index[id(node)]
+        st = self.batch.get_state()
+        if kind == "x" and name == "qmu":
+            st["X"][0, i] = np.asarray(value).reshape(-1)
+            self.batch.set_state(X=st["X"])
+        elif kind in ("a", "c") and name in ("qmu", "qcov"):
+            M, V = ("A_mean", "A_colvar") if kind == "a" else ("C_mean", "C_colvar")
+            if name == "qmu":
+                st[M][0][:, i] = np.asarray(value).reshape(-1)
+            else:
+                st[V][0, i] = np.diag(np.asarray(value))
+            self.batch.set_state(**{M: st[M], V: st[V]})
+        elif kind in ("q", "r") and name == "qb":
+            key = "Q_b" if kind == "q" else "R_b"
+            st[key][0] = np.broadcast_to(np.asarray(value, dtype=float), st[key][0].shape)
+            self.batch.set_state(**{key: st[key]})
+        # other attributes (q_ln_det, observed nodes) are host-only bookkeeping
+
+    # -- lower bound -----------------------------------------------------------------------------
+    def elbo_parts(self):
+        self.flush()
+        return self.batch.elbo()[0]
+
+    def node_llb(self, node):
+        kind, _ = self.index[id(node)]
+        if kind == "q":
+            return float(self.elbo_parts()[4])
+        if kind == "r":
+            return float(self.elbo_parts()[5])
+        raise NotImplementedError(
+            "per-node log_lower_bound() of the %d state/output/column nodes is not split out on the device; "
+            "use Network.learn / Network.llb or plan.elbo_parts() (sums per node class)" % (2 * self.T + 2 * self.D))
+
+
+# -------------------------------------------------------------------------------------------------
+def _component(start):
+    """All nodes connected to `start` (parents and children), in discovery order."""
+    seen, order, stack = set(), [], [start]
+    while stack:
+        n = stack.pop()
+        if id(n) in seen:
+            continue
+        seen.add(id(n))
+        order.append(n)
+        nxt = list(getattr(n, "children", []))
+        for attr in ("mean_parent", "precision_parent", "A", "B"):
+            if hasattr(n, attr):
+                nxt.append(getattr(n, attr))
+        nxt.extend(getattr(n, "parents", []))
+        stack.extend(nxt)
+    return order
+
+
+def _fail(why):
+    raise NotImplementedError("this graph has no HIP plan (%s); pyvb_amd executes the linear-dynamical-system graph of "
+                              "examples/Linear_Dynamic_System.py only and has no CPU fallback" % why)
+
+
+def _diag_constant(node, what):
+    if not isinstance(node, N.Constant):
+        _fail("%s must be a Constant" % what)
+    v = node.value
+    if np.abs(v - np.diag(np.diag(v))).max() != 0.0:
+        _fail("%s must be diagonal" % what)
+    return np.diag(v).copy()
+
+
+def describe(start):
+    """Recognise the LDS graph around `start`; returns the pieces and the priors (no GPU involved)."""
+    comp = _component(start)
+    stacks = [n for n in comp if isinstance(n, N.hstack)]
+    noise = [n for n in comp if isinstance(n, (N.Gamma, N.DiagonalGamma, N.Wishart))]
+    if len(stacks) != 2 or len(noise) != 2:
+        _fail("expected two hstack matrices and two noise-precision nodes, found %d and %d" % (len(stacks), len(noise)))
+    if any(isinstance(n, N.Wishart) for n in noise):
+        _fail("Wishart noise")
+    if type(noise[0]) is not type(noise[1]):
+        _fail("Q and R must both be DiagonalGamma or both Gamma")
+    if any(isinstance(n, N.Addition) for n in comp):
+        _fail("Addition nodes")
+    # the chain start: a Gaussian with Constant parents that is multiplied by an hstack
+    gauss = [n for n in comp if isinstance(n, N.Gaussian)]
+    cols = set(id(p) for s in stacks for p in s.parents)
+    heads = [g for g in gauss if id(g) not in cols and isinstance(g.mean_parent, N.Constant)]
+    if len(heads) != 1 or not isinstance(heads[0].precision_parent, N.Constant):
+        _fail("expected exactly one state with Constant parents (X_0)")
+    X0 = heads[0]
+    Xs, Ys, A, C = [X0], [], None, None
+    x = X0
+    while True:
+        nxt = None
+        for m in x.children:
+            if not isinstance(m, N.Multiplication) or m.B is not x or not isinstance(m.A, N.hstack) or len(m.children) != 1:
+                _fail("a state has a child that is not hstack * state feeding one Gaussian")
+            child = m.children[0]
+            if child.observed:
+                if C is None:
+                    C = m.A
+                if m.A is not C:
+                    _fail("outputs use different observation matrices")
+                Ys.append(child)
+            else:
+                if A is None:
+                    A = m.A
+                if m.A is not A or nxt is not None:
+                    _fail("states use different transition matrices")
+                nxt = child
+        if len(Ys) != len(Xs):
+            _fail("every state needs exactly one fully observed output")
+        if nxt is None:
+            break
+        Xs.append(nxt)
+        x = nxt
+    if A is None or C is None or A is C:
+        _fail("need distinct transition and observation matrices")
+    T, D, K = len(Xs), A.shape[0], C.shape[0]
+    if T < 2 or A.shape != (D, D) or C.shape != (K, D) or X0.shape[0] != D:
+        _fail("shapes")
+    Q, R = Xs[1].precision_parent, Ys[0].precision_parent
+    if Q is R or any(x.precision_parent is not Q for x in Xs[1:]) or any(y.precision_parent is not R for y in Ys):
+        _fail("noise precisions are not shared along the chain")
+    if any(y.partially_observed for y in Ys) or any(x.partially_observed or x.observed for x in Xs):
+        _fail("partial observations")
+    As, Cs = A.parents, C.parents
+    for col in As + Cs:
+        if col.observed or col.partially_observed:
+            _fail("observed matrix columns (LDS_knowns_in_A.py) are not supported yet")
+    kind = "diagonal_gamma" if isinstance(Q, N.DiagonalGamma) else "gamma"
+    pri = {
+        "noise": kind,
+        "x0_mean": X0.mean_parent.value.reshape(-1).astype(float), "x0_prec": np.asarray(X0.precision_parent.value, dtype=float),
+        "A_prior_mean": np.hstack([a.mean_parent.value for a in As]).astype(float),
+        "A_prior_prec": np.stack([_diag_constant(a.precision_parent, "a column's prior precision") for a in As]),
+        "C_prior_mean": np.hstack([c.mean_parent.value for c in Cs]).astype(float),
+        "C_prior_prec": np.stack([_diag_constant(c.precision_parent, "a column's prior precision") for c in Cs]),
+    }
+    for a in As + Cs:
+        if not isinstance(a.mean_parent, N.Constant):
+            _fail("matrix columns need Constant mean parents")
+    if kind == "diagonal_gamma":
+        pri.update(Q_a0=Q.a0s, Q_b0=Q.b0s, R_a0=R.a0s, R_b0=R.b0s)
+    else:
+        pri.update(Q_a0=float(Q.a0), Q_b0=float(Q.b0), R_a0=float(R.a0), R_b0=float(R.b0))
+    for col in As + Cs:
+        cov = col.__dict__["_h_qcov"]
+        if np.abs(cov - np.diag(np.diag(cov))).max() != 0.0:
+            _fail("initial column covariances must be diagonal")
+    return dict(Xs=Xs, Ys=Ys, As=As, Cs=Cs, A=A, C=C, Q=Q, R=R, pri=pri)
+
+
+def bind(node):
+    d = describe(node)
+    return LDSPlan(**d)

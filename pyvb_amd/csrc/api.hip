@@ -395,23 +395,20 @@ int pyvb_lds_update_x(pyvb_lds* h, int t) {
     return PYVB_OK;
 }
 
-int pyvb_lds_update_A(pyvb_lds* h) {
+int pyvb_lds_update_columns(pyvb_lds* h, int which, int col_begin, int col_end) {
     ENTER(h);
+    ARGCHK(which == 0 || which == 1, "which must be 0 (A) or 1 (C)");
+    ARGCHK(col_begin >= 0 && col_begin < col_end && col_end <= h->D, "bad column range");
     int rc = ensure_stats(h);
     if (rc) return rc;
-    if ((rc = launch_cols(h, 0))) return rc;
-    params_changed(h); h->resQ_valid = false;
+    if ((rc = launch_cols(h, which, col_begin, col_end))) return rc;
+    params_changed(h);
+    if (which == 0) h->resQ_valid = false; else h->resR_valid = false;
     return PYVB_OK;
 }
 
-int pyvb_lds_update_C(pyvb_lds* h) {
-    ENTER(h);
-    int rc = ensure_stats(h);
-    if (rc) return rc;
-    if ((rc = launch_cols(h, 1))) return rc;
-    params_changed(h); h->resR_valid = false;
-    return PYVB_OK;
-}
+int pyvb_lds_update_A(pyvb_lds* h) { ARGCHK(h, "handle is NULL"); return pyvb_lds_update_columns(h, 0, 0, h->D); }
+int pyvb_lds_update_C(pyvb_lds* h) { ARGCHK(h, "handle is NULL"); return pyvb_lds_update_columns(h, 1, 0, h->D); }
 
 int pyvb_lds_update_Q(pyvb_lds* h) {
     ENTER(h);

@@ -21,6 +21,7 @@ struct ParamArgs {
     double *resQ, *resR, *elbo;
     Priors pri;
     int N, T, D, K, noise;
+    int c0, c1;             // k_cols: columns [c0, c1) are updated
     Layout L;
 };
 
@@ -115,11 +116,11 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
     const double lam = live ? (WHICH == 0 ? a.Q_a[(size_t)n * D + lane] / a.Q_b[(size_t)n * D + lane]
                                           : a.R_a[(size_t)n * K + lane] / a.R_b[(size_t)n * K + lane]) : 0.0;
     const int lr = live ? lane : 0;                 // clamped row for the per-lane prior loads
-    double grow_n = G[lc], p0_n = pp[lr], pm_n = pm[(size_t)lr * D];
+    double grow_n = G[(size_t)a.c0 * D + lc], p0_n = pp[(size_t)a.c0 * rows + lr], pm_n = pm[(size_t)lr * D + a.c0];
     __syncthreads();
-    for (int i = 0; i < D; ++i) {
+    for (int i = a.c0; i < a.c1; ++i) {
         const double grow = grow_n, p0 = p0_n, m0 = pm_n;
-        const int in = i + 1 < D ? i + 1 : i;
+        const int in = i + 1 < a.c1 ? i + 1 : i;
         grow_n = G[(size_t)in * D + lc];
         p0_n = pp[(size_t)in * rows + lr];
         pm_n = pm[(size_t)lr * D + in];
@@ -315,7 +316,7 @@ static ParamArgs make_args(pyvb_lds* h) {
     a.A_mean = h->A_mean; a.A_var = h->A_var; a.C_mean = h->C_mean; a.C_var = h->C_var;
     a.Q_a = h->Q_a; a.Q_b = h->Q_b; a.R_a = h->R_a; a.R_b = h->R_b; a.qld_A = h->qld_A; a.qld_C = h->qld_C;
     a.resQ = h->resQ; a.resR = h->resR; a.elbo = h->elbo; a.pri = h->pri;
-    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L;
+    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L; a.c0 = 0; a.c1 = h->D;
     return a;
 }
 
@@ -327,8 +328,9 @@ int launch_moments(pyvb_lds* h) {
     return PYVB_OK;
 }
 
-int launch_cols(pyvb_lds* h, int which) {
+int launch_cols(pyvb_lds* h, int which, int c0, int c1) {
     ParamArgs a = make_args(h);
+    a.c0 = c0; a.c1 = c1;
     TimedLaunch tl(h, PYVB_K_PARAMS);
     if (which == 0) hipLaunchKernelGGL(k_cols<0>, dim3(h->N), dim3(64), 0, h->stream, a);
     else hipLaunchKernelGGL(k_cols<1>, dim3(h->N), dim3(64), 0, h->stream, a);

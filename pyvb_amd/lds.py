@@ -111,6 +111,10 @@ class LDSBatch(object):
     def update_C(self):
         C.check(C.lib.pyvb_lds_update_C(self._h))
 
+    def update_columns(self, which, col_begin, col_end):
+        """As[i].update() (which = "A") or Cs[i].update() ("C") for i in [col_begin, col_end), in order."""
+        C.check(C.lib.pyvb_lds_update_columns(self._h, 0 if which == "A" else 1, int(col_begin), int(col_end)))
+
     def update_Q(self):
         C.check(C.lib.pyvb_lds_update_Q(self._h))
 

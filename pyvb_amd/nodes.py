@@ -1,0 +1,370 @@
+"""pyvb's node API on top of the MI355X kernels.
+
+Same classes, constructor signatures, attributes and error behaviour as the reference's
+src/pyvb/nodes/{node,gaussian,nodes_todo}.py, so a script such as
+examples/Linear_Dynamic_System.py runs unchanged with `from pyvb_amd import nodes`.
+The difference is where the arithmetic happens: the nodes only record the graph.  The first
+call that needs a posterior (`update()`, reading `qmu`, `Network.learn` ...) hands the connected
+graph to a recogniser; if it is the linear-dynamical-system graph of that example the state
+moves to the GPU (pyvb_amd.lds.LDSBatch, one replicate) and from then on
+
+  * `node.update()` only queues the request;
+  * the queue is flushed when a result is read, and runs of requests that spell a whole sweep --
+    `[x.update() for x in Xs]`, its reverse, `[a.update() for a in As]` ... -- become one kernel
+    launch each (Linear_Dynamic_System.py:69-77); anything else falls back to per-node launches;
+  * `qmu`, `qcov`, `qa`, `qb` ... read back from the device.
+
+Graphs the recogniser does not know have no HIP path and raise NotImplementedError: there is
+no CPU execution of updates in this package.  The `pass_down_*` accessors, which the reference's
+examples use for plotting, combine posteriors already fetched from the device on the host.
+"""
+import numpy as np
+
+__all__ = ["Node", "Addition", "Multiplication", "Constant", "hstack", "Transpose", "Gaussian",
+           "DiagonalGaussian", "Gamma", "DiagonalGamma", "Wishart", "ConjugacyError"]
+
+
+class ConjugacyError(ValueError):            # nodes_todo.py:8-10
+    def __init__(self, message):
+        ValueError.__init__(self, message)
+
+
+# -------------------------------------------------------------------------------------------------
+# operation nodes (node.py)
+# -------------------------------------------------------------------------------------------------
+class Node(object):
+    """Base class: shape, children, operator overloads (node.py:6-50)."""
+    __array_ufunc__ = None       # let `ndarray * node` reach __rmul__ instead of broadcasting over the array
+
+    def __init__(self, shape):
+        self.children = []
+        self.shape = shape
+        self._plan = None
+
+    def addChild(self, child):
+        self.children.append(child)
+
+    def update(self):
+        pass
+
+    def log_lower_bound(self):
+        return 0.
+
+    def __add__(self, other):
+        return Addition(self, other)
+
+    def __mul__(self, other):
+        return Multiplication(self, other)
+
+    def __rmul__(self, other):
+        return Multiplication(other, self)
+
+
+def _wrap(x):
+    return Constant(x) if isinstance(x, np.ndarray) else x
+
+
+class Addition(Node):
+    """A + B (node.py:52-129).  Arrays are wrapped in Constant before they are linked, which
+    the reference intends but does not do."""
+
+    def __init__(self, A, B):
+        assert A.shape == B.shape, "Bad shapes for addition"
+        Node.__init__(self, A.shape)
+        self.A, self.B = _wrap(A), _wrap(B)
+        self.A.addChild(self)
+        self.B.addChild(self)
+
+    def pass_down_Ex(self):
+        return self.A.pass_down_Ex() + self.B.pass_down_Ex()
+
+    def pass_down_ExxT(self):
+        outer = np.dot(self.A.pass_down_Ex(), self.B.pass_down_Ex().T)
+        return self.A.pass_down_ExxT() + self.B.pass_down_ExxT() + outer + outer.T
+
+
+class Multiplication(Node):
+    """A * B with B a column vector (node.py:131-276)."""
+
+    def __init__(self, A, B):
+        m1, n1 = A.shape
+        m2, n2 = B.shape
+        assert n1 == m2, "incompatible multiplication dimensions"
+        assert n2 == 1, "right hand object must be a vector"
+        Node.__init__(self, (m1, n2))
+        self.A, self.B = _wrap(A), _wrap(B)
+        self.A.addChild(self)
+        self.B.addChild(self)
+
+    def pass_down_Ex(self):                     # node.py:235-242
+        return np.dot(self.A.pass_down_Ex(), self.B.pass_down_Ex())
+
+    def pass_down_ExxT(self):                   # node.py:244-276, hstack and Constant branches
+        BBT = self.B.pass_down_ExxT()
+        if isinstance(self.A, Constant):
+            Am = self.A.pass_down_Ex()
+            return np.dot(Am, np.dot(BBT, Am.T))
+        if hasattr(self.A, "parents"):
+            Am = self.A.pass_down_Ex()
+            ret = np.dot(Am, np.dot(BBT, Am.T))
+            for i, p in enumerate(self.A.parents):
+                ret += p.qcov * float(BBT[i, i])
+            return ret
+        raise NotImplementedError("pass_down_ExxT for this left operand")
+
+
+class Constant(Node):
+    """A fixed array (node.py:279-311)."""
+
+    def __init__(self, value):
+        Node.__init__(self, value.shape)
+        self.value = value
+        self.value_xxT = np.dot(value, value.T)
+        self.value_xTx = np.dot(value.T, value)
+        if self.shape[0] == self.shape[1]:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                self.lndet = np.log(np.linalg.det(self.value))
+
+    def pass_down_Ex(self):
+        return self.value
+
+    def pass_down_ExxT(self):
+        return self.value_xxT
+
+    def pass_down_ExTx(self):
+        return self.value_xTx
+
+    def pass_down_lndet(self):
+        return self.lndet
+
+
+class hstack(Node):
+    """A matrix whose columns are Gaussian nodes (nodes_todo.py:12-62)."""
+
+    def __init__(self, parents):
+        assert type(parents) == list
+        dims = [e.shape[0] for e in parents]
+        assert np.all(dims[0] == np.array(dims)), "dimensions incompatible"
+        Node.__init__(self, (dims[0], len(parents)))
+        self.parents = parents
+        [e.addChild(self) for e in self.parents]
+
+    def pass_down_Ex(self):
+        return np.hstack([e.pass_down_Ex() for e in self.parents])
+
+    def pass_down_ExxT(self):
+        return np.sum([p.pass_down_ExxT() for p in self.parents], 0)
+
+    def pass_down_ExTx(self):
+        raise NotImplementedError
+
+
+class Transpose(Node):
+    """The reference's Transpose raises NameError on construction; there is no such path."""
+
+    def __init__(self, parent):
+        raise NotImplementedError("Transpose is broken in the reference (nodes_todo.py:65-72) and has no HIP path")
+
+
+# -------------------------------------------------------------------------------------------------
+# random-variable nodes
+# -------------------------------------------------------------------------------------------------
+def _plan_of(node):
+    if node._plan is None:
+        from . import _recognise
+        _recognise.bind(node)
+    return node._plan
+
+
+class _DeviceAttr(object):
+    """Attribute that lives on the host until the graph is bound, on the device afterwards."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        if obj._plan is not None:
+            return obj._plan.read(obj, self.name)
+        return obj.__dict__.get("_h_" + self.name)
+
+    def __set__(self, obj, value):
+        obj.__dict__["_h_" + self.name] = value
+        if getattr(obj, "_plan", None) is not None:
+            obj._plan.write(obj, self.name, value)
+
+
+class Gaussian(Node):
+    """q(x) = N(qmu, qcov) with a Gaussian-family mean parent and a Gamma-family precision parent
+    (gaussian.py:9-183)."""
+    qmu = _DeviceAttr("qmu")
+    qcov = _DeviceAttr("qcov")
+    q_ln_det = _DeviceAttr("q_ln_det")
+
+    def __init__(self, dim, pmu, pprec):
+        Node.__init__(self, (dim, 1))
+        assert pmu.shape == self.shape, "Parent node (or array) has incorrect dimension"
+        if type(pmu) == np.ndarray:
+            self.mean_parent = Constant(pmu)
+        elif isinstance(pmu, (Gaussian, Addition, Multiplication, Constant)):
+            self.mean_parent = pmu
+        else:
+            raise ConjugacyError("mean parent for a Gaussian node should be one of:\nGaussian\nConstant\nAddition\n"
+                                 "Multiplication\nnumpy array. \n\n" + str(type(pmu)) + " is invalid")
+        assert pprec.shape == (self.shape[0], self.shape[0]), "Parent precision array has incorrect dimension"
+        if type(pprec) == np.ndarray:
+            self.precision_parent = Constant(pprec)
+        elif isinstance(pprec, (Gamma, DiagonalGamma, Wishart, Constant)):
+            self.precision_parent = pprec
+        else:
+            raise ConjugacyError("Precision parent for a Gaussian node should be one of:\nGamma\nDiagonalGamma\nWishart\n"
+                                 "Constant\nnumpy array. \n\n" + str(type(pprec)) + " is invalid")
+        self.mean_parent.addChild(self)
+        self.precision_parent.addChild(self)
+        self.observed = False
+        self.partially_observed = False
+        # random initial posterior, gaussian.py:70-72
+        self.qmu = np.random.randn(self.shape[0], 1)
+        self.qprec = np.eye(self.shape[0]) * np.random.rand()
+        self.qcov = np.linalg.inv(self.qprec)
+
+    def observe(self, val):                     # gaussian.py:74-100
+        assert val.shape == self.shape, "Bad shape for observation data"
+        if np.isnan(val).all():
+            return
+        elif np.isnan(val).any():
+            self.partially_observed = True
+            self.obs_value = val
+            self.obs_index = np.nonzero(1 - np.isnan(val))[0]
+            self.missing_index = np.nonzero(np.isnan(val))[0]
+        else:
+            self.observed = True
+            self.qmu = val.copy()               # the reference keeps a reference to the caller's array (Q10)
+            self.qcov = np.zeros((self.shape[0], self.shape[0]))
+
+    def update(self):                           # gaussian.py:102-134
+        if self.observed:
+            return
+        _plan_of(self).enqueue(self)
+
+    def log_lower_bound(self):
+        return _plan_of(self).node_llb(self)
+
+    def pass_down_Ex(self):
+        return self.qmu
+
+    def pass_down_ExxT(self):
+        return np.dot(self.qmu, self.qmu.T) + self.qcov
+
+    def pass_down_ExTx(self):
+        return np.trace(self.pass_down_ExxT())
+
+
+class DiagonalGaussian(Gaussian):               # gaussian.py:185-203
+    def __init__(self, dim, pmu, pprec):
+        Gaussian.__init__(self, dim, pmu, pprec)
+        self.shape = (self.shape[0], self.shape[0])
+
+    def pass_down_Ex(self):
+        return np.diag(self.qmu[:, 0])
+
+    def pass_down_ExxT(self):
+        return np.diag(self.qmu[:, 0] * self.qmu[:, 0] + np.diag(self.qcov))
+
+    def pass_down_ExTx(self):
+        return self.pass_down_ExxT()
+
+
+class _NoiseNode(object):
+    """Shared behaviour of Gamma, DiagonalGamma and Wishart (nodes_todo.py:88-234)."""
+    qb = _DeviceAttr("qb")
+
+    def _init_common(self, dim):
+        self.shape = (dim, dim)
+        self.children = []
+        self._plan = None
+
+    def update(self):
+        _plan_of(self).enqueue(self)
+
+    def log_lower_bound(self):
+        return _plan_of(self).node_llb(self)
+
+
+class Gamma(_NoiseNode):                        # nodes_todo.py:88-157
+    def __init__(self, dim, a0, b0):
+        self._init_common(dim)
+        self.a0, self.b0 = a0, b0
+        self.update_a()
+        self.qb = np.random.rand()
+
+    def addChild(self, child):
+        self.children.append(child)
+        self.update_a()
+
+    def update_a(self):
+        self.qa = self.a0
+        for child in self.children:
+            self.qa += 0.5 * child.shape[0]
+
+    def pass_down_Ex(self):
+        return np.eye(self.shape[0]) * self.qa / self.qb
+
+    def pass_down_lndet(self):
+        return self.shape[0] * (np.log(self.qa) - np.log(self.qb))
+
+
+class DiagonalGamma(_NoiseNode):                # nodes_todo.py:159-204
+    def __init__(self, dim, a0s, b0s):
+        self._init_common(dim)
+        assert a0s.size == self.shape[0]
+        assert b0s.size == self.shape[0]
+        self.a0s = a0s.flatten()
+        self.b0s = b0s.flatten()
+        self.update_a()
+        self.qb = np.random.rand()
+
+    def addChild(self, child):
+        assert child.shape == (self.shape[0], 1)
+        self.children.append(child)
+        self.update_a()
+
+    def update_a(self):
+        self.qa = self.a0s.copy()
+        for child in self.children:
+            self.qa += 0.5
+
+    def pass_down_Ex(self):
+        return np.diag(self.qa / self.qb)
+
+    def pass_down_lndet(self):
+        return np.log(np.prod(self.qa / self.qb))
+
+
+class Wishart(_NoiseNode):                      # nodes_todo.py:205-234
+    """Constructible, so that graphs can name it; no HIP path yet."""
+
+    def __init__(self, dim, v0, w0):
+        self._init_common(dim)
+        assert w0.shape == self.shape
+        self.v0, self.w0 = v0, w0
+        self.update_v()
+        l = np.random.randn(self.shape[0], 1)
+        self.qw = np.dot(l, l.T)
+
+    def addChild(self, child):
+        assert child.shape == (self.shape[0], 1)
+        self.children.append(child)
+        self.update_v()
+
+    def update_v(self):
+        self.qv = self.v0
+        for child in self.children:
+            self.qv += 0.5
+
+    def update(self):
+        raise NotImplementedError("Wishart noise has no HIP path (SURVEY.md §8f item 4)")
+
+    def pass_down_Ex(self):
+        return self.qv * np.linalg.inv(self.qw)

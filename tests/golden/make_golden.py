@@ -169,6 +169,32 @@ def run_case(ref, name, T, D, K, kind, iters, seed, dense_cov=False):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def crawl_labels(mod, T=4, D=2, K=3):
+    """Order in which Network.fetch_network() (network.py:58-96) discovers the LDS graph from [A]."""
+    from pyvb_amd import synth
+    Y, st0, pri = synth.make_problem(T, D, K, 1, 5)
+    g = build_graph(mod.nodes, Y[0], pri, st0)
+    label = {}
+    for nm in ("As", "Cs", "Xs", "Ys"):
+        for i, n in enumerate(g[nm]):
+            label[id(n)] = "%s%d" % (nm[0], i)
+    for nm in ("A", "C", "Q", "R"):
+        label[id(g[nm])] = "h" + nm if nm in "AC" else nm
+    net = mod.Network([g["A"]])
+    net.fetch_network()
+    out = []
+    for n in net.nodes:
+        if id(n) in label:
+            out.append(label[id(n)])
+        else:
+            cls = type(n).__name__
+            if cls == "Multiplication":
+                out.append("M(%s,%s)" % (label[id(n.A)], label[id(n.B)]))
+            else:
+                out.append(cls)
+    return out
+
+
 CASES = [
     # name, T, D, K, noise, checkpoints, seed, dense column covariances stored
     ("example_d2k5_t200", 200, 2, 5, "diagonal_gamma", (1, 2, 5), 20240, True),
@@ -187,6 +213,9 @@ if __name__ == "__main__":
     warnings.simplefilter("ignore", DeprecationWarning)
     ref = load_reference()
     sel = sys.argv[1:]
+    if not sel or sel == ["small"] or "crawl" in sel:
+        np.savez_compressed(os.path.join(HERE, "crawl_lds_t4.npz"), order=np.array(crawl_labels(ref)))
+        print("wrote crawl_lds_t4.npz")
     for c in CASES:
         if sel and sel != ["small"] and c[0] not in sel:
             continue

@@ -1,0 +1,126 @@
+"""CPU-only tests of the pyvb-compatible front end: constructors, error behaviour, the network
+crawl order (against the order recorded from the reference) and the LDS recogniser.  No kernel runs."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from pyvb_amd import nodes, synth, _recognise
+from pyvb_amd.network import Network
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden_module():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _graph(T=6, D=3, K=4, kind="diagonal_gamma", seed=3):
+    Y, st0, pri = synth.make_problem(T, D, K, 1, seed)
+    pri["noise"] = kind
+    if kind == "gamma":
+        for k in ("Q_a0", "Q_b0", "R_a0", "R_b0"):
+            pri[k] = np.float64(1e-3)
+    return _golden_module().build_graph(nodes, Y[0], pri, st0), Y, st0, pri
+
+
+def test_constructor_checks_match_the_reference():
+    with pytest.raises(AssertionError):                      # gaussian.py:46
+        nodes.Gaussian(3, np.zeros((2, 1)), np.eye(3))
+    with pytest.raises(AssertionError):                      # gaussian.py:55
+        nodes.Gaussian(3, np.zeros((3, 1)), np.eye(2))
+    g = nodes.Gaussian(2, np.zeros((2, 1)), np.eye(2))
+    class Fake(object):
+        def __init__(self, shape):
+            self.shape = shape
+    with pytest.raises(nodes.ConjugacyError):                # gaussian.py:52: not a Gaussian-family mean parent
+        nodes.Gaussian(2, Fake((2, 1)), np.eye(2))
+    with pytest.raises(nodes.ConjugacyError):                # gaussian.py:61: not a Gamma-family precision parent
+        nodes.Gaussian(2, np.zeros((2, 1)), Fake((2, 2)))
+    assert issubclass(nodes.ConjugacyError, ValueError)
+    with pytest.raises(AssertionError):                      # node.py:166-167
+        nodes.Multiplication(nodes.Constant(np.eye(3)), g)
+    with pytest.raises(AssertionError):
+        nodes.Addition(g, nodes.Constant(np.zeros((3, 1))))
+    with pytest.raises(AssertionError):                      # nodes_todo.py:180
+        nodes.DiagonalGamma(3, np.ones(3), np.ones(3)).addChild(g)
+    with pytest.raises(AssertionError):
+        g.observe(np.zeros((3, 1)))
+
+
+def test_operator_overloads_and_array_wrapping():
+    g = nodes.Gaussian(2, np.zeros((2, 1)), np.eye(2))
+    m = np.ones((3, 2)) * g                                  # ndarray * node -> Multiplication with a Constant (Q4 fixed)
+    assert isinstance(m, nodes.Multiplication) and isinstance(m.A, nodes.Constant) and m.shape == (3, 1)
+    assert m in g.children and m in m.A.children
+    s = g + np.ones((2, 1))
+    assert isinstance(s, nodes.Addition) and isinstance(s.B, nodes.Constant)
+    c = nodes.Constant(np.diag([2.0, 3.0]))
+    assert np.isclose(c.pass_down_lndet(), np.log(6.0))
+
+
+def test_noise_node_bookkeeping():
+    Q = nodes.DiagonalGamma(2, np.ones(2) * 1e-3, np.ones(2) * 1e-3)
+    G = nodes.Gamma(3, 1e-3, 1e-3)
+    for _ in range(4):
+        nodes.Gaussian(2, np.zeros((2, 1)), Q)
+        nodes.Gaussian(3, np.zeros((3, 1)), G)
+    assert np.allclose(Q.qa, 1e-3 + 0.5 * 4)                 # nodes_todo.py:183-186
+    assert np.isclose(G.qa, 1e-3 + 0.5 * 3 * 4)              # nodes_todo.py:125-128
+    assert Q.pass_down_Ex().shape == (2, 2) and G.pass_down_Ex().shape == (3, 3)
+
+
+def test_observe_variants():
+    g = nodes.Gaussian(3, np.zeros((3, 1)), np.eye(3))
+    g.observe(np.full((3, 1), np.nan))                       # gaussian.py:90-91: nothing observed
+    assert not g.observed and not g.partially_observed
+    g.observe(np.array([[1.0], [np.nan], [2.0]]))            # :92-96
+    assert g.partially_observed and list(g.obs_index) == [0, 2] and list(g.missing_index) == [1]
+    h = nodes.Gaussian(2, np.zeros((2, 1)), np.eye(2))
+    v = np.array([[1.0], [2.0]])
+    h.observe(v)                                             # :97-100
+    assert h.observed and np.array_equal(h.qmu, v) and not h.qcov.any()
+    h.update()                                               # observed nodes return immediately (:109-110)
+
+
+def test_fetch_network_order_matches_reference():
+    z = np.load(os.path.join(HERE, "golden", "crawl_lds_t4.npz"), allow_pickle=False)
+    got = _golden_module().crawl_labels(__import__("pyvb_amd"), 4, 2, 3)
+    assert got == [str(s) for s in z["order"]]
+
+
+def test_recogniser_extracts_the_lds(capsys):
+    g, Y, st0, pri = _graph()
+    d = _recognise.describe(g["Q"])                          # any node of the graph will do
+    assert [x is y for x, y in zip(d["Xs"], g["Xs"])] == [True] * 6
+    assert [x is y for x, y in zip(d["Ys"], g["Ys"])] == [True] * 6
+    assert d["A"] is g["A"] and d["C"] is g["C"] and d["Q"] is g["Q"] and d["R"] is g["R"]
+    for k in ("x0_mean", "x0_prec", "A_prior_mean", "A_prior_prec", "C_prior_mean", "C_prior_prec", "Q_a0", "Q_b0", "R_a0", "R_b0"):
+        assert np.array_equal(np.asarray(d["pri"][k]), np.asarray(pri[k])), k
+    net = Network([g["C"]])
+    net.fetch_network(verbose=False)
+    net.find_iterable()
+    assert len(net.iterable_nodes) == 2 * 6 + 2 * 3 + 2
+
+
+def test_recogniser_refuses_other_graphs():
+    # simple mean inference (src/tests.py:9-19): a valid pyvb graph, but not the LDS path
+    mu = nodes.Gaussian(1, np.zeros((1, 1)), np.eye(1) * 1e-3)
+    prec = nodes.Gamma(1, 1e-3, 1e-3)
+    xs = [nodes.Gaussian(1, mu, prec) for _ in range(5)]
+    [x.observe(np.random.randn(1, 1)) for x in xs]
+    with pytest.raises(NotImplementedError):
+        mu.update()
+    # an LDS with a known entry of A (LDS_knowns_in_A.py:73-74)
+    g, Y, st0, pri = _graph()
+    g["As"][0].observe(np.array([[1.0], [np.nan], [np.nan]]))
+    with pytest.raises(NotImplementedError):
+        g["Xs"][0].update()
+    with pytest.raises(NotImplementedError):
+        nodes.Wishart(2, 1e-3, np.eye(2)).update()
+    with pytest.raises(NotImplementedError):
+        nodes.Transpose(mu)
