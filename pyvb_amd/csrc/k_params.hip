@@ -22,6 +22,7 @@ struct ParamArgs {
     Priors pri;
     int N, T, D, K, noise;
     int c0, c1;             // k_cols: columns [c0, c1) are updated
+    int which0;             // blockIdx.y + which0 selects the matrix / noise node (0: A, Q; 1: C, R)
     Layout L;
 };
 
@@ -85,10 +86,9 @@ __global__ void __launch_bounds__(256) k_moments(ParamArgs a) {
 // [a.update() for a in As] (WHICH = 0) / [c.update() for c in Cs] (WHICH = 1).
 // Lane k owns row k of the matrix; its row lives in LDS (Mb[col][lane]) together with its row of
 // H.  Row i of G is fetched one column ahead with one coalesced load and broadcast by readlane.
-template <int WHICH>
 __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
+    const int WHICH = a.which0 + blockIdx.y;
     __shared__ double Mb[64 * 64];     // Mb[col * 64 + row]
-    __shared__ double Hb[64 * 64];
     const int n = blockIdx.x, lane = threadIdx.x, D = a.D, K = a.K;
     const int rows = WHICH == 0 ? D : K;
     double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
@@ -101,26 +101,27 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
     const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
     const bool live = lane < rows;
     const int lc = lane < D ? lane : D - 1;         // clamped column for the coalesced row loads
-    for (int k0 = 0; k0 < rows; k0 += 8) {          // transpose rows of M and H into LDS, 8 rows of loads in flight
-        double m[8], hh[8];
+    for (int k0 = 0; k0 < rows; k0 += 8) {          // transpose the rows of M into LDS, 8 rows of loads in flight
+        double m[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int k = k0 + u < rows ? k0 + u : rows - 1;
             m[u] = M[(size_t)k * D + lc];
-            hh[u] = H[(size_t)k * D + lc];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (k0 + u < rows) { Mb[lc * 64 + k0 + u] = m[u]; Hb[lc * 64 + k0 + u] = hh[u]; }
+            if (k0 + u < rows) Mb[lc * 64 + k0 + u] = m[u];
     }
     const double lam = live ? (WHICH == 0 ? a.Q_a[(size_t)n * D + lane] / a.Q_b[(size_t)n * D + lane]
                                           : a.R_a[(size_t)n * K + lane] / a.R_b[(size_t)n * K + lane]) : 0.0;
     const int lr = live ? lane : 0;                 // clamped row for the per-lane prior loads
     double grow_n = G[(size_t)a.c0 * D + lc], p0_n = pp[(size_t)a.c0 * rows + lr], pm_n = pm[(size_t)lr * D + a.c0];
+    double h_n = H[(size_t)lr * D + a.c0];          // this lane's H[row][col], fetched one column ahead
     __syncthreads();
     for (int i = a.c0; i < a.c1; ++i) {
-        const double grow = grow_n, p0 = p0_n, m0 = pm_n;
+        const double grow = grow_n, p0 = p0_n, m0 = pm_n, hki = h_n;
         const int in = i + 1 < a.c1 ? i + 1 : i;
+        h_n = H[(size_t)lr * D + in];
         grow_n = G[(size_t)in * D + lc];
         p0_n = pp[(size_t)in * rows + lr];
         pm_n = pm[(size_t)lr * D + in];
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
         const double gii = bcast(grow, i);
         acc -= Mb[i * 64 + lane] * gii;                                        // j != i only
         const double prec = p0 + lam * gii;                                    // qprec  gaussian.py:117
-        const double num = p0 * m0 + lam * (Hb[i * 64 + lane] - acc);
+        const double num = p0 * m0 + lam * (hki - acc);
         const double val = num / prec;                                         // qmu    gaussian.py:122-123
         double lp = 0.0;
         if (live) {
@@ -147,8 +148,8 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
 }
 
 // res[k] = 1/2 own[k] + 1/2 <mu mu^T>[k,k] - (H M^T)[k,k]  for the children of Q (WHICH = 0) / R (1)
-template <int WHICH>
 __global__ void __launch_bounds__(64) k_resid(ParamArgs a) {
+    const int WHICH = a.which0 + blockIdx.y;
     __shared__ double Mb[64 * 64];
     const int n = blockIdx.x, lane = threadIdx.x, D = a.D, K = a.K;
     const int rows = WHICH == 0 ? D : K;
@@ -194,8 +195,8 @@ __global__ void __launch_bounds__(64) k_resid(ParamArgs a) {
     if (live) (WHICH == 0 ? a.resQ : a.resR)[(size_t)n * rows + lane] = 0.5 * own + 0.5 * e - hm;
 }
 
-template <int WHICH>
 __global__ void __launch_bounds__(64) k_noise(ParamArgs a) {
+    const int WHICH = a.which0 + blockIdx.y;
     const int n = blockIdx.x, lane = threadIdx.x;
     const int dim = WHICH == 0 ? a.D : a.K;
     const double* res = (WHICH == 0 ? a.resQ : a.resR) + (size_t)n * dim;
@@ -316,7 +317,7 @@ static ParamArgs make_args(pyvb_lds* h) {
     a.A_mean = h->A_mean; a.A_var = h->A_var; a.C_mean = h->C_mean; a.C_var = h->C_var;
     a.Q_a = h->Q_a; a.Q_b = h->Q_b; a.R_a = h->R_a; a.R_b = h->R_b; a.qld_A = h->qld_A; a.qld_C = h->qld_C;
     a.resQ = h->resQ; a.resR = h->resR; a.elbo = h->elbo; a.pri = h->pri;
-    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L; a.c0 = 0; a.c1 = h->D;
+    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L; a.c0 = 0; a.c1 = h->D; a.which0 = 0;
     return a;
 }
 
@@ -328,30 +329,30 @@ int launch_moments(pyvb_lds* h) {
     return PYVB_OK;
 }
 
+// which: 0 = A / Q, 1 = C / R, 2 = both in one launch (they are independent given the statistics)
 int launch_cols(pyvb_lds* h, int which, int c0, int c1) {
     ParamArgs a = make_args(h);
-    a.c0 = c0; a.c1 = c1;
+    a.c0 = c0; a.c1 = c1; a.which0 = which == 1 ? 1 : 0;
     TimedLaunch tl(h, PYVB_K_PARAMS);
-    if (which == 0) hipLaunchKernelGGL(k_cols<0>, dim3(h->N), dim3(64), 0, h->stream, a);
-    else hipLaunchKernelGGL(k_cols<1>, dim3(h->N), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(k_cols, dim3(h->N, which == 2 ? 2 : 1), dim3(64), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
 
 int launch_resid(pyvb_lds* h, int which) {
     ParamArgs a = make_args(h);
+    a.which0 = which == 1 ? 1 : 0;
     TimedLaunch tl(h, PYVB_K_PARAMS);
-    if (which == 0) hipLaunchKernelGGL(k_resid<0>, dim3(h->N), dim3(64), 0, h->stream, a);
-    else hipLaunchKernelGGL(k_resid<1>, dim3(h->N), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(k_resid, dim3(h->N, which == 2 ? 2 : 1), dim3(64), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
 
 int launch_noise(pyvb_lds* h, int which) {
     ParamArgs a = make_args(h);
+    a.which0 = which == 1 ? 1 : 0;
     TimedLaunch tl(h, PYVB_K_PARAMS);
-    if (which == 0) hipLaunchKernelGGL(k_noise<0>, dim3(h->N), dim3(64), 0, h->stream, a);
-    else hipLaunchKernelGGL(k_noise<1>, dim3(h->N), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(k_noise, dim3(h->N, which == 2 ? 2 : 1), dim3(64), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
