@@ -103,14 +103,38 @@ def main():
     comm = pdist.init(world, rank)         # gloo rendezvous for barriers / max-reduce; RCCL inside the library
     T, D, K, N = args.T, args.D, args.K, args.replicates
     Y, st0, pri = make_inputs(T, D, K, N, seed=20240 + 1000 * rank)
-    b = LDSBatch.from_problem(Y, st0, pri, device=local_rank)
+    from pyvb_amd import _capi
+    ndev = _capi.ctypes.c_int(0)
+    _capi.check(_capi.lib.pyvb_device_count(_capi.ctypes.byref(ndev)))
+    device = local_rank % max(ndev.value, 1)          # a launcher may already have narrowed the visible devices
+    b = LDSBatch.from_problem(Y, st0, pri, device=device)
     del Y
+    collective = "none (1 GPU)"
     if world > 1:
-        uid = comm.broadcast_bytes(LDSBatch.comm_unique_id() if rank == 0 else None)
-        b.comm_init(uid, rank, world)
+        # the one collective of the data path: all-reduce of the 6 lower-bound parts, over RCCL inside the library
+        uid, ok = None, 0.0
+        if rank == 0:
+            try:
+                uid = LDSBatch.comm_unique_id()
+            except Exception as e:
+                sys.stderr.write("rank 0: no RCCL unique id (%s)\n" % (e,))
+        uid = comm.broadcast_bytes(uid)
+        if uid is not None:
+            try:
+                b.comm_init(uid, rank, world)
+                ok = 1.0
+            except Exception as e:      # keep the run alive: the 48-byte reduction then goes over gloo, and the line says so
+                sys.stderr.write("rank %d: RCCL communicator failed (%s); reducing the lower bound over gloo\n" % (rank, e))
+        ok = -comm.max_float(-ok)       # min over ranks
+        collective = "rccl allreduce(6 x f64) per step" if ok == 1.0 else "gloo allreduce(6 x f64) per step (RCCL init failed)"
+        use_rccl = ok == 1.0
+    else:
+        use_rccl = False
 
     def step():
         b.iterate(1)
+        if world > 1 and not use_rccl:
+            return comm.allreduce_sum(b.elbo().sum(0))
         return b.elbo_total()           # device reduction over replicates (+ one ncclAllReduce of 6 doubles)
 
     for _ in range(args.warmup):
@@ -134,8 +158,17 @@ def main():
     bytes_per_launch = float(N) * 8 * T * (K + 2 * D)
     mean_ms = sweep_ms / max(sweep_n, 1)
     achieved = flops_per_launch / (mean_ms * 1e-3) / 1e12 if sweep_n else 0.0
+    # HBM bytes per k_sweep launch from the PMC passes committed with this round's profiles
+    # (profiles/collect_traffic.sh: FETCH_SIZE x2 per the gfx950 correction, + WRITE_SIZE; mean of the two directions)
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "r01", "traffic_pmc.json")
+    if os.path.exists(tpath) and (N, T, D, K) == (1024, 10000, 64, 64):
+        tj = json.load(open(tpath))
+        vals = [v["hbm_bytes_per_launch"] for k, v in tj.items() if "k_sweep" in k]
+        traffic = sum(vals) / len(vals) if vals else None
     roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel": "k_sweep", "launches": sweep_n, "mean_launch_ms": mean_ms,
                 "hbm_algorithmic_GBs": bytes_per_launch / (mean_ms * 1e-3) / 1e9 if sweep_n else 0.0}
 
@@ -153,7 +186,7 @@ def main():
             "vs_baseline": None, "dtype": "f64",
             "data": "synthetic LDS (simulated x_t = A x_{t-1} + w, y_t = C x_t + v; up to 128 distinct systems tiled, distinct initial posteriors)",
             "config": {"workload": "LDS T=%d D=%d K=%d, %d replicates per GPU (BASELINE configs[%d])" % (T, D, K, N, 2 if world == 1 else 3),
-                       "replicates_total": total_rep, "parallelism": "replicates sharded over %d GPU(s)" % world,
+                       "replicates_total": total_rep, "parallelism": "replicates sharded over %d GPU(s)" % world, "collective": collective,
                        "elbo_rel_err_vs_numpy": rel, "elbo_total": float(np.sum(elbo)),
                        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kt.items() if v[1]}},
             "roofline": roofline,

@@ -298,3 +298,19 @@ def test_headline_shape_against_oracle():
     # same values up to summation order
     assert np.all(np.abs(e[:2] - got) <= 1e-12 * np.abs(got).sum(axis=1, keepdims=True))
     big.close()
+
+
+def test_rccl_communicator_single_rank():
+    """The RCCL leg of pyvb_lds_elbo_total (dlopen of librccl, unique id, communicator, all-reduce on
+    the handle's stream) with a one-rank communicator: the sum over ranks is the local sum."""
+    from pyvb_amd.lds import LDSBatch
+    Y, st0, pri = synth.make_problem(50, 8, 8, 3, seed=5)
+    b = _batch(Y, st0, pri)
+    b.iterate(1)
+    local = b.elbo().sum(0)
+    uid = LDSBatch.comm_unique_id()
+    assert len(uid) == 128
+    b.comm_init(uid, 0, 1)
+    tot = b.elbo_total()
+    assert np.allclose(tot, local, rtol=1e-13)
+    b.close()
