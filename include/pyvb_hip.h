@@ -77,6 +77,11 @@ int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_pre
 /* Gaussian.observe for every Y_t (gaussian.py:74-100, full observations only). */
 int pyvb_lds_set_observations(pyvb_lds* h, const double* Y);
 
+/* As[i].observe(v) / Cs[i].observe(v) (gaussian.py:74-100; examples/LDS_knowns_in_A.py:73-74): known entries of the
+ * transition / observation matrices, A_obs[D][D] and C_obs[K][D] as (row, col), NaN = not observed; NULL = leave.
+ * Call after set_state: fully known columns take their value at once, partially known ones at their next update. */
+int pyvb_lds_set_column_observations(pyvb_lds* h, const double* A_obs, const double* C_obs);
+
 /* Explicit posterior state instead of the constructors' random initialisation
  * (gaussian.py:70-72, nodes_todo.py:119,177). */
 int pyvb_lds_set_state(pyvb_lds* h, const double* X, const double* A_mean, const double* A_colvar,

@@ -202,28 +202,54 @@ def statistics(st, Y):
 # ----------------------------------------------------------------------------
 # hstack columns  (Gaussian.update for As[i] / Cs[i])
 # ----------------------------------------------------------------------------
-def _update_columns(M, Mcov, prior_mean, prior_prec, Lam, G, H):
+def _update_columns(M, Mcov, prior_mean, prior_prec, Lam, G, H, obs=None):
     """Gauss-Seidel over the columns i = 0..D-1 of an hstack.
     hstack.pass_up_m1_m2 nodes_todo.py:43-62:
       m1 = sum_t Lam <x x^T>[i,i]                          (:56)
       m2 = sum_t (Lam mu_child) x[i] - sum_t sum_{j!=i} Lam <x x^T>[i,j] <m_j>   (:59-61)
     then Gaussian.update gaussian.py:117-123 with the column's Constant parents.
     G = sum <x x^T>, H = sum (child mean) x^T  ([rows, D]).  prior_prec[i] is the
-    diagonal of column i's prior precision."""
+    diagonal of column i's prior precision.
+    obs [rows, D]: observed entries of the matrix (NaN = not observed), as set by
+    As[i].observe(...) in examples/LDS_knowns_in_A.py:73-74.  A fully observed column never
+    updates (gaussian.py:109-110); a partially observed one is conditioned on its known
+    entries after the update (gaussian.py:125-134)."""
     N, rows, D = M.shape
-    qld = np.empty((N, D))
+    qld = np.full((N, D), np.nan)
     LH = np.einsum("nkl,nli->nki", Lam, H)
     for i in range(D):
+        known = None if obs is None else ~np.isnan(obs[:, i])
+        if known is not None and known.all():
+            continue
         prec = np.einsum("nkl,n->nkl", Lam, G[:, i, i]) + np.diag(prior_prec[i])[None]
         Gi = G[:, i, :].copy()
         Gi[:, i] = 0.0
         m2 = LH[:, :, i] - np.einsum("nkl,nl->nk", Lam, np.einsum("nlj,nj->nl", M, Gi))
         w = (prior_prec[i] * prior_mean[:, i])[None] + m2
         cov = np.linalg.inv(prec)
-        Mcov[:, i] = cov
-        M[:, :, i] = np.einsum("nkl,nl->nk", cov, w)
+        mu = np.einsum("nkl,nl->nk", cov, w)
         qld[:, i] = _chol_qld(prec)
+        if known is not None and known.any():
+            oi = np.nonzero(known)[0]
+            cov_obs_inv = np.linalg.inv(cov[:, oi][:, :, oi])
+            cov_obs_all = cov[:, :, oi]
+            gain = np.einsum("nko,nop->nkp", cov_obs_all, cov_obs_inv)
+            mu = mu + np.einsum("nko,no->nk", gain, obs[oi, i][None] - mu[:, oi])
+            cov = cov - np.einsum("nko,nlo->nkl", gain, cov_obs_all)
+        Mcov[:, i] = cov
+        M[:, :, i] = mu
     return qld
+
+
+def observe_columns(st, which, obs):
+    """Gaussian.observe on whole columns (gaussian.py:97-100): fully known columns take their
+    value with zero covariance at once; partially known ones only at their next update()."""
+    M, Mcov = st[which + "_mean"], st[which + "_cov"]
+    for i in range(M.shape[2]):
+        known = ~np.isnan(obs[:, i])
+        if known.all():
+            M[:, :, i] = obs[:, i][None]
+            Mcov[:, i] = 0.0
 
 
 def update_A(st, pri, S):
@@ -232,7 +258,7 @@ def update_A(st, pri, S):
     (<Q>, <Q> qmu_{t+1})."""
     Qb = noise_expect(pri["noise"], st["Q_a"], st["Q_b"], st["A_mean"].shape[1])
     st["qld_A"] = _update_columns(st["A_mean"], st["A_cov"], pri["A_prior_mean"],
-                                  pri["A_prior_prec"], Qb, S["Sxx_m"], S["Sx1x"])
+                                  pri["A_prior_prec"], Qb, S["Sxx_m"], S["Sx1x"], pri.get("A_obs"))
 
 
 def update_C(st, pri, S):
@@ -240,7 +266,7 @@ def update_C(st, pri, S):
     observed Y_t send (<R>, <R> y_t)."""
     Rb = noise_expect(pri["noise"], st["R_a"], st["R_b"], st["C_mean"].shape[1])
     st["qld_C"] = _update_columns(st["C_mean"], st["C_cov"], pri["C_prior_mean"],
-                                  pri["C_prior_prec"], Rb, S["Sxx"], S["Syx"])
+                                  pri["C_prior_prec"], Rb, S["Sxx"], S["Syx"], pri.get("C_obs"))
 
 
 # ----------------------------------------------------------------------------
@@ -331,19 +357,25 @@ def elbo_parts(st, pri, S, T):
     E, HM = _residual_second_moment(S["Syy"], st["C_mean"], st["C_cov"], S["Sxx"], S["Syx"])
     LY = T * (-0.5 * K * LN2PI + 0.5 * lndR) - 0.5 * np.einsum("nij,nji->n", Rb, E - 2 * HM)
 
-    def cols(M, Mcov, pm, pp, qldc, rows):
+    def cols(M, Mcov, pm, pp, qldc, rows, obs):
         # column i: Constant mean pm[:,i], Constant precision diag(pp[i])
         tot = np.zeros(N)
         for i in range(D):
+            known = np.zeros(rows, dtype=bool) if obs is None else ~np.isnan(obs[:, i])
             ex = np.einsum("nk,nl->nkl", M[:, :, i], M[:, :, i]) + Mcov[:, i] \
                 + np.outer(pm[:, i], pm[:, i])[None] - 2 * np.einsum("nk,l->nkl", M[:, :, i], pm[:, i])
             tot += -0.5 * rows * LN2PI + 0.5 * np.log(np.linalg.det(np.diag(pp[i]))) \
                 - 0.5 * np.einsum("k,nkk->n", pp[i], ex)
-            tot += 0.5 * rows * LN2PI + 0.5 * qldc[:, i] + 0.5 * rows
+            if not known.any():             # gaussian.py:145-147
+                tot += 0.5 * rows * LN2PI + 0.5 * qldc[:, i] + 0.5 * rows
+            elif not known.all():           # gaussian.py:148-150 (the sign of the 2 pi term is the reference's)
+                mi = np.nonzero(~known)[0]
+                cm = Mcov[:, i][:, mi][:, :, mi]
+                tot -= 0.5 * len(mi) * LN2PI - 0.5 * np.log(np.linalg.det(cm)) - 0.5 * len(mi)
         return tot
 
-    LA = cols(st["A_mean"], st["A_cov"], pri["A_prior_mean"], pri["A_prior_prec"], st["qld_A"], D)
-    LC = cols(st["C_mean"], st["C_cov"], pri["C_prior_mean"], pri["C_prior_prec"], st["qld_C"], K)
+    LA = cols(st["A_mean"], st["A_cov"], pri["A_prior_mean"], pri["A_prior_prec"], st["qld_A"], D, pri.get("A_obs"))
+    LC = cols(st["C_mean"], st["C_cov"], pri["C_prior_mean"], pri["C_prior_prec"], st["qld_C"], K, pri.get("C_obs"))
     LQ = noise_llb(kind, pri["Q_a0"], pri["Q_b0"], st["Q_a"], st["Q_b"])
     LR = noise_llb(kind, pri["R_a0"], pri["R_b0"], st["R_a"], st["R_b"])
     return np.stack([LX, LY, LA, LC, LQ, LR], axis=1)
@@ -363,6 +395,11 @@ def expand_state(st0, pri, T):
         st["Q_b"] = st["Q_b"][:, 0].copy()
         st["R_b"] = st["R_b"][:, 0].copy()
     init_noise_a(st, pri, T)
+    st["qld_A"] = np.full(st["A_mean"].shape[:1] + st["A_mean"].shape[2:], np.nan)
+    st["qld_C"] = st["qld_A"].copy()
+    for which in ("A", "C"):
+        if pri.get(which + "_obs") is not None:
+            observe_columns(st, which, pri[which + "_obs"])
     return st
 
 

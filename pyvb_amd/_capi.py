@@ -29,6 +29,7 @@ SIGNATURES = {
     "pyvb_lds_destroy": (ctypes.c_int, [_h]),
     "pyvb_lds_set_priors": (ctypes.c_int, [_h] + [_dp] * 10),
     "pyvb_lds_set_observations": (ctypes.c_int, [_h, _dp]),
+    "pyvb_lds_set_column_observations": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_lds_set_state": (ctypes.c_int, [_h] + [_dp] * 7),
     "pyvb_lds_get_state": (ctypes.c_int, [_h] + [_dp] * 9),
     "pyvb_lds_get_posterior_classes": (ctypes.c_int, [_h, _dp, _dp]),

@@ -35,6 +35,8 @@ class LDSPlan(object):
             C_mean=np.hstack([c.__dict__["_h_qmu"] for c in Cs]).reshape(1, K, D),
             C_colvar=diag(Cs).reshape(1, D, K),
             Q_b=qb(Q, D), R_b=qb(R, K))
+        if pri.get("A_obs") is not None:
+            self.batch.set_column_observations(pri["A_obs"], pri["C_obs"])
         self.index = {}
         for t, x in enumerate(Xs):
             self.index[id(x)] = ("x", t)
@@ -247,9 +249,17 @@ def describe(start):
     if any(y.partially_observed for y in Ys) or any(x.partially_observed or x.observed for x in Xs):
         _fail("partial observations")
     As, Cs = A.parents, C.parents
-    for col in As + Cs:
-        if col.observed or col.partially_observed:
-            _fail("observed matrix columns (LDS_knowns_in_A.py) are not supported yet")
+
+    def known_entries(cols, rows):
+        """As[i].observe(...) (examples/LDS_knowns_in_A.py:73-74) -> [rows, D] array, NaN = unknown"""
+        obs = np.full((rows, len(cols)), np.nan)
+        for i, col in enumerate(cols):
+            if col.observed:
+                obs[:, i] = col.__dict__["_h_qmu"].reshape(-1)
+            elif col.partially_observed:
+                obs[:, i] = col.obs_value.reshape(-1)
+        return obs
+
     kind = "diagonal_gamma" if isinstance(Q, N.DiagonalGamma) else "gamma"
     pri = {
         "noise": kind,
@@ -270,6 +280,8 @@ def describe(start):
         cov = col.__dict__["_h_qcov"]
         if np.abs(cov - np.diag(np.diag(cov))).max() != 0.0:
             _fail("initial column covariances must be diagonal")
+    if any(c.observed or c.partially_observed for c in As + Cs):
+        pri["A_obs"], pri["C_obs"] = known_entries(As, D), known_entries(Cs, K)
     return dict(Xs=Xs, Ys=Ys, As=As, Cs=Cs, A=A, C=C, Q=Q, R=R, pri=pri)
 
 

@@ -120,13 +120,15 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int)));
     TRYHIP(hipMemset(h->status, 0, sizeof(int)));
     // priors block: x0_mean D, x0_prec D*D, A_pm D*D, A_pp D*D, C_pm K*D, C_pp D*K, Q_a0 D, Q_b0 D, R_a0 K, R_b0 K
-    size_t pn = (size_t)D + 3 * (size_t)D * D + 2 * (size_t)K * D + 2 * (size_t)D + 2 * (size_t)K;
+    size_t pn = (size_t)D + 3 * (size_t)D * D + 2 * (size_t)K * D + 2 * (size_t)D + 2 * (size_t)K + (size_t)D * D + (size_t)K * D;
     TRY(dev_alloc(&h->pri_block, pn));
     double* p = h->pri_block;
     h->pri.x0_mean = p; p += D; h->pri.x0_prec = p; p += D * D;
     h->pri.A_pm = p; p += D * D; h->pri.A_pp = p; p += D * D;
     h->pri.C_pm = p; p += K * D; h->pri.C_pp = p; p += D * K;
     h->pri.Q_a0 = p; p += D; h->pri.Q_b0 = p; p += D; h->pri.R_a0 = p; p += K; h->pri.R_b0 = p; p += K;
+    h->pri.A_obs = p; p += D * D; h->pri.C_obs = p; p += K * D;
+    TRYHIP(hipMemset(h->pri.A_obs, 0xFF, ((size_t)D * D + (size_t)K * D) * sizeof(double)));     // all-ones bytes = NaN = nothing observed
     h->fresh = (unsigned char*)calloc(T, 1);
     h->world = 1;
     // q_ln_det is undefined until a node has been updated (the reference raises AttributeError)
@@ -234,6 +236,18 @@ int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_pre
     }
     if ((rc = h2d(h, h->Q_a, qa.data(), qa.size()))) return rc;
     if ((rc = h2d(h, h->R_a, ra.data(), ra.size()))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    params_changed(h);
+    h->resQ_valid = h->resR_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_lds_set_column_observations(pyvb_lds* h, const double* A_obs, const double* C_obs) {
+    ENTER(h);
+    int rc;
+    if ((rc = h2d(h, h->pri.A_obs, A_obs, (size_t)h->D * h->D))) return rc;
+    if ((rc = h2d(h, h->pri.C_obs, C_obs, (size_t)h->K * h->D))) return rc;
+    if ((rc = launch_observe(h))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     params_changed(h);
     h->resQ_valid = h->resR_valid = false;

@@ -56,6 +56,7 @@ static inline Layout make_layout(int D, int K) {
 
 struct Priors {          // device pointers, shared by all replicates
     double *x0_mean, *x0_prec, *A_pm, *A_pp, *C_pm, *C_pp, *Q_a0, *Q_b0, *R_a0, *R_b0;
+    double *A_obs, *C_obs;   // observed entries of the matrices, [row][col], NaN = not observed
     double x0_lndet;     // ln det of x0_prec (Constant.lndet, node.py:301-302)
 };
 
@@ -106,6 +107,7 @@ int launch_syy(pyvb_lds* h);
 int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal);
 int launch_stats(pyvb_lds* h);
 int launch_moments(pyvb_lds* h);
+int launch_observe(pyvb_lds* h);
 int launch_cols(pyvb_lds* h, int which, int c0, int c1);      // which: 0 = A, 1 = C; columns [c0, c1)
 int launch_resid(pyvb_lds* h, int which);     // 0 = Q, 1 = R
 int launch_noise(pyvb_lds* h, int which);

@@ -117,6 +117,8 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
     const int lr = live ? lane : 0;                 // clamped row for the per-lane prior loads
     double grow_n = G[(size_t)a.c0 * D + lc], p0_n = pp[(size_t)a.c0 * rows + lr], pm_n = pm[(size_t)lr * D + a.c0];
     double h_n = H[(size_t)lr * D + a.c0];          // this lane's H[row][col], fetched one column ahead
+    const double* obs = WHICH == 0 ? a.pri.A_obs : a.pri.C_obs;     // [row][col], NaN = not observed
+    double obs_n = obs[(size_t)lr * D + a.c0];
     __syncthreads();
     for (int i = a.c0; i < a.c1; ++i) {
         const double grow = grow_n, p0 = p0_n, m0 = pm_n, hki = h_n;
@@ -132,15 +134,23 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
         acc -= Mb[i * 64 + lane] * gii;                                        // j != i only
         const double prec = p0 + lam * gii;                                    // qprec  gaussian.py:117
         const double num = p0 * m0 + lam * (hki - acc);
-        const double val = num / prec;                                         // qmu    gaussian.py:122-123
+        double val = num / prec, var = 1.0 / prec;                             // qmu, qcov  gaussian.py:119-123
+        // known entries (Gaussian.observe on a column, LDS_knowns_in_A.py:73-74): conditioning a diagonal
+        // Gaussian on them (gaussian.py:125-134) pins those entries and leaves the others alone; a column
+        // whose entries are all known is thereby never changed (gaussian.py:109-110)
+        const double ob = obs_n;
+        obs_n = obs[(size_t)lr * D + in];
+        const bool known = live && (ob == ob);
+        if (known) { val = ob; var = 0.0; }
         double lp = 0.0;
         if (live) {
             Mb[i * 64 + lane] = val;
-            V[(size_t)i * rows + lane] = 1.0 / prec;                           // qcov (diagonal)
+            V[(size_t)i * rows + lane] = var;
             lp = 0.5 * log(prec);                                              // log of the Cholesky diagonal
         }
         lp = wave_sum(lp);
-        if (lane == 0) qld[i] = 0.5 / lp;                                      // gaussian.py:120 (quirk Q1)
+        const int nknown = (int)wave_sum(known ? 1.0 : 0.0);
+        if (lane == 0 && nknown < rows) qld[i] = 0.5 / lp;                     // gaussian.py:120 (quirk Q1)
     }
     __syncthreads();
     if (lane < D)
@@ -267,26 +277,33 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
     LX += (double)(T - 1) * (-0.5 * D * LN2PI + 0.5 * lndQ) - trQ;
     LX += (double)T * (0.5 * D * LN2PI + 0.5 * D) + 0.5 * (qx[0] + nint * qx[1] + qx[2]);
     const double LY = (double)T * (-0.5 * K * LN2PI + 0.5 * lndR) - trR;
-    // --- columns of A and C against their Constant parents
+    // --- columns of A and C against their Constant parents (gaussian.py:141-150).  The last term depends
+    // on how much of the column was observed: nothing -> the q_ln_det form (:147), some entries -> the
+    // covariance of the missing part (:150, with the reference's sign of the 2 pi term), all -> no term.
     double la = 0.0, lc = 0.0;
     if (lane < D) {
         const int i = lane;   // column i
-        double lndet = 0.0, tr = 0.0;
+        auto column = [&](int rows, const double* pp, const double* pm, const double* M, const double* V,
+                          const double* obs, double qld) {
+            double lndet = 0.0, tr = 0.0, lvar = 0.0;
+            int missing = 0;
 #pragma unroll 8
-        for (int k = 0; k < D; ++k) {
-            const double p = a.pri.A_pp[(size_t)i * D + k], m = a.A_mean[((size_t)n * D + k) * D + i], m0 = a.pri.A_pm[(size_t)k * D + i];
-            lndet += log(p);
-            tr += p * (m * m + a.A_var[((size_t)n * D + i) * D + k] + m0 * m0 - 2.0 * m * m0);
-        }
-        la = -0.5 * D * LN2PI + 0.5 * lndet - 0.5 * tr + 0.5 * D * LN2PI + 0.5 * a.qld_A[(size_t)n * D + i] + 0.5 * D;
-        lndet = 0.0; tr = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < K; ++k) {
-            const double p = a.pri.C_pp[(size_t)i * K + k], m = a.C_mean[((size_t)n * K + k) * D + i], m0 = a.pri.C_pm[(size_t)k * D + i];
-            lndet += log(p);
-            tr += p * (m * m + a.C_var[((size_t)n * D + i) * K + k] + m0 * m0 - 2.0 * m * m0);
-        }
-        lc = -0.5 * K * LN2PI + 0.5 * lndet - 0.5 * tr + 0.5 * K * LN2PI + 0.5 * a.qld_C[(size_t)n * D + i] + 0.5 * K;
+            for (int k = 0; k < rows; ++k) {
+                const double p = pp[(size_t)i * rows + k], m = M[(size_t)k * D + i], m0 = pm[(size_t)k * D + i];
+                const double v = V[(size_t)i * rows + k], ob = obs[(size_t)k * D + i];
+                lndet += log(p);
+                tr += p * (m * m + v + m0 * m0 - 2.0 * m * m0);
+                if (!(ob == ob)) { ++missing; lvar += log(v); }
+            }
+            double r = -0.5 * rows * LN2PI + 0.5 * lndet - 0.5 * tr;
+            if (missing == rows) r += 0.5 * rows * LN2PI + 0.5 * qld + 0.5 * rows;
+            else if (missing > 0) r -= 0.5 * missing * LN2PI - 0.5 * lvar - 0.5 * missing;
+            return r;
+        };
+        la = column(D, a.pri.A_pp, a.pri.A_pm, a.A_mean + (size_t)n * D * D, a.A_var + (size_t)n * D * D, a.pri.A_obs,
+                    a.qld_A[(size_t)n * D + i]);
+        lc = column(K, a.pri.C_pp, a.pri.C_pm, a.C_mean + (size_t)n * K * D, a.C_var + (size_t)n * D * K, a.pri.C_obs,
+                    a.qld_C[(size_t)n * D + i]);
     }
     const double LA = wave_sum(la), LC = wave_sum(lc);
     if (lane == 0) {
@@ -311,6 +328,20 @@ __global__ void __launch_bounds__(256) k_elbo_sum(SumArgs a) {
     }
 }
 
+// Gaussian.observe on fully known columns (gaussian.py:97-100): value in, covariance zero, for every replicate
+__global__ void __launch_bounds__(64) k_observe(ParamArgs a) {
+    const int WHICH = blockIdx.y, n = blockIdx.x, lane = threadIdx.x, D = a.D;
+    const int rows = WHICH == 0 ? a.D : a.K;
+    double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
+    double* V = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
+    const double* obs = WHICH == 0 ? a.pri.A_obs : a.pri.C_obs;
+    for (int i = 0; i < D; ++i) {
+        const double ob = lane < rows ? obs[(size_t)lane * D + i] : 0.0;
+        const int nknown = (int)wave_sum((lane < rows && ob == ob) ? 1.0 : 0.0);
+        if (nknown == rows && lane < rows) { M[(size_t)lane * D + i] = ob; V[(size_t)i * rows + lane] = 0.0; }
+    }
+}
+
 static ParamArgs make_args(pyvb_lds* h) {
     ParamArgs a;
     a.part = h->stats; a.nchunk = h->nchunk; a.mom = h->mom; a.Sigma = h->Sigma; a.qld_x = h->qld_x; a.X = h->X[h->cur]; a.Syy = h->Syy;
@@ -319,6 +350,13 @@ static ParamArgs make_args(pyvb_lds* h) {
     a.resQ = h->resQ; a.resR = h->resR; a.elbo = h->elbo; a.pri = h->pri;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L; a.c0 = 0; a.c1 = h->D; a.which0 = 0;
     return a;
+}
+
+int launch_observe(pyvb_lds* h) {
+    ParamArgs a = make_args(h);
+    hipLaunchKernelGGL(k_observe, dim3(h->N, 2), dim3(64), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
 }
 
 int launch_moments(pyvb_lds* h) {

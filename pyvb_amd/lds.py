@@ -71,6 +71,13 @@ class LDSBatch(object):
         arrs = [None if a is None else _f64(a, s, nm) for nm, a, s in shapes]
         C.check(C.lib.pyvb_lds_set_state(self._h, *[C.dptr(a) for a in arrs]))
 
+    def set_column_observations(self, A_obs=None, C_obs=None):
+        """Known entries of A ([D,D]) and C ([K,D]) as (row, col) arrays with NaN where unknown
+        (As[i].observe(...), examples/LDS_knowns_in_A.py:73-74).  Call after set_state."""
+        a = None if A_obs is None else _f64(A_obs, (self.D, self.D), "A_obs")
+        c = None if C_obs is None else _f64(C_obs, (self.K, self.D), "C_obs")
+        C.check(C.lib.pyvb_lds_set_column_observations(self._h, C.dptr(a), C.dptr(c)))
+
     # -- outputs ----------------------------------------------------------------------------
     def get_state(self, what=("X", "A_mean", "A_colvar", "C_mean", "C_colvar", "Q_a", "Q_b", "R_a", "R_b")):
         N, T, D, K = self.N, self.T, self.D, self.K
@@ -174,4 +181,6 @@ class LDSBatch(object):
         b.set_priors(pri)
         b.set_observations(Y)
         b.set_state(**{k: st0[k] for k in ("X", "A_mean", "A_colvar", "C_mean", "C_colvar", "Q_b", "R_b")})
+        if pri.get("A_obs") is not None or pri.get("C_obs") is not None:
+            b.set_column_observations(pri.get("A_obs"), pri.get("C_obs"))
         return b

@@ -77,16 +77,21 @@ def build_graph(nodes, Y, pri, st0):
         Xs.append(nodes.Gaussian(D, A * Xs[-1], Q))
         Ys.append(nodes.Gaussian(K, C * Xs[-1], R))
         Ys[-1].observe(Y[t].reshape(K, 1).copy())
+    # known entries of A and C (examples/LDS_knowns_in_A.py:73-74): NaN = unknown
+    for cols, key in ((As, "A_obs"), (Cs, "C_obs")):
+        if pri.get(key) is not None:
+            for i, col in enumerate(cols):
+                col.observe(pri[key][:, [i]].copy())
     # explicit initial state
     for t, x in enumerate(Xs):
         x.qmu = st0["X"][0, t].reshape(D, 1).copy()
     for i in range(D):
-        As[i].qmu = st0["A_mean"][0, :, [i]].reshape(D, 1).copy()
-        As[i].qcov = np.diag(st0["A_colvar"][0, i])
-        As[i].qprec = np.linalg.inv(As[i].qcov)
-        Cs[i].qmu = st0["C_mean"][0, :, [i]].reshape(K, 1).copy()
-        Cs[i].qcov = np.diag(st0["C_colvar"][0, i])
-        Cs[i].qprec = np.linalg.inv(Cs[i].qcov)
+        for col, mk, vk, rows in ((As[i], "A_mean", "A_colvar", D), (Cs[i], "C_mean", "C_colvar", K)):
+            if col.observed:            # a fully known column keeps its observation
+                continue
+            col.qmu = st0[mk][0, :, [i]].reshape(rows, 1).copy()
+            col.qcov = np.diag(st0[vk][0, i])
+            col.qprec = np.linalg.inv(col.qcov)
     if kind == "diagonal_gamma":
         Q.qb = st0["Q_b"][0].copy()
         R.qb = st0["R_b"][0].copy()
@@ -118,7 +123,7 @@ def snapshot(g, out, tag, kind, with_elbo=True, dense_cov=False):
         else:
             out[tag + nm + "_colvar"] = np.stack([np.diag(c) for c in cov])
             out[tag + nm + "_cov_offdiag_max"] = np.max([np.abs(c - np.diag(np.diag(c))).max() for c in cov])
-        out[tag + "qld_" + nm] = np.array([c.q_ln_det for c in cols])
+        out[tag + "qld_" + nm] = np.array([getattr(c, "q_ln_det", np.nan) for c in cols])
     if kind == "wishart":
         out[tag + "Q_a"], out[tag + "Q_b"] = np.float64(Q.qv), np.array(Q.qw)
         out[tag + "R_a"], out[tag + "R_b"] = np.float64(R.qv), np.array(R.qw)
@@ -131,10 +136,15 @@ def snapshot(g, out, tag, kind, with_elbo=True, dense_cov=False):
         out[tag + "elbo_parts"] = np.array(parts)
 
 
-def run_case(ref, name, T, D, K, kind, iters, seed, dense_cov=False):
+def run_case(ref, name, T, D, K, kind, iters, seed, dense_cov=False, knowns=False):
     from pyvb_amd import synth
     Y, st0, pri = synth.make_problem(T, D, K, 1, seed)
     pri["noise"] = kind
+    if knowns:      # one and two known entries in columns of A, a fully known column and a known entry in C
+        A_obs = np.full((D, D), np.nan); C_obs = np.full((K, D), np.nan)
+        A_obs[0, 0] = 1.0; A_obs[0, 1] = 0.05; A_obs[2, 1] = -0.3
+        C_obs[:, 0] = np.linspace(-1.0, 1.0, K); C_obs[1, 2] = 0.7
+        pri["A_obs"], pri["C_obs"] = A_obs, C_obs
     if kind == "gamma":
         for k in ("Q_a0", "Q_b0", "R_a0", "R_b0"):
             pri[k] = np.float64(1e-3)
@@ -206,6 +216,7 @@ CASES = [
     ("gamma_d4k5_t60", 60, 4, 5, "gamma", (1, 3), 20246, True),
     ("wishart_d3k4_t40", 40, 3, 4, "wishart", (1,), 20247, True),
     ("d64k64_t4", 4, 64, 64, "diagonal_gamma", (1, 2), 20248, False),
+    ("knowns_d3k4_t50", 50, 3, 4, "diagonal_gamma", (1, 2, 4), 20249, True, True),
 ]
 
 

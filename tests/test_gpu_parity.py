@@ -28,7 +28,8 @@ def _close(a, b, what, rtol=RTOL):
 
 def _close_qld(a, b, what):
     sa, sb = 0.5 / np.asarray(a, dtype=float), 0.5 / np.asarray(b, dtype=float)
-    assert np.all(np.abs(sa - sb) <= 1e-9 * np.maximum(1.0, np.abs(sb))), what
+    ok = np.isfinite(sb)            # never-updated (fully observed) columns have no q_ln_det
+    assert np.all(np.abs(sa - sb)[ok] <= 1e-9 * np.maximum(1.0, np.abs(sb[ok]))), what
 
 
 def _batch(Y, st0, pri):
@@ -314,3 +315,15 @@ def test_rccl_communicator_single_rank():
     tot = b.elbo_total()
     assert np.allclose(tot, local, rtol=1e-13)
     b.close()
+
+
+def test_known_matrix_entries_vs_oracle():
+    """Observed entries of A and C (LDS_knowns_in_A.py): partially and fully known columns."""
+    T, D, K, N = 80, 5, 6, 2
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=41)
+    A_obs = np.full((D, D), np.nan); C_obs = np.full((K, D), np.nan)
+    A_obs[0, 0] = 1.0; A_obs[1, 0] = 1e-2; A_obs[3, 2] = -0.5
+    A_obs[:, 4] = np.linspace(-0.2, 0.2, D)
+    C_obs[2, 1] = 3.0; C_obs[:, 3] = np.arange(K) - 2.0
+    pri["A_obs"], pri["C_obs"] = A_obs, C_obs
+    _stagewise(Y, st0, pri, iters=3)

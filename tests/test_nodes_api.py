@@ -115,12 +115,25 @@ def test_recogniser_refuses_other_graphs():
     [x.observe(np.random.randn(1, 1)) for x in xs]
     with pytest.raises(NotImplementedError):
         mu.update()
-    # an LDS with a known entry of A (LDS_knowns_in_A.py:73-74)
+    # an LDS whose outputs have missing values
     g, Y, st0, pri = _graph()
-    g["As"][0].observe(np.array([[1.0], [np.nan], [np.nan]]))
+    g["Ys"][2].observed = False
+    g["Ys"][2].observe(np.array([[1.0], [np.nan], [0.5], [np.nan]]))
     with pytest.raises(NotImplementedError):
         g["Xs"][0].update()
     with pytest.raises(NotImplementedError):
         nodes.Wishart(2, 1e-3, np.eye(2)).update()
     with pytest.raises(NotImplementedError):
         nodes.Transpose(mu)
+
+
+def test_recogniser_collects_known_matrix_entries():
+    """examples/LDS_knowns_in_A.py:73-74: As[i].observe([[v], [nan]]) reaches the plan as A_obs."""
+    g, Y, st0, pri = _graph()
+    g["As"][0].observe(np.array([[1.0], [np.nan], [np.nan]]))
+    g["Cs"][1].observe(np.array([[0.1], [0.2], [0.3], [0.4]]))
+    d = _recognise.describe(g["Xs"][0])
+    A_obs, C_obs = d["pri"]["A_obs"], d["pri"]["C_obs"]
+    assert A_obs.shape == (3, 3) and C_obs.shape == (4, 3)
+    assert A_obs[0, 0] == 1.0 and np.isnan(A_obs).sum() == 8
+    assert np.array_equal(C_obs[:, 1], [0.1, 0.2, 0.3, 0.4]) and np.isnan(C_obs).sum() == 8

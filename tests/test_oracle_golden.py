@@ -23,7 +23,8 @@ def _close_qld(a, b, what):
     """q_ln_det = 0.5 / s with s = sum(log diag chol) (quirk Q1) is ill-conditioned when
     s is near 0: compare s itself, whose rounding error is ~1e-16 * sum|log diag|."""
     sa, sb = 0.5 / np.asarray(a, dtype=float), 0.5 / np.asarray(b, dtype=float)
-    assert np.all(np.abs(sa - sb) <= 1e-10 * np.maximum(1.0, np.abs(sb))), what
+    ok = np.isfinite(sb)            # never-updated (fully observed) columns have no q_ln_det
+    assert np.all(np.abs(sa - sb)[ok] <= 1e-10 * np.maximum(1.0, np.abs(sb[ok]))), what
 
 
 def _prepare(st0, pri, T):
