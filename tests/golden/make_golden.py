@@ -179,6 +179,100 @@ def run_case(ref, name, T, D, K, kind, iters, seed, dense_cov=False, knowns=Fals
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def pca_problem(N, d, q, seed, p_missing=0.15):
+    """Data of examples/PCA_missing_data.py:11-28 (seeded, Bernoulli mask; one fully missing and one
+    fully observed row are forced in) with an explicit initial state."""
+    rng = np.random.default_rng(seed)
+    W = rng.standard_normal((d, q)); Z = rng.standard_normal((N, q)); mean = rng.standard_normal(d)
+    X = Z @ W.T + mean + rng.standard_normal((N, d)) * np.sqrt(1.0 / 20.0)
+    obs = rng.random((N, d)) > p_missing
+    obs[0, 0] = False                      # X_0 is the node updated before Mu: make it matter
+    if N > 3:
+        obs[2, :] = False
+        obs[3, :] = True
+    init = {"obs": obs,
+            "X": np.where(obs, X, rng.standard_normal((N, d))),       # data; random posterior means where missing
+            "W_mean": rng.standard_normal((d, q)), "Z": rng.standard_normal((N, q)),
+            "Z_cov": np.eye(q) / rng.random(), "Mu_mean": rng.standard_normal(d), "beta_b": rng.random()}
+    pri = {"W_prior_mean": np.zeros((d, q)), "W_prior_prec": np.full((q, d), 1e-3),
+           "Mu_prior_mean": np.zeros(d), "Mu_prior_prec": np.full(d, 1e-3), "beta_a0": 1e-3, "beta_b0": 1e-3}
+    return init, pri
+
+
+def pca_build_graph(mod, init, pri):
+    """Graph of examples/PCA_missing_data.py:31-42 with explicit initial posteriors; returns the network too."""
+    nodes = mod.nodes
+    N, d = init["X"].shape
+    q = init["Z"].shape[1]
+    Ws = [nodes.Gaussian(d, pri["W_prior_mean"][:, [i]].copy(), np.diag(pri["W_prior_prec"][i])) for i in range(q)]
+    W = nodes.hstack(Ws)
+    Mu = nodes.Gaussian(d, pri["Mu_prior_mean"].reshape(d, 1).copy(), np.diag(pri["Mu_prior_prec"]))
+    Beta = nodes.Gamma(d, float(pri["beta_a0"]), float(pri["beta_b0"]))
+    Zs = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q)) for n in range(N)]
+    Xs = [nodes.Gaussian(d, W * z + Mu, Beta) for z in Zs]
+    data = np.where(init["obs"], init["X"], np.nan)
+    [xn.observe(row.reshape(d, 1).copy()) for xn, row in zip(Xs, data)]
+    for i, w in enumerate(Ws):
+        w.qmu = init["W_mean"][:, [i]].copy()
+    for n, z in enumerate(Zs):
+        z.qmu = init["Z"][n].reshape(q, 1).copy()
+        z.qcov = init["Z_cov"].copy()
+    for n, x in enumerate(Xs):
+        if not x.observed:
+            x.qmu = init["X"][n].reshape(d, 1).copy()
+    Mu.qmu = init["Mu_mean"].reshape(d, 1).copy()
+    Beta.qb = float(init["beta_b"])
+    net = mod.Network()
+    net.addnode(W)
+    net.fetch_network()
+    return dict(Ws=Ws, W=W, Mu=Mu, Beta=Beta, Zs=Zs, Xs=Xs, net=net)
+
+
+def run_pca_case(ref, name, N, d, q, iters, seed):
+    init, pri = pca_problem(N, d, q, seed)
+    g = pca_build_graph(ref, init, pri)
+    net = g["net"]
+    net.find_iterable()
+    lab = {}
+    for key, pre in (("Ws", "W"), ("Zs", "Z"), ("Xs", "X")):
+        for i, n in enumerate(g[key]):
+            lab[id(n)] = "%s%d" % (pre, i)
+    lab[id(g["Mu"])], lab[id(g["Beta"])] = "Mu", "Beta"
+    out = {"N": N, "d": d, "q": q, "order": np.array([lab[id(n)] for n in net.iterable_nodes])}
+    for k, v in init.items():
+        out["init_" + k] = v
+    for k, v in pri.items():
+        out["prior_" + k] = v
+    groups = (g["Ws"], g["Zs"], g["Xs"], [g["Mu"]], [g["Beta"]])
+    for it in range(1, max(iters) + 1):
+        for n in net.iterable_nodes:            # network.py:46-48
+            n.update()
+        if it in iters:
+            tag = "it%d_" % it
+            out[tag + "W_mean"] = np.hstack([w.qmu for w in g["Ws"]])
+            out[tag + "W_var"] = np.stack([np.diag(w.qcov) for w in g["Ws"]])
+            out[tag + "W_cov_offdiag_max"] = np.max([np.abs(w.qcov - np.diag(np.diag(w.qcov))).max() for w in g["Ws"]])
+            out[tag + "Z"] = np.hstack([z.qmu for z in g["Zs"]]).T
+            out[tag + "Z_cov"] = g["Zs"][0].qcov
+            out[tag + "Z_cov_spread"] = np.max([np.abs(z.qcov - g["Zs"][0].qcov).max() for z in g["Zs"]])
+            out[tag + "X"] = np.hstack([x.qmu for x in g["Xs"]]).T
+            out[tag + "X_var"] = np.stack([np.diag(x.qcov) for x in g["Xs"]])
+            out[tag + "Mu_mean"] = g["Mu"].qmu.reshape(-1)
+            out[tag + "Mu_var"] = np.diag(g["Mu"].qcov)
+            out[tag + "beta_a"], out[tag + "beta_b"] = np.float64(g["Beta"].qa), np.float64(g["Beta"].qb)
+            out[tag + "elbo_parts"] = np.array([np.sum([float(n.log_lower_bound()) for n in grp]) for grp in groups])
+        print(name, "iteration", it, flush=True)
+    out["iters"] = np.array(sorted(iters))
+    path = os.path.join(HERE, "pca_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+PCA_CASES = [("example_n200_d5_q2", 200, 5, 2, (1, 2, 5), 30100),
+             ("n60_d12_q3", 60, 12, 3, (1, 3), 30101),
+             ("n40_d70_q17", 40, 70, 17, (1, 2), 30102)]
+
+
 def crawl_labels(mod, T=4, D=2, K=3):
     """Order in which Network.fetch_network() (network.py:58-96) discovers the LDS graph from [A]."""
     from pyvb_amd import synth
@@ -227,6 +321,9 @@ if __name__ == "__main__":
     if not sel or sel == ["small"] or "crawl" in sel:
         np.savez_compressed(os.path.join(HERE, "crawl_lds_t4.npz"), order=np.array(crawl_labels(ref)))
         print("wrote crawl_lds_t4.npz")
+    for c in PCA_CASES:
+        if not sel or sel == ["small"] or "pca" in sel or c[0] in sel:
+            run_pca_case(ref, *c)
     for c in CASES:
         if sel and sel != ["small"] and c[0] not in sel:
             continue
