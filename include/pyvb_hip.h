@@ -129,6 +129,42 @@ int pyvb_comm_unique_id(char id[128]);
 int pyvb_lds_comm_init(pyvb_lds* h, const char id[128], int rank, int world);
 int pyvb_lds_comm_destroy(pyvb_lds* h);
 
+/* ------------------------------------------------------------------------------------------------
+ * VB-PCA with missing data: the graph of examples/PCA_missing_data.py:31-42 --
+ *   W = hstack(q Gaussian columns of dim d), Mu Gaussian(d), Beta = Gamma(d), Z_n ~ N(0, I),
+ *   X_n ~ N(W * Z_n + Mu, Beta), X_n.observe(row with NaN for missing entries), n = 0..N-1.
+ * One handle holds N rows of one model; with several GPUs the rows are sharded (N_total rows in all,
+ * this handle's first row has global index row_offset) and the sums over n are all-reduced over RCCL.
+ * Arrays: X[N][d], Z[N][q], W_mean[d][q] (row, col), W_var[q][d] (column i, entry k), Z_cov[q][q],
+ * Mu_mean[d], Mu_var[d], X_rowvar[N] (variance of the missing entries of row n), beta_ab[2] = (qa, qb).
+ * Limits: d <= 256, q <= 32. */
+typedef struct pyvb_pca pyvb_pca;
+int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_total, long row_offset);
+int pyvb_pca_destroy(pyvb_pca* h);
+/* Constant parents of the W columns and of Mu (diagonal precisions), Gamma hyper-parameters (PCA_missing_data.py:31-34) */
+int pyvb_pca_set_priors(pyvb_pca* h, const double* W_prior_mean, const double* W_prior_prec,
+                        const double* Mu_prior_mean, const double* Mu_prior_prec, double beta_a0, double beta_b0);
+/* [x.observe(row) for x in Xs] (gaussian.py:74-100): NaN = missing; rows may be fully, partially or not observed */
+int pyvb_pca_set_data(pyvb_pca* h, const double* X);
+/* explicit posterior state; X_missing[N][d] supplies the posterior means of the missing entries only */
+int pyvb_pca_set_state(pyvb_pca* h, const double* X_missing, const double* W_mean, const double* Z, const double* Z_cov,
+                       const double* Mu_mean, const double* beta_b);
+int pyvb_pca_get_state(pyvb_pca* h, double* X, double* X_rowvar, double* W_mean, double* W_var, double* Z, double* Z_cov,
+                       double* Mu_mean, double* Mu_var, double* beta_ab);
+/* [w.update() for w in Ws]; [z.update() for z in Zs]; Xs[lo:hi] updates; Mu.update(); Beta.update() */
+int pyvb_pca_update_W(pyvb_pca* h);
+int pyvb_pca_update_Z(pyvb_pca* h);
+int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi);
+int pyvb_pca_update_Mu(pyvb_pca* h);
+int pyvb_pca_update_Beta(pyvb_pca* h);
+/* sum of log_lower_bound() per node class: parts[5] = W columns, Z_n, X_n, Mu, Beta (NULL: leave on the device) */
+int pyvb_pca_elbo(pyvb_pca* h, double parts[5]);
+/* niters passes of Network.learn's loop body (network.py:46-49) in the crawl order of fetch_network:
+ * W columns, Z_0.., X_0, Mu, X_1.., Beta, lower bound */
+int pyvb_pca_iterate(pyvb_pca* h, int niters);
+int pyvb_pca_sync(pyvb_pca* h);
+int pyvb_pca_comm_init(pyvb_pca* h, const char id[128], int rank, int world);
+
 #ifdef __cplusplus
 }
 #endif

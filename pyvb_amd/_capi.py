@@ -53,6 +53,21 @@ SIGNATURES = {
     "pyvb_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "pyvb_lds_comm_init": (ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "pyvb_lds_comm_destroy": (ctypes.c_int, [_h]),
+    "pyvb_pca_create": (ctypes.c_int, [ctypes.POINTER(_h), ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_long]),
+    "pyvb_pca_destroy": (ctypes.c_int, [_h]),
+    "pyvb_pca_set_priors": (ctypes.c_int, [_h, _dp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double]),
+    "pyvb_pca_set_data": (ctypes.c_int, [_h, _dp]),
+    "pyvb_pca_set_state": (ctypes.c_int, [_h] + [_dp] * 6),
+    "pyvb_pca_get_state": (ctypes.c_int, [_h] + [_dp] * 9),
+    "pyvb_pca_update_W": (ctypes.c_int, [_h]),
+    "pyvb_pca_update_Z": (ctypes.c_int, [_h]),
+    "pyvb_pca_update_X": (ctypes.c_int, [_h, ctypes.c_long, ctypes.c_long]),
+    "pyvb_pca_update_Mu": (ctypes.c_int, [_h]),
+    "pyvb_pca_update_Beta": (ctypes.c_int, [_h]),
+    "pyvb_pca_elbo": (ctypes.c_int, [_h, _dp]),
+    "pyvb_pca_iterate": (ctypes.c_int, [_h, ctypes.c_int]),
+    "pyvb_pca_sync": (ctypes.c_int, [_h]),
+    "pyvb_pca_comm_init": (ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
 }
 
 

@@ -537,6 +537,26 @@ int pyvb_comm_unique_id(char id[128]) {
     return PYVB_OK;
 }
 
+}  // extern "C"
+
+// shared with the PCA path (api_pca.hip)
+int pyvb_comm_create(void** comm, const char id[128], int rank, int world) {
+    ARGCHK(comm && id && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+    int rc = load_rccl();
+    if (rc) return rc;
+    nccl_uid u;
+    memcpy(u.internal, id, 128);
+    NCCLCHK(g_nccl.initrank(comm, world, u, rank));
+    return PYVB_OK;
+}
+void pyvb_comm_free(void* comm) { if (comm && g_nccl.destroy) g_nccl.destroy(comm); }
+int pyvb_allreduce_f64(void* comm, double* buf, size_t count, hipStream_t stream) {
+    NCCLCHK(g_nccl.allreduce(buf, buf, count, 8, 0, comm, stream));     // ncclDouble = 8, ncclSum = 0
+    return PYVB_OK;
+}
+
+extern "C" {
+
 int pyvb_lds_comm_init(pyvb_lds* h, const char id[128], int rank, int world) {
     ENTER(h);
     ARGCHK(id && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");

@@ -1,0 +1,327 @@
+// Host side of the VB-PCA path: handle, copies, dependency tracking, the all-reduce of the statistics.
+#include "pca.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define ARGCHK(cond, msg) do { if (!(cond)) { pyvb_set_error("%s", msg); return PYVB_E_ARG; } } while (0)
+#define ENTER(h) do { ARGCHK(h, "handle is NULL"); HIPCHK(hipSetDevice((h)->device)); } while (0)
+
+int pyvb_allreduce_f64(void* comm, double* buf, size_t count, hipStream_t stream);   // api.hip (RCCL)
+int pyvb_comm_create(void** comm, const char id[128], int rank, int world);
+void pyvb_comm_free(void* comm);
+
+static int alloc_d(double** p, size_t n) {
+    HIPCHK(hipMalloc((void**)p, n * sizeof(double)));
+    HIPCHK(hipMemset(*p, 0, n * sizeof(double)));
+    return PYVB_OK;
+}
+
+extern "C" {
+
+int pyvb_pca_destroy(pyvb_pca* h) {
+    if (!h) return PYVB_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) pyvb_comm_free(h->comm);
+    void* bufs[] = {h->X, h->M, h->xvar, h->nmiss, h->Z, h->W_mean, h->W_var, h->Mu_mean, h->Mu_var, h->Z_cov, h->qld_W, h->W_pm, h->W_pp,
+                    h->Mu_pm, h->Mu_pp, h->scal, h->Gz, h->g0, h->part, h->stats, h->aux, h->elbo, h->status};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PYVB_OK;
+}
+
+int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_total, long row_offset) {
+    ARGCHK(out, "out is NULL");
+    ARGCHK(N >= 1 && N_total >= N && row_offset >= 0, "bad row counts");
+    ARGCHK(d >= 1 && d <= 256, "observed dimension d must be in 1..256");
+    ARGCHK(q >= 1 && q <= 32, "latent dimension q must be in 1..32");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    ARGCHK(device >= 0 && device < ndev, "no such device");
+    HIPCHK(hipSetDevice(device));
+    pyvb_pca* h = new pyvb_pca();
+    memset(h, 0, sizeof(*h));
+    h->device = device; h->N = N; h->N_total = N_total; h->row_offset = row_offset; h->d = d; h->q = q;
+    h->DP = (d + 15) & ~15; h->QP = (q + 15) & ~15; h->DT = h->DP / 16; h->QT = h->QP / 16;
+    h->SL = pca_stats_layout(h->DP, h->QP);
+    h->world = 1;
+    long nchunk = (2048 + h->DT - 1) / h->DT;
+    const long ntile = (N + 15) / 16;
+    if (nchunk > ntile) nchunk = ntile;
+    if (nchunk < 1) nchunk = 1;
+    long rows = (N + nchunk - 1) / nchunk;
+    rows = (rows + 15) & ~15L;
+    nchunk = (N + rows - 1) / rows;
+    h->nchunk = (int)nchunk; h->chunk_rows = rows;
+    int rc = PYVB_OK;
+#define TRY(x) do { rc = (x); if (rc != PYVB_OK) { pyvb_pca_destroy(h); return rc; } } while (0)
+#define TRYHIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { rc = pyvb_hip_fail(_e, #x, __FILE__, __LINE__); pyvb_pca_destroy(h); return rc; } } while (0)
+    TRYHIP(hipStreamCreate(&h->stream));
+    const size_t n = (size_t)N, DP = h->DP, QP = h->QP;
+    TRY(alloc_d(&h->X, n * DP));
+    TRYHIP(hipMalloc((void**)&h->M, n * DP)); TRYHIP(hipMemset(h->M, 1, n * DP));
+    TRY(alloc_d(&h->xvar, n));
+    TRYHIP(hipMalloc((void**)&h->nmiss, n * sizeof(int))); TRYHIP(hipMemset(h->nmiss, 0, n * sizeof(int)));
+    TRY(alloc_d(&h->Z, n * QP));
+    TRY(alloc_d(&h->W_mean, (size_t)d * q)); TRY(alloc_d(&h->W_var, (size_t)q * d));
+    TRY(alloc_d(&h->Mu_mean, d)); TRY(alloc_d(&h->Mu_var, d)); TRY(alloc_d(&h->Z_cov, (size_t)q * q)); TRY(alloc_d(&h->qld_W, q));
+    TRY(alloc_d(&h->W_pm, (size_t)d * q)); TRY(alloc_d(&h->W_pp, (size_t)q * d)); TRY(alloc_d(&h->Mu_pm, d)); TRY(alloc_d(&h->Mu_pp, d));
+    TRY(alloc_d(&h->scal, PS_COUNT));
+    TRY(alloc_d(&h->Gz, (size_t)h->QT * (DP / 4) * 64)); TRY(alloc_d(&h->g0, QP));
+    TRY(alloc_d(&h->part, (size_t)h->nchunk * (h->SL.total + h->DT)));
+    TRY(alloc_d(&h->stats, h->SL.total));
+    TRY(alloc_d(&h->aux, (size_t)h->nchunk * QP + QP + DP));
+    TRY(alloc_d(&h->elbo, 8));
+    TRYHIP(hipMalloc((void**)&h->status, sizeof(int))); TRYHIP(hipMemset(h->status, 0, sizeof(int)));
+#undef TRY
+#undef TRYHIP
+    *out = h;
+    return PYVB_OK;
+}
+
+static int up(pyvb_pca* h, double* dst, const double* src, size_t n) {
+    if (!src) return PYVB_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return PYVB_OK;
+}
+static int down(pyvb_pca* h, double* dst, const double* src, size_t n) {
+    if (!dst) return PYVB_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return PYVB_OK;
+}
+
+int pyvb_pca_set_priors(pyvb_pca* h, const double* W_pm, const double* W_pp, const double* Mu_pm, const double* Mu_pp,
+                        double beta_a0, double beta_b0) {
+    ENTER(h);
+    ARGCHK(W_pm && W_pp && Mu_pm && Mu_pp, "all prior arrays are required");
+    int rc;
+    if ((rc = up(h, h->W_pm, W_pm, (size_t)h->d * h->q))) return rc;
+    if ((rc = up(h, h->W_pp, W_pp, (size_t)h->q * h->d))) return rc;
+    if ((rc = up(h, h->Mu_pm, Mu_pm, h->d))) return rc;
+    if ((rc = up(h, h->Mu_pp, Mu_pp, h->d))) return rc;
+    double sc[PS_COUNT];
+    HIPCHK(hipMemcpy(sc, h->scal, sizeof(sc), hipMemcpyDeviceToHost));
+    sc[PS_BETA_A0] = beta_a0; sc[PS_BETA_B0] = beta_b0;
+    sc[PS_BETA_A] = beta_a0 + 0.5 * (double)h->d * (double)h->N_total;      // Gamma.update_a, nodes_todo.py:125-128
+    sc[PS_QLD_Z] = sc[PS_QLD_X] = sc[PS_QLD_MU] = NAN;
+    HIPCHK(hipMemcpy(h->scal, sc, sizeof(sc), hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PYVB_OK;
+}
+
+// rows [N][d] on the host -> padded device rows [N][DP]
+static int upload_rows(pyvb_pca* h, double* dst, const double* src, int cols, int CP) {
+    std::vector<double> buf((size_t)h->N * CP, 0.0);
+    for (long n = 0; n < h->N; ++n) memcpy(&buf[(size_t)n * CP], src + (size_t)n * cols, cols * sizeof(double));
+    HIPCHK(hipMemcpy(dst, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    return PYVB_OK;
+}
+static int download_rows(pyvb_pca* h, double* dst, const double* src, int cols, int CP) {
+    std::vector<double> buf((size_t)h->N * CP);
+    HIPCHK(hipMemcpy(buf.data(), src, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (long n = 0; n < h->N; ++n) memcpy(dst + (size_t)n * cols, &buf[(size_t)n * CP], cols * sizeof(double));
+    return PYVB_OK;
+}
+
+int pyvb_pca_set_data(pyvb_pca* h, const double* X) {
+    ENTER(h);
+    ARGCHK(X, "X is NULL");
+    const long N = h->N; const int d = h->d, DP = h->DP;
+    std::vector<double> xb((size_t)N * DP, 0.0);
+    std::vector<unsigned char> mb((size_t)N * DP, 1);
+    std::vector<int> nm(N, 0);
+    double counts[3] = {0, 0, 0};          // missing entries in partially observed rows, rows without observations, partial rows
+    for (long n = 0; n < N; ++n) {
+        int miss = 0;
+        for (int k = 0; k < d; ++k) {
+            const double v = X[(size_t)n * d + k];
+            if (v != v) { mb[(size_t)n * DP + k] = 0; ++miss; } else xb[(size_t)n * DP + k] = v;
+        }
+        nm[n] = miss;
+        if (miss == d) counts[1] += 1; else if (miss > 0) { counts[0] += miss; counts[2] += 1; }
+    }
+    HIPCHK(hipMemcpy(h->X, xb.data(), xb.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->M, mb.data(), mb.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->nmiss, nm.data(), nm.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (h->comm) {       // global counts
+        HIPCHK(hipMemcpy(h->elbo, counts, sizeof(counts), hipMemcpyHostToDevice));
+        int rc = pyvb_allreduce_f64(h->comm, h->elbo, 3, h->stream);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(counts, h->elbo, sizeof(counts), hipMemcpyDeviceToHost));
+    }
+    h->n_part_missing = (long)counts[0]; h->n_none_rows = (long)counts[1]; h->n_part_rows = (long)counts[2];
+    h->full_valid = h->lin_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_pca_set_state(pyvb_pca* h, const double* X_missing, const double* W_mean, const double* Z, const double* Z_cov,
+                       const double* Mu_mean, const double* beta_b) {
+    ENTER(h);
+    const long N = h->N; const int d = h->d, q = h->q, DP = h->DP;
+    int rc;
+    if (X_missing) {        // posterior means of the missing entries; observed positions of the argument are ignored
+        std::vector<double> xb((size_t)N * DP);
+        std::vector<unsigned char> mb((size_t)N * DP);
+        HIPCHK(hipMemcpy(xb.data(), h->X, xb.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(mb.data(), h->M, mb.size(), hipMemcpyDeviceToHost));
+        for (long n = 0; n < N; ++n)
+            for (int k = 0; k < d; ++k)
+                if (!mb[(size_t)n * DP + k]) xb[(size_t)n * DP + k] = X_missing[(size_t)n * d + k];
+        HIPCHK(hipMemcpy(h->X, xb.data(), xb.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if ((rc = up(h, h->W_mean, W_mean, (size_t)d * q))) return rc;
+    if (Z && (rc = upload_rows(h, h->Z, Z, q, h->QP))) return rc;
+    if ((rc = up(h, h->Z_cov, Z_cov, (size_t)q * q))) return rc;
+    if ((rc = up(h, h->Mu_mean, Mu_mean, d))) return rc;
+    if (beta_b) HIPCHK(hipMemcpyAsync(h->scal + PS_BETA_B, beta_b, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->full_valid = h->lin_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_pca_sync(pyvb_pca* h) {
+    ENTER(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int st = 0;
+    HIPCHK(hipMemcpy(&st, h->status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        pyvb_set_error("a posterior precision was not positive definite (numpy.linalg.LinAlgError in the reference)");
+        HIPCHK(hipMemset(h->status, 0, sizeof(int)));
+        return PYVB_E_LINALG;
+    }
+    return PYVB_OK;
+}
+
+int pyvb_pca_get_state(pyvb_pca* h, double* X, double* X_rowvar, double* W_mean, double* W_var, double* Z, double* Z_cov,
+                       double* Mu_mean, double* Mu_var, double* beta_ab) {
+    ENTER(h);
+    const int d = h->d, q = h->q;
+    int rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (X && (rc = download_rows(h, X, h->X, d, h->DP))) return rc;
+    if (Z && (rc = download_rows(h, Z, h->Z, q, h->QP))) return rc;
+    if ((rc = down(h, X_rowvar, h->xvar, h->N))) return rc;
+    if ((rc = down(h, W_mean, h->W_mean, (size_t)d * q))) return rc;
+    if ((rc = down(h, W_var, h->W_var, (size_t)q * d))) return rc;
+    if ((rc = down(h, Z_cov, h->Z_cov, (size_t)q * q))) return rc;
+    if ((rc = down(h, Mu_mean, h->Mu_mean, d))) return rc;
+    if ((rc = down(h, Mu_var, h->Mu_var, d))) return rc;
+    if ((rc = down(h, beta_ab, h->scal + PS_BETA_A, 2))) return rc;
+    return pyvb_pca_sync(h);
+}
+
+// ---- dependency tracking: "full" = every sum current, "lin" = at least sum x and sum z ----
+static int full_stats(pyvb_pca* h, long lo_upd, long hi_upd) {
+    int rc;
+    if ((rc = pca_launch_pass2(h, lo_upd, hi_upd))) return rc;
+    if ((rc = pca_launch_reduce(h, 0))) return rc;
+    if (h->comm && (rc = pyvb_allreduce_f64(h->comm, h->stats, h->SL.total, h->stream))) return rc;
+    h->full_valid = h->lin_valid = true;
+    return PYVB_OK;
+}
+static int ensure_full(pyvb_pca* h) { return h->full_valid ? PYVB_OK : full_stats(h, 0, 0); }
+
+int pyvb_pca_update_W(pyvb_pca* h) {
+    ENTER(h);
+    int rc = ensure_full(h);
+    if (rc) return rc;
+    return pca_launch_small(h, PCA_W);
+}
+
+// exchange [new sum z | delta of sum x] and fold it into the statistics
+static int exchange_lin(pyvb_pca* h) {
+    int rc;
+    double* v = h->aux + (size_t)h->nchunk * h->QP;
+    if (h->comm && (rc = pyvb_allreduce_f64(h->comm, v, (size_t)h->QP + h->DP, h->stream))) return rc;
+    return pca_launch_small(h, PCA_APPLY);
+}
+
+int pyvb_pca_update_Z(pyvb_pca* h) {
+    ENTER(h);
+    int rc;
+    const bool had_lin = h->lin_valid;
+    if ((rc = pca_launch_small(h, PCA_PREPZ))) return rc;
+    if ((rc = pca_launch_pass1(h))) return rc;
+    if ((rc = pca_launch_reduce(h, 1))) return rc;
+    HIPCHK(hipMemsetAsync(h->aux + (size_t)h->nchunk * h->QP + h->QP, 0, h->DP * sizeof(double), h->stream));
+    if ((rc = exchange_lin(h))) return rc;
+    h->full_valid = false; h->lin_valid = had_lin;
+    return PYVB_OK;
+}
+
+int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi) {
+    ENTER(h);
+    ARGCHK(lo >= 0 && lo <= hi && hi <= h->N, "bad row range");
+    if (lo == hi) return PYVB_OK;
+    int rc;
+    if (lo == 0 && hi == 1) {        // Xs[0] alone: keep sum x current without a pass over all rows
+        if (!h->lin_valid && (rc = ensure_full(h))) return rc;
+        HIPCHK(hipMemcpyAsync(h->aux + (size_t)h->nchunk * h->QP, h->stats + h->SL.osz, h->QP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (h->comm && h->rank != 0)    // the sum of z travels once: every rank but 0 contributes zero to it
+            HIPCHK(hipMemsetAsync(h->aux + (size_t)h->nchunk * h->QP, 0, h->QP * sizeof(double), h->stream));
+        if ((rc = pca_launch_small(h, PCA_X0))) return rc;
+        if ((rc = exchange_lin(h))) return rc;
+        h->full_valid = false;
+        return PYVB_OK;
+    }
+    return full_stats(h, lo, hi);
+}
+
+int pyvb_pca_update_Mu(pyvb_pca* h) {
+    ENTER(h);
+    int rc;
+    if (!h->lin_valid && (rc = ensure_full(h))) return rc;
+    return pca_launch_small(h, PCA_MU);
+}
+
+int pyvb_pca_update_Beta(pyvb_pca* h) {
+    ENTER(h);
+    int rc = ensure_full(h);
+    if (rc) return rc;
+    return pca_launch_small(h, PCA_BETA);
+}
+
+int pyvb_pca_elbo(pyvb_pca* h, double parts[5]) {
+    ENTER(h);
+    int rc = ensure_full(h);
+    if (rc) return rc;
+    if ((rc = pca_launch_small(h, PCA_ELBO))) return rc;
+    if (parts) {
+        HIPCHK(hipMemcpyAsync(parts, h->elbo, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        return pyvb_pca_sync(h);
+    }
+    return PYVB_OK;
+}
+
+// niters passes of Network.learn's body over the fetched PCA network: crawl order W, Z, X_0, Mu, X_1.., Beta, bound
+int pyvb_pca_iterate(pyvb_pca* h, int niters) {
+    ENTER(h);
+    ARGCHK(niters >= 0, "niters must be >= 0");
+    int rc;
+    for (int it = 0; it < niters; ++it) {
+        if ((rc = pyvb_pca_update_W(h))) return rc;
+        if ((rc = pyvb_pca_update_Z(h))) return rc;
+        const long first = h->row_offset == 0 ? 1 : 0;         // global row 0 lives on the rank with offset 0
+        if ((rc = pyvb_pca_update_X(h, 0, 1))) return rc;       // (a no-op for the data on other ranks, but the exchange is collective)
+        if ((rc = pyvb_pca_update_Mu(h))) return rc;
+        if ((rc = pyvb_pca_update_X(h, first, h->N))) return rc;
+        if ((rc = pyvb_pca_update_Beta(h))) return rc;
+        if ((rc = pyvb_pca_elbo(h, nullptr))) return rc;
+    }
+    return PYVB_OK;
+}
+
+int pyvb_pca_comm_init(pyvb_pca* h, const char id[128], int rank, int world) {
+    ENTER(h);
+    int rc = pyvb_comm_create(&h->comm, id, rank, world);
+    if (rc) return rc;
+    h->rank = rank; h->world = world;
+    return PYVB_OK;
+}
+
+}  // extern "C"

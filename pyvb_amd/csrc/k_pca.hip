@@ -1,0 +1,488 @@
+// VB-PCA with missing data (examples/PCA_missing_data.py:31-45), N data rows on one GPU.
+//
+// The reference updates 2N+q+2 node objects one by one.  Here the N rows are processed in 16-row
+// tiles on the matrix cores (v_mfma_f64_16x16x4_f64), in two passes per iteration:
+//   pass 1  [z.update() for z in Zs]     Z = X Gz^T - g0,  Gz = beta Sigma_z <W>^T     (gaussian.py:102-123,
+//           node.py:203-227 for the message of Mult(W, z_n); all Z_n share Sigma_z)
+//   pass 2  [x.update() for x in Xs]     missing entries <- <W><z_n> + <Mu>, variance 1/beta, known entries
+//           pinned (gaussian.py:125-134 on a diagonal covariance), and, on the same tiles, the sums over n that
+//           the W, Mu and Beta updates and the lower bound read: sum x z^T, sum z z^T, sum x, sum z, sum |x|^2.
+// A wavefront of pass 2 owns one 16-column tile of X: the imputed tile comes out of the MFMA in accumulator
+// layout (row = 4*reg + lane/16, col = lane%16), which is exactly the A-operand layout of X^T for the product
+// X^T Z, so the statistics take it straight from registers.
+// Small single-workgroup kernels do the q x q / d-vector work (W columns, Sigma_z, Mu, Beta, lower bound).
+#include "pca.h"
+#include <cstdlib>
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define LN2PI 1.8378770664093453
+
+struct PcaArgs {
+    double* X; const unsigned char* M; double* xvar; const int* nmiss; double* Z;
+    double *W_mean, *W_var, *Mu_mean, *Mu_var, *Z_cov, *qld_W;
+    const double *W_pm, *W_pp, *Mu_pm, *Mu_pp;
+    double* scal; double* Gz; double* g0;
+    double* part; double* stats; double* aux; double* elbo; int* status;
+    long N, N_total, chunk_rows, lo_upd, hi_upd, n_part_missing, n_none_rows, row_offset;
+    int d, q, DP, QP, DT, QT, nchunk, mode;
+    PcaStatsLayout SL;
+};
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// position of Gz[i][k] in the B-operand block of pass 1: k-step s = 4*(k/16) + k%4, lane group (k%16)/4,
+// column tile t = i/16 -- a lane then reads 4 consecutive doubles of a row of X for 4 consecutive k-steps
+__device__ __forceinline__ size_t gz_pos(int i, int k, int DS) {
+    const int s = 4 * (k >> 4) + (k & 3), qk = (k & 15) >> 2;
+    return ((size_t)((i >> 4) * DS + s) * 64) + qk * 16 + (i & 15);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pass 1: Z <- X Gz^T - g0 for a chunk of rows; partial column sums of the new Z
+// ---------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ void __launch_bounds__(64) k_pca_pass1(PcaArgs a) {
+    extern __shared__ double gl[];                       // Gz^T as B operands [QT][DS][64]
+    const int lane = threadIdx.x, c = lane & 15, qk = lane >> 4;
+    const int DP = a.DP, QP = a.QP, DS = DP / 4;
+    for (int i = lane; i < QT * DS * 64; i += 64) gl[i] = a.Gz[i];
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * a.chunk_rows;
+    const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
+    double g0c[QT], szc[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { g0c[t] = a.g0[16 * t + c]; szc[t] = 0.0; }
+    for (long n0 = r0; n0 < r1; n0 += 16) {
+        const long rowA = (n0 + c < a.N) ? n0 + c : a.N - 1;              // A operand: row = lane % 16
+        const double* xr = a.X + rowA * DP + 4 * qk;
+        d4 acc[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) acc[t] = d4{-g0c[t], -g0c[t], -g0c[t], -g0c[t]};
+        for (int j = 0; j < DP / 16; ++j) {
+            const d4 x4 = *reinterpret_cast<const d4*>(xr + 16 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) acc[t] = MFMA(x4[e], gl[(size_t)(t * DS + 4 * j + e) * 64 + lane], acc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = n0 + 4 * r + qk;                         // accumulator: row = 4*reg + lane/16
+                if (row < r1) { a.Z[row * QP + 16 * t + c] = acc[t][r]; szc[t] += acc[t][r]; }
+            }
+    }
+    // column sums over the 4 lane groups -> part1[chunk][QP]
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        double s = szc[t];
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        if (qk == 0) a.aux[(size_t)blockIdx.x * QP + 16 * t + c] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pass 2: impute + statistics.  grid (nchunk, DT); the wavefront owns columns [16m, 16m+16) of X.
+// ---------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ void __launch_bounds__(64) k_pca_pass2(PcaArgs a) {
+    const int lane = threadIdx.x, c = lane & 15, qk = lane >> 4, m = blockIdx.y;
+    const int DP = a.DP, QP = a.QP, d = a.d, q = a.q;
+    constexpr int QS = 4 * QT;
+    const long r0 = (long)blockIdx.x * a.chunk_rows;
+    const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
+    const int dim = 16 * m + c;
+    // B operand of the prediction  pred[n][dim] = sum_i Z[n][i] W[dim][i]:  B[k = i][col = dim]
+    double wb[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) { const int i = 4 * s + qk; wb[s] = (dim < d && i < q) ? a.W_mean[(size_t)dim * q + i] : 0.0; }
+    const double mu = dim < d ? a.Mu_mean[dim] : 0.0;
+    const double var_new = a.scal[PS_BETA_B] / a.scal[PS_BETA_A];          // 1 / <beta>
+    if (blockIdx.x == 0 && m == 0 && lane == 0 && a.hi_upd > a.lo_upd)       // q_ln_det of rows without any observation
+        a.scal[PS_QLD_X] = 0.5 / (0.5 * d * log(1.0 / var_new));
+    d4 sxz[QT], szz[QT][QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        sxz[t] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < QT; ++u) szz[t][u] = d4{0, 0, 0, 0};
+    }
+    double sx = 0.0, sxx = 0.0, sz[QT], sxv = 0.0, slv = 0.0;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) sz[t] = 0.0;
+    for (long n0 = r0; n0 < r1; n0 += 16) {
+        // Z tile, A layout (row = lane%16, k = i) for the prediction ...
+        const long rowA = (n0 + c < a.N) ? n0 + c : a.N - 1;
+        double za[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) za[s] = a.Z[rowA * QP + 4 * s + qk];
+        // ... and B layout (k = row, col = i) for the statistics; rows past the chunk contribute nothing
+        double zb[4][QT];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long row = n0 + 4 * s + qk;
+            const bool ok = row < r1;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) { const double v = a.Z[(ok ? row : a.N - 1) * QP + 16 * t + c]; zb[s][t] = ok ? v : 0.0; }
+        }
+        d4 pred = d4{mu, mu, mu, mu};
+#pragma unroll
+        for (int s = 0; s < QS; ++s) pred = MFMA(za[s], wb[s], pred);
+        // accumulator element r: row n0 + 4r + qk, column dim
+        double xn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = n0 + 4 * r + qk;
+            const bool ok = row < r1;
+            const size_t off = (size_t)(ok ? row : a.N - 1) * DP + dim;
+            const double xo = a.X[off];
+            const bool known = a.M[off] != 0;
+            const bool upd = ok && !known && row >= a.lo_upd && row < a.hi_upd;
+            const double v = upd ? pred[r] : xo;
+            if (upd) a.X[off] = v;
+            xn[r] = ok ? v : 0.0;
+            sx += xn[r]; sxx += xn[r] * xn[r];
+        }
+        if (m == 0 && c == 0) {          // one lane per row: variance of the row's missing entries
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = n0 + 4 * r + qk;
+                if (row < r1) {
+                    const int nm = a.nmiss[row];
+                    double v = a.xvar[row];
+                    if (nm > 0 && row >= a.lo_upd && row < a.hi_upd) { v = var_new; a.xvar[row] = v; }
+                    sxv += nm * v;
+                    if (nm > 0 && nm < d) slv += nm * log(v);
+                }
+            }
+        }
+        // statistics: the imputed tile is X^T's A operand (row = dim = lane%16, k = row index = lane/16)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) sxz[t] = MFMA(xn[s], zb[s][t], sxz[t]);
+        if (m == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    sz[t] += zb[s][t];
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) szz[t][u] = MFMA(zb[s][t], zb[s][u], szz[t][u]);
+                }
+        }
+    }
+    // partial sums of this (chunk, column tile)
+    double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[a.SL.oSxz + (size_t)(16 * m + 4 * r + qk) * QP + 16 * t + c] = sxz[t][r];
+    sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
+    if (qk == 0) P[a.SL.osx + dim] = sx;
+    sxx = wsum(sxx);
+    if (lane == 0) P[a.SL.total + m] = sxx;
+    if (m == 0) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            double s = sz[t];
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            if (qk == 0) P[a.SL.osz + 16 * t + c] = s;
+#pragma unroll
+            for (int u = 0; u < QT; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[a.SL.oSzz + (size_t)(16 * t + 4 * r + qk) * QP + 16 * u + c] = szz[t][u][r];
+        }
+        sxv = wsum(sxv); slv = wsum(slv);
+        if (lane == 0) { P[a.SL.osxv] = sxv; P[a.SL.oslv] = slv; }
+    }
+}
+
+// sum the per-chunk partials: what = 0: full statistics of pass 2 -> stats;  what = 1: [sz (QP)] of pass 1 -> aux2
+__global__ void __launch_bounds__(256) k_pca_reduce(PcaArgs a, int what) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (what == 1) {
+        if (idx >= (size_t)a.QP) return;
+        double s = 0.0;
+        for (int ch = 0; ch < a.nchunk; ++ch) s += a.aux[(size_t)ch * a.QP + idx];
+        a.aux[(size_t)a.nchunk * a.QP + idx] = s;     // aux tail = [sz | delta sx]
+        return;
+    }
+    if (idx >= a.SL.total) return;
+    const size_t stride = a.SL.total + a.DT;
+    double s = 0.0;
+    if (idx == a.SL.osxx) {
+        for (int ch = 0; ch < a.nchunk; ++ch)
+            for (int m = 0; m < a.DT; ++m) s += a.part[(size_t)ch * stride + a.SL.total + m];
+    } else {
+        for (int ch = 0; ch < a.nchunk; ++ch) s += a.part[(size_t)ch * stride + idx];
+    }
+    a.stats[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small single-workgroup kernels (256 threads)
+// ---------------------------------------------------------------------------------------------------
+__device__ static double bsum(double v, double* red) {      // block-wide sum, 256 threads
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double s = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return s;
+}
+
+__device__ static double digamma_pos(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    const double ser = f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))));
+    return r + log(x) - 0.5 / x - ser;
+}
+
+// <W^T W>[i][j] for independent Gaussian columns (node.py:213-227 with an isotropic child precision) -> wtw [q][q] in LDS
+__device__ static void wtw_lds(const PcaArgs& a, double* wtw) {
+    const int d = a.d, q = a.q;
+    for (int idx = threadIdx.x; idx < q * q; idx += 256) {
+        const int i = idx / q, j = idx % q;
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s += a.W_mean[(size_t)k * q + i] * a.W_mean[(size_t)k * q + j];
+        if (i == j) for (int k = 0; k < d; ++k) s += a.W_var[(size_t)i * d + k];
+        wtw[idx] = s;
+    }
+    __syncthreads();
+}
+
+// residual  sum_n tr[<x x^T> + <m m^T> - 2 <x><m>^T],  m = W z_n + Mu   (node.py:121-129, :260-271); all threads get it
+__device__ static double residual(const PcaArgs& a, const double* wtw, double* red) {
+    const int d = a.d, q = a.q, QP = a.QP;
+    const double* S = a.stats;
+    const double N = (double)a.N_total;
+    double wz = 0.0;         // sum_ij <w_i^T w_j> Szz_ij, Szz = sum z z^T + N Sigma_z
+    for (int idx = threadIdx.x; idx < q * q; idx += 256) {
+        const int i = idx / q, j = idx % q;
+        wz += wtw[idx] * (S[a.SL.oSzz + (size_t)i * QP + j] + N * a.Z_cov[idx]);
+    }
+    double mm = 0.0, cross = 0.0;
+    for (int k = threadIdx.x; k < d; k += 256) {
+        const double mu = a.Mu_mean[k];
+        double wsz = 0.0, xzw = 0.0;
+        for (int i = 0; i < q; ++i) { const double w = a.W_mean[(size_t)k * q + i]; wsz += w * S[a.SL.osz + i]; xzw += w * S[a.SL.oSxz + (size_t)k * QP + i]; }
+        mm += N * (mu * mu + a.Mu_var[k]) + 2.0 * wsz * mu;
+        cross += xzw + S[a.SL.osx + k] * mu;
+    }
+    const double tot = bsum(wz + mm - 2.0 * cross, red);
+    return S[a.SL.osxx] + S[a.SL.osxv] + tot;
+}
+
+__global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
+    __shared__ double sm[64 * 64 + 64 * 64 + 64], red[4];
+    const int tid = threadIdx.x, d = a.d, q = a.q, QP = a.QP, DP = a.DP;
+    const double* S = a.stats;
+    const double beta = a.scal[PS_BETA_A] / a.scal[PS_BETA_B];
+    const double N = (double)a.N_total;
+    if (a.mode == PCA_W) {
+        // [w.update() for w in Ws]: rows of W decouple (isotropic beta, diagonal priors); thread = row k
+        // message chain hstack -> Mult(W, z_n) -> Addition(., Mu) -> X_n: (beta I, beta (x_n - <Mu>))
+        double* szz = sm;                                   // Szz = sum z z^T + N Sigma_z  [q][q]
+        for (int idx = tid; idx < q * q; idx += 256) szz[idx] = S[a.SL.oSzz + (size_t)(idx / q) * QP + idx % q] + N * a.Z_cov[idx];
+        __syncthreads();
+        const int k = tid;
+        double w[64];
+        if (k < d) for (int i = 0; i < q; ++i) w[i] = a.W_mean[(size_t)k * q + i];
+        for (int i = 0; i < q; ++i) {
+            double lp = 0.0;
+            if (k < d) {
+                const double pp = a.W_pp[(size_t)i * d + k];
+                const double prec = pp + beta * szz[i * q + i];
+                double acc = 0.0;
+                for (int j = 0; j < q; ++j) acc += (j == i) ? 0.0 : szz[i * q + j] * w[j];
+                const double h = S[a.SL.oSxz + (size_t)k * QP + i] - a.Mu_mean[k] * S[a.SL.osz + i];
+                w[i] = (pp * a.W_pm[(size_t)k * q + i] + beta * (h - acc)) / prec;
+                a.W_var[(size_t)i * d + k] = 1.0 / prec;
+                lp = 0.5 * log(prec);
+            }
+            lp = bsum(lp, red);
+            if (tid == 0) a.qld_W[i] = 0.5 / lp;             // gaussian.py:120 (quirk Q1)
+        }
+        if (k < d) for (int i = 0; i < q; ++i) a.W_mean[(size_t)k * q + i] = w[i];
+    } else if (a.mode == PCA_PREPZ) {
+        // posterior of the Z_n: precision I + beta <W^T W>, shared by all n; Gz = beta Sigma_z <W>^T
+        double* P = sm; double* Sg = sm + 64 * 64;
+        wtw_lds(a, Sg);
+        for (int idx = tid; idx < q * q; idx += 256) P[idx] = ((idx / q == idx % q) ? 1.0 : 0.0) + beta * Sg[idx];
+        __syncthreads();
+        // Gauss-Jordan inverse in place (SPD, no pivoting); log det from the pivots
+        double logdet = 0.0;
+        for (int p = 0; p < q; ++p) {
+            const double piv = P[p * q + p];
+            if (tid == 0 && !(piv > 0.0)) atomicOr(a.status, 1);
+            logdet += log(piv);
+            const double dinv = 1.0 / piv;
+            __syncthreads();
+            double nv[16];
+            int cnt = 0;
+            for (int idx = tid; idx < q * q; idx += 256, ++cnt) {
+                const int i = idx / q, j = idx % q;
+                const double cij = P[i * q + p], rpj = P[p * q + j];
+                nv[cnt] = (i == p) ? ((j == p) ? dinv : rpj * dinv) : ((j == p) ? -cij * dinv : P[idx] - cij * rpj * dinv);
+            }
+            __syncthreads();
+            cnt = 0;
+            for (int idx = tid; idx < q * q; idx += 256, ++cnt) P[idx] = nv[cnt];
+            __syncthreads();
+        }
+        for (int idx = tid; idx < q * q; idx += 256) a.Z_cov[idx] = P[idx];
+        if (tid == 0) a.scal[PS_QLD_Z] = 0.5 / (0.5 * logdet);
+        // Gz[i][k] = beta sum_j Sigma_z[i][j] W[k][j], stored as pass 1's B operands; g0 = Gz <Mu>
+        const int DS = DP / 4;
+        for (int idx = tid; idx < a.QT * DS * 64; idx += 256) a.Gz[idx] = 0.0;
+        __syncthreads();
+        for (int idx = tid; idx < q * d; idx += 256) {
+            const int i = idx / d, k = idx % d;
+            double s = 0.0;
+            for (int j = 0; j < q; ++j) s += P[i * q + j] * a.W_mean[(size_t)k * q + j];
+            a.Gz[gz_pos(i, k, DS)] = beta * s;
+        }
+        if (tid < q) {                                      // t_j = sum_k W[k][j] <Mu>_k
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += a.W_mean[(size_t)k * q + tid] * a.Mu_mean[k];
+            Sg[tid] = s;
+        }
+        __syncthreads();
+        if (tid < QP) {
+            double s = 0.0;
+            if (tid < q) for (int j = 0; j < q; ++j) s += P[tid * q + j] * Sg[j];
+            a.g0[tid] = beta * s;
+        }
+    } else if (a.mode == PCA_X0) {
+        // Xs[0].update() alone (the crawl order puts it before Mu): aux = [sz (QP) | delta of sum x (DP)]
+        double* dsx = a.aux + QP;
+        if (tid < DP) dsx[tid] = 0.0;
+        __syncthreads();
+        if (a.row_offset == 0 && a.nmiss[0] > 0) {
+            if (tid < d && a.M[tid] == 0) {
+                double pred = a.Mu_mean[tid];
+                for (int i = 0; i < q; ++i) pred += a.W_mean[(size_t)tid * q + i] * a.Z[i];
+                dsx[tid] = pred - a.X[tid];
+                a.X[tid] = pred;
+            }
+            if (tid == 0) { a.xvar[0] = 1.0 / beta; a.scal[PS_QLD_X] = 0.5 / (0.5 * d * log(beta)); }
+        }
+    } else if (a.mode == PCA_APPLY) {
+        // after the all-reduce of aux: the new sum of z replaces the old one, the sum of x moves by the delta
+        if (tid < QP) a.stats[a.SL.osz + tid] = a.aux[tid];
+        if (tid < DP) a.stats[a.SL.osx + tid] += a.aux[QP + tid];
+    } else if (a.mode == PCA_MU) {
+        // Mu.update(): N Addition children, each sends (beta I, beta (x_n - <W><z_n>))
+        double lp = 0.0;
+        if (tid < d) {
+            const int k = tid;
+            const double pp = a.Mu_pp[k], prec = pp + N * beta;
+            double wsz = 0.0;
+            for (int i = 0; i < q; ++i) wsz += a.W_mean[(size_t)k * q + i] * S[a.SL.osz + i];
+            a.Mu_mean[k] = (pp * a.Mu_pm[k] + beta * (S[a.SL.osx + k] - wsz)) / prec;
+            a.Mu_var[k] = 1.0 / prec;
+            lp = 0.5 * log(prec);
+        }
+        lp = bsum(lp, red);
+        if (tid == 0) a.scal[PS_QLD_MU] = 0.5 / lp;
+    } else if (a.mode == PCA_BETA) {
+        // Beta.update(): Gamma, traces (nodes_todo.py:130-138)
+        wtw_lds(a, sm);
+        const double res = residual(a, sm, red);
+        if (tid == 0) a.scal[PS_BETA_B] = a.scal[PS_BETA_B0] + 0.5 * res;
+    } else if (a.mode == PCA_ELBO) {
+        wtw_lds(a, sm);
+        const double res = residual(a, sm, red);
+        const double qa = a.scal[PS_BETA_A], qb = a.scal[PS_BETA_B];
+        const double lnd_beta = d * (log(qa) - log(qb));                  // Gamma.pass_down_lndet (quirk Q2)
+        // X_n (gaussian.py:136-151)
+        double LX = N * (-0.5 * d * LN2PI + 0.5 * lnd_beta) - 0.5 * beta * res;
+        LX -= 0.5 * (double)a.n_part_missing * LN2PI - 0.5 * S[a.SL.oslv] - 0.5 * (double)a.n_part_missing;
+        if (a.n_none_rows > 0) LX += (double)a.n_none_rows * (0.5 * d * LN2PI + 0.5 * a.scal[PS_QLD_X] + 0.5 * d);
+        // Z_n against Constant(0), Constant(I)
+        double tr = 0.0;
+        if (tid < q) tr = S[a.SL.oSzz + (size_t)tid * QP + tid] + N * a.Z_cov[tid * q + tid];
+        tr = bsum(tr, red);
+        const double LZ = N * (-0.5 * q * LN2PI) - 0.5 * tr + N * (0.5 * q * LN2PI + 0.5 * a.scal[PS_QLD_Z] + 0.5 * q);
+        // W columns and Mu against their Constant parents
+        double lw = 0.0;
+        if (tid < q) {
+            const int i = tid;
+            double lndet = 0.0, t2 = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double pp = a.W_pp[(size_t)i * d + k], w = a.W_mean[(size_t)k * q + i], pm = a.W_pm[(size_t)k * q + i];
+                lndet += log(pp);
+                t2 += pp * (w * w + a.W_var[(size_t)i * d + k] + pm * pm - 2.0 * w * pm);
+            }
+            lw = -0.5 * d * LN2PI + 0.5 * lndet - 0.5 * t2 + 0.5 * d * LN2PI + 0.5 * a.qld_W[i] + 0.5 * d;
+        }
+        const double LW = bsum(lw, red);
+        double lm = 0.0;
+        if (tid < d) {
+            const double pp = a.Mu_pp[tid], mu = a.Mu_mean[tid], pm = a.Mu_pm[tid];
+            lm = 0.5 * log(pp) - 0.5 * pp * (mu * mu + a.Mu_var[tid] + pm * pm - 2.0 * mu * pm);
+        }
+        const double LM = bsum(lm, red) - 0.5 * d * LN2PI + 0.5 * d * LN2PI + 0.5 * a.scal[PS_QLD_MU] + 0.5 * d;
+        if (tid == 0) {
+            const double a0 = a.scal[PS_BETA_A0], b0 = a.scal[PS_BETA_B0];
+            const double Elnx = digamma_pos(qa) - log(qb);
+            double LB = (a0 - 1.0) * Elnx - lgamma(a0) + a0 * log(b0) - b0 * beta;
+            LB -= (qa - 1.0) * Elnx - lgamma(qa) + qa * log(qb) - qb * beta;
+            a.elbo[0] = LW; a.elbo[1] = LZ; a.elbo[2] = LX; a.elbo[3] = LM; a.elbo[4] = LB;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+static PcaArgs pca_args(pyvb_pca* h) {
+    PcaArgs a;
+    a.X = h->X; a.M = h->M; a.xvar = h->xvar; a.nmiss = h->nmiss; a.Z = h->Z;
+    a.W_mean = h->W_mean; a.W_var = h->W_var; a.Mu_mean = h->Mu_mean; a.Mu_var = h->Mu_var; a.Z_cov = h->Z_cov; a.qld_W = h->qld_W;
+    a.W_pm = h->W_pm; a.W_pp = h->W_pp; a.Mu_pm = h->Mu_pm; a.Mu_pp = h->Mu_pp;
+    a.scal = h->scal; a.Gz = h->Gz; a.g0 = h->g0; a.part = h->part; a.stats = h->stats; a.aux = h->aux; a.elbo = h->elbo; a.status = h->status;
+    a.N = h->N; a.N_total = h->N_total; a.chunk_rows = h->chunk_rows; a.lo_upd = 0; a.hi_upd = 0;
+    a.n_part_missing = h->n_part_missing; a.n_none_rows = h->n_none_rows; a.row_offset = h->row_offset;
+    a.d = h->d; a.q = h->q; a.DP = h->DP; a.QP = h->QP; a.DT = h->DT; a.QT = h->QT; a.nchunk = h->nchunk; a.mode = 0; a.SL = h->SL;
+    return a;
+}
+
+int pca_launch_small(pyvb_pca* h, int mode) {
+    PcaArgs a = pca_args(h); a.mode = mode;
+    if (mode == PCA_X0 || mode == PCA_APPLY) a.aux = h->aux + (size_t)h->nchunk * h->QP;    // the [sz | delta sx] vector
+    hipLaunchKernelGGL(k_pca_small, dim3(1), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+int pca_launch_pass1(pyvb_pca* h) {
+    PcaArgs a = pca_args(h);
+    const size_t lds = (size_t)h->QT * (h->DP / 4) * 64 * sizeof(double);
+    if (h->QT == 1) hipLaunchKernelGGL(k_pca_pass1<1>, dim3(h->nchunk), dim3(64), lds, h->stream, a);
+    else hipLaunchKernelGGL(k_pca_pass1<2>, dim3(h->nchunk), dim3(64), lds, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
+    PcaArgs a = pca_args(h); a.lo_upd = lo_upd; a.hi_upd = hi_upd;
+    if (h->QT == 1) hipLaunchKernelGGL(k_pca_pass2<1>, dim3(h->nchunk, h->DT), dim3(64), 0, h->stream, a);
+    else hipLaunchKernelGGL(k_pca_pass2<2>, dim3(h->nchunk, h->DT), dim3(64), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+int pca_launch_reduce(pyvb_pca* h, int what) {
+    PcaArgs a = pca_args(h);
+    const size_t n = what == 1 ? (size_t)h->QP : h->SL.total;
+    hipLaunchKernelGGL(k_pca_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a, what);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}

@@ -1,0 +1,52 @@
+// Internal definitions of the VB-PCA-with-missing-data path (examples/PCA_missing_data.py of the reference).
+#pragma once
+#include "common.h"
+
+// Reduced statistics vector (doubles), all sums over the rows n of this rank (then over ranks):
+//   Szz [QP][QP]  sum z_n z_n^T (means only; the shared covariance is added by the consumers)
+//   Sxz [DP][QP]  sum x_n z_n^T           sx [DP]  sum x_n           sz [QP]  sum z_n
+//   sxx           sum ||x_n||^2           sxv      sum_n (#missing_n * var_n)
+//   slv           sum over partially observed rows of #missing_n * log(var_n)
+struct PcaStatsLayout {
+    int DP, QP;
+    size_t oSzz, oSxz, osx, osz, osxx, osxv, oslv, total;
+};
+static inline PcaStatsLayout pca_stats_layout(int DP, int QP) {
+    PcaStatsLayout L; L.DP = DP; L.QP = QP;
+    size_t o = 0;
+    L.oSzz = o; o += (size_t)QP * QP; L.oSxz = o; o += (size_t)DP * QP; L.osx = o; o += DP; L.osz = o; o += QP;
+    L.osxx = o++; L.osxv = o++; L.oslv = o++;
+    L.total = (o + 7) & ~(size_t)7;
+    return L;
+}
+
+// device scalars
+enum { PS_BETA_A = 0, PS_BETA_B, PS_QLD_Z, PS_QLD_X, PS_QLD_MU, PS_BETA_A0, PS_BETA_B0, PS_COUNT = 16 };
+
+struct pyvb_pca {
+    int device; long N, N_total, row_offset; int d, q, DP, QP, DT, QT;
+    hipStream_t stream;
+    double *X; unsigned char* M;         // [N][DP] posterior means of the X_n (data / imputed); 1 = observed
+    double *xvar;                        // [N] variance of the missing entries of row n
+    int *nmiss;                          // [N]
+    double *Z;                           // [N][QP]
+    double *W_mean, *W_var, *Mu_mean, *Mu_var, *Z_cov, *qld_W;   // [d][q], [q][d], [d], [d], [q][q], [q]
+    double *W_pm, *W_pp, *Mu_pm, *Mu_pp; // priors: [d][q], [q][d], [d], [d]
+    double *scal;                        // [PS_COUNT]
+    double *Gz, *g0;                     // Z-pass operands: Gz^T as MFMA B operands [QT][DP/4][64], g0 [QP]
+    double *part; int nchunk; long chunk_rows;   // [nchunk][DT+1][stats.total] partial statistics
+    double *stats;                       // [stats.total] reduced (global after the all-reduce)
+    double *aux;                         // [nchunk][QP] pass-1 partials, then [QP + DP]: new sum z | delta of sum x
+    double *elbo;                        // [5]
+    int *status;
+    PcaStatsLayout SL;
+    long n_part_missing, n_none_rows, n_part_rows;   // global counts (from the mask)
+    bool full_valid, lin_valid;          // all statistics current / at least sum x and sum z current
+    void* comm; int rank, world;
+};
+
+int pca_launch_small(pyvb_pca* h, int mode);
+int pca_launch_pass1(pyvb_pca* h);
+int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd);
+int pca_launch_reduce(pyvb_pca* h, int what);
+enum { PCA_W = 0, PCA_PREPZ = 1, PCA_MU = 2, PCA_BETA = 3, PCA_ELBO = 4, PCA_X0 = 5, PCA_APPLY = 6 };

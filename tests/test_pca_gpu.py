@@ -1,0 +1,101 @@
+"""GPU parity of the VB-PCA-with-missing-data path: against the fixtures produced by the reference
+(tests/golden/pca_*.npz) and against the oracle, stage by stage.  Tolerance 1e-8 relative."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pca_closed_form as P
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "pca_*.npz")))
+RTOL = 1e-8
+
+
+def _load(path):
+    from test_pca_oracle_golden import load_pca
+    return load_pca(path)
+
+
+def _close(a, b, what, rtol=RTOL):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert np.all(np.isfinite(a)), what + ": non-finite"
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    assert err <= rtol, "%s: rel err %.3e" % (what, err)
+
+
+def _compare(b, st, tag):
+    g = b.get_state()
+    for k in ("W_mean", "W_var", "Z", "Z_cov", "X", "Mu_mean", "Mu_var"):
+        _close(g[k], st[k], tag + k)
+    _close(g["beta_a"], st["beta_a"], tag + "beta_a")
+    _close(g["beta_b"], st["beta_b"], tag + "beta_b")
+    nm = (~st["obs"]).sum(1)
+    ref_var = np.where(nm > 0, st["X_var"].max(1), 0.0)
+    _close(g["X_rowvar"][nm > 0], ref_var[nm > 0], tag + "X_rowvar")
+
+
+@pytest.mark.parametrize("path", FILES, ids=lambda p: os.path.basename(p)[4:-4])
+def test_golden_fixtures(path):
+    from pyvb_amd.pca import PCABatch
+    N, d, q, init, pri, z = _load(path)
+    b = PCABatch.from_problem(init, pri)
+    for it in range(1, int(max(z["iters"])) + 1):
+        b.iterate(1)
+        if it in z["iters"]:
+            tag = "it%d_" % it
+            g = b.get_state()
+            for k in ("W_mean", "W_var", "Z", "Z_cov", "X", "Mu_mean", "Mu_var", "beta_a", "beta_b"):
+                _close(g[k], z[tag + k], tag + k)
+            parts = b.elbo()
+            ref = z[tag + "elbo_parts"]
+            assert np.all(np.abs(parts - ref) <= RTOL * np.abs(ref).sum()), (parts, ref)
+    b.close()
+
+
+@pytest.mark.parametrize("N,d,q", [(300, 20, 4), (1000, 64, 16), (77, 33, 17), (5000, 256, 16), (16, 3, 1), (17, 250, 31)])
+def test_stagewise_vs_oracle(N, d, q):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    from pyvb_amd.pca import PCABatch
+    init, pri = G.pca_problem(N, d, q, seed=1000 + N + d)
+    st = P.make_state(init, pri, N, d, q)
+    b = PCABatch.from_problem(init, pri)
+    for it in range(2):
+        tag = "it%d " % it
+        P.update_W(st, pri); b.update_W()
+        _close(b.get_state()["W_mean"], st["W_mean"], tag + "W after update_W")
+        P.update_Z(st, pri); b.update_Z()
+        _close(b.get_state()["Z"], st["Z"], tag + "Z after update_Z")
+        P.update_X(st, pri, 0, 1); b.update_X(0, 1)
+        P.update_Mu(st, pri); b.update_Mu()
+        _close(b.get_state()["Mu_mean"], st["Mu_mean"], tag + "Mu after update_Mu")
+        P.update_X(st, pri, 1, N); b.update_X(1, N)
+        _close(b.get_state()["X"], st["X"], tag + "X after imputation")
+        P.update_Beta(st, pri); b.update_Beta()
+        _compare(b, st, tag)
+        ref = P.elbo_parts(st, pri)
+        got = b.elbo()
+        assert np.all(np.abs(got - ref) <= RTOL * np.abs(ref).sum()), (got, ref)
+    b.close()
+
+
+def test_iterate_equals_individual_calls():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    from pyvb_amd.pca import PCABatch
+    N, d, q = 400, 24, 5
+    init, pri = G.pca_problem(N, d, q, seed=5)
+    a, b = PCABatch.from_problem(init, pri), PCABatch.from_problem(init, pri)
+    a.iterate(3)
+    for _ in range(3):
+        b.update_W(); b.update_Z(); b.update_X(0, 1); b.update_Mu(); b.update_X(1, N); b.update_Beta()
+    ga, gb = a.get_state(), b.get_state()
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+    assert np.array_equal(a.elbo(), b.elbo())
+    a.close(); b.close()
