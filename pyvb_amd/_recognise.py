@@ -51,6 +51,7 @@ class LDSPlan(object):
         self.pending = []
         self.cache = None
         self.x_updated = False
+        self.n_random_nodes = 2 * self.T + 2 * self.D + 2
         for n in Xs + Ys + As + Cs + [A, C, Q, R]:
             n._plan = self
 
@@ -286,5 +287,172 @@ def describe(start):
 
 
 def bind(node):
-    d = describe(node)
-    return LDSPlan(**d)
+    comp = _component(node)
+    if any(isinstance(n, N.Addition) for n in comp):
+        return PCAPlan(**describe_pca(node))
+    return LDSPlan(**describe(node))
+
+
+# -------------------------------------------------------------------------------------------------
+# VB-PCA with missing data: examples/PCA_missing_data.py:31-42
+# -------------------------------------------------------------------------------------------------
+def describe_pca(start):
+    """Recognise  X_n ~ N(W * Z_n + Mu, Beta)  with W = hstack of Gaussian columns, Mu Gaussian, Beta Gamma,
+    Z_n ~ N(0, I); returns the pieces, the priors and the observation mask (no GPU involved)."""
+    comp = _component(start)
+    stacks = [n for n in comp if isinstance(n, N.hstack)]
+    gammas = [n for n in comp if isinstance(n, (N.Gamma, N.DiagonalGamma, N.Wishart))]
+    adds = [n for n in comp if isinstance(n, N.Addition)]
+    if len(stacks) != 1 or len(gammas) != 1 or not isinstance(gammas[0], N.Gamma) or not adds:
+        _fail("expected one hstack matrix, one Gamma precision and Addition nodes (the PCA graph)")
+    W, Beta = stacks[0], gammas[0]
+    Ws = W.parents
+    d, q = W.shape
+    Mu, Zs, Xs = None, [], []
+    # the X_n in construction order = the order in which Beta adopted them as children
+    for x in Beta.children:
+        add = x.mean_parent
+        if not isinstance(x, N.Gaussian) or not isinstance(add, N.Addition) or x.precision_parent is not Beta:
+            _fail("a child of the precision node is not a Gaussian on an Addition")
+        mult, mu = add.A, add.B
+        if not isinstance(mult, N.Multiplication) or mult.A is not W or not isinstance(mult.B, N.Gaussian) or len(add.children) != 1:
+            _fail("the mean of an observation is not  W * z + Mu")
+        if Mu is None:
+            Mu = mu
+        if mu is not Mu or not isinstance(Mu, N.Gaussian):
+            _fail("observations use different offsets")
+        z = mult.B
+        if not isinstance(z.mean_parent, N.Constant) or not isinstance(z.precision_parent, N.Constant) \
+                or z.mean_parent.value.any() or not np.array_equal(z.precision_parent.value, np.eye(q)) or len(z.children) != 1:
+            _fail("latent variables must be N(0, I) with a single use")
+        if x.children:
+            _fail("observations must be leaves")
+        Zs.append(z)
+        Xs.append(x)
+    if len(W.children) != len(Xs) or len(Mu.children) != len(Xs):
+        _fail("W or Mu feed other nodes too")
+    for col in Ws + [Mu]:
+        if not isinstance(col.mean_parent, N.Constant) or col.observed or col.partially_observed:
+            _fail("matrix columns and the offset need Constant parents and no observations")
+        cov = col.__dict__["_h_qcov"]
+        if np.abs(cov - np.diag(np.diag(cov))).max() != 0.0:
+            _fail("initial covariances of the columns must be diagonal")
+    zc = Zs[0].__dict__["_h_qcov"]
+    if any(np.abs(z.__dict__["_h_qcov"] - zc).max() != 0.0 for z in Zs):
+        _fail("the device path keeps one covariance for all Z_n: give them equal initial covariances")
+    pri = {
+        "W_prior_mean": np.hstack([w.mean_parent.value for w in Ws]).astype(float),
+        "W_prior_prec": np.stack([_diag_constant(w.precision_parent, "a column's prior precision") for w in Ws]),
+        "Mu_prior_mean": Mu.mean_parent.value.reshape(-1).astype(float),
+        "Mu_prior_prec": _diag_constant(Mu.precision_parent, "the offset's prior precision"),
+        "beta_a0": float(Beta.a0), "beta_b0": float(Beta.b0),
+    }
+    N_ = len(Xs)
+    obs = np.ones((N_, d), dtype=bool)
+    X = np.empty((N_, d))
+    for n, x in enumerate(Xs):
+        X[n] = x.__dict__["_h_qmu"].reshape(-1)
+        if x.partially_observed:
+            obs[n] = ~np.isnan(x.obs_value.reshape(-1))
+            X[n] = np.where(obs[n], x.obs_value.reshape(-1), X[n])
+        elif not x.observed:
+            obs[n] = False
+    init = {"obs": obs, "X": X, "W_mean": np.hstack([w.__dict__["_h_qmu"] for w in Ws]),
+            "Z": np.hstack([z.__dict__["_h_qmu"] for z in Zs]).T.copy(), "Z_cov": zc.copy(),
+            "Mu_mean": Mu.__dict__["_h_qmu"].reshape(-1).copy(),
+            "beta_b": float(np.asarray(Beta.__dict__["_h_qb"], dtype=float).reshape(-1)[0])}
+    return dict(Ws=Ws, W=W, Mu=Mu, Beta=Beta, Zs=Zs, Xs=Xs, init=init, pri=pri)
+
+
+class PCAPlan(object):
+    def __init__(self, Ws, W, Mu, Beta, Zs, Xs, init, pri):
+        from .pca import PCABatch
+        self.Ws, self.W, self.Mu, self.Beta, self.Zs, self.Xs = Ws, W, Mu, Beta, Zs, Xs
+        self.N, self.d, self.q = len(Xs), W.shape[0], W.shape[1]
+        self.obs = init["obs"]
+        self.batch = PCABatch.from_problem(init, pri)
+        self.index = {}
+        for i, w in enumerate(Ws):
+            self.index[id(w)] = ("w", i)
+        for n, z in enumerate(Zs):
+            self.index[id(z)] = ("z", n)
+        for n, x in enumerate(Xs):
+            self.index[id(x)] = ("x", n)
+        self.index[id(Mu)] = ("mu", 0)
+        self.index[id(Beta)] = ("beta", 0)
+        self.pending, self.cache = [], None
+        self.n_random_nodes = 2 * self.N + self.q + 2
+        for n in Ws + Zs + Xs + [W, Mu, Beta]:
+            n._plan = self
+
+    def enqueue(self, node):
+        self.pending.append(self.index[id(node)])
+
+    def flush(self):
+        ops, self.pending = self.pending, []
+        if not ops:
+            return
+        self.cache = None
+        b, i = self.batch, 0
+        while i < len(ops):
+            kind, idx = ops[i]
+            j = i
+            while j + 1 < len(ops) and ops[j + 1] == (kind, ops[j][1] + 1):
+                j += 1
+            lo, hi = idx, ops[j][1] + 1
+            if kind == "w":
+                if (lo, hi) != (0, self.q):
+                    raise NotImplementedError("the columns of W update together on the device: call update() on all of them in order")
+                b.update_W()
+            elif kind == "z":
+                if (lo, hi) != (0, self.N):
+                    raise NotImplementedError("the Z_n update together on the device: call update() on all of them in order")
+                b.update_Z()
+            elif kind == "x":
+                b.update_X(lo, hi)
+            elif kind == "mu":
+                b.update_Mu()
+            elif kind == "beta":
+                b.update_Beta()
+            i = j + 1
+
+    def _pull(self):
+        self.flush()
+        if self.cache is None:
+            self.cache = self.batch.get_state()
+        return self.cache
+
+    def read(self, node, name):
+        kind, i = self.index[id(node)]
+        st = self._pull()
+        if kind == "w":
+            return st["W_mean"][:, [i]].copy() if name == "qmu" else (np.diag(st["W_var"][i]) if name == "qcov" else node.__dict__.get("_h_" + name))
+        if kind == "z":
+            return st["Z"][i].reshape(-1, 1).copy() if name == "qmu" else (st["Z_cov"].copy() if name == "qcov" else node.__dict__.get("_h_" + name))
+        if kind == "x":
+            if name == "qmu":
+                return st["X"][i].reshape(-1, 1).copy()
+            if name == "qcov":
+                return np.diag(np.where(self.obs[i], 0.0, st["X_rowvar"][i]))
+            return node.__dict__.get("_h_" + name)
+        if kind == "mu":
+            return st["Mu_mean"].reshape(-1, 1).copy() if name == "qmu" else (np.diag(st["Mu_var"]) if name == "qcov" else node.__dict__.get("_h_" + name))
+        if name == "qb":
+            return float(st["beta_b"])
+        raise AttributeError(name)
+
+    def write(self, node, name, value):
+        raise NotImplementedError("assigning posteriors after the PCA graph is bound is not supported; set them before the first update()")
+
+    def elbo_parts(self):
+        self.flush()
+        return self.batch.elbo()
+
+    def node_llb(self, node):
+        kind, _ = self.index[id(node)]
+        parts = self.elbo_parts()
+        if kind == "mu":
+            return float(parts[3])
+        if kind == "beta":
+            return float(parts[4])
+        raise NotImplementedError("per-node log_lower_bound() is summed per node class on the device: use Network.learn / plan.elbo_parts()")

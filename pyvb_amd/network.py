@@ -38,7 +38,7 @@ class Network(object):
         missing = [n for n in self.iterable_nodes if n._plan is not plan]
         if missing:
             raise NotImplementedError("the network spans nodes outside one recognised LDS graph; no HIP plan")
-        needed = 2 * plan.T + 2 * plan.D + 2
+        needed = plan.n_random_nodes
         if len(set(id(n) for n in self.iterable_nodes)) != needed:
             raise NotImplementedError("Network.learn needs every random-variable node of the graph (the lower bound is a "
                                       "sum over all of them): call fetch_network() first")

@@ -137,3 +137,24 @@ def test_recogniser_collects_known_matrix_entries():
     assert A_obs.shape == (3, 3) and C_obs.shape == (4, 3)
     assert A_obs[0, 0] == 1.0 and np.isnan(A_obs).sum() == 8
     assert np.array_equal(C_obs[:, 1], [0.1, 0.2, 0.3, 0.4]) and np.isnan(C_obs).sum() == 8
+
+
+def test_recogniser_extracts_the_pca_graph():
+    """examples/PCA_missing_data.py:31-42 built from pyvb_amd.nodes: data, mask, priors and crawl order."""
+    import pyvb_amd
+    G = _golden_module()
+    init, pri = G.pca_problem(12, 5, 2, seed=3)
+    g = G.pca_build_graph(pyvb_amd, init, pri)
+    d = _recognise.describe_pca(g["Mu"])
+    assert [a is b for a, b in zip(d["Xs"], g["Xs"])] == [True] * 12
+    assert [a is b for a, b in zip(d["Zs"], g["Zs"])] == [True] * 12
+    assert np.array_equal(d["init"]["obs"], init["obs"])
+    for k in ("X", "W_mean", "Z", "Z_cov", "Mu_mean"):
+        assert np.array_equal(d["init"][k], init[k]), k
+    assert d["init"]["beta_b"] == float(init["beta_b"])
+    for k in ("W_prior_mean", "W_prior_prec", "Mu_prior_mean", "Mu_prior_prec"):
+        assert np.array_equal(d["pri"][k], pri[k]), k
+    g["net"].find_iterable()
+    order = g["net"].iterable_nodes
+    assert order[:2] == g["Ws"] and order[2:14] == g["Zs"] and order[14] is g["Xs"][0] and order[15] is g["Mu"]
+    assert order[16:27] == g["Xs"][1:] and order[27] is g["Beta"]

@@ -119,3 +119,32 @@ def test_partial_order_and_attribute_writes():
     new = np.arange(D, dtype=float).reshape(D, 1)
     Xs[4].qmu = new
     assert np.array_equal(Xs[4].qmu, new)
+
+
+def test_pca_example_through_network_learn():
+    """examples/PCA_missing_data.py: net.addnode(W); net.fetch_network(); net.learn(n) on pyvb_amd, against the
+    reference's recorded outputs."""
+    import glob
+    import pyvb_amd
+    from test_pca_oracle_golden import load_pca
+    G = _golden_module()
+    for path in sorted(glob.glob(os.path.join(HERE, "golden", "pca_*.npz")))[:2]:
+        N, d, q, init, pri, z = load_pca(path)
+        g = G.pca_build_graph(pyvb_amd, init, pri)
+        net = g["net"]
+        done = 0
+        for it in [int(i) for i in z["iters"]]:
+            net.learn(it - done, tol=-np.inf, verbose=False)
+            done = it
+            tag = "it%d_" % it
+            assert _rel(np.hstack([w.qmu for w in g["Ws"]]), z[tag + "W_mean"]) <= RTOL
+            assert _rel(np.hstack([zz.qmu for zz in g["Zs"]]).T, z[tag + "Z"]) <= RTOL
+            assert _rel(np.hstack([x.qmu for x in g["Xs"]]).T, z[tag + "X"]) <= RTOL
+            assert _rel(g["Mu"].qmu.reshape(-1), z[tag + "Mu_mean"]) <= RTOL
+            assert _rel(g["Zs"][3].qcov, z[tag + "Z_cov"]) <= RTOL
+            assert _rel(np.stack([np.diag(x.qcov) for x in g["Xs"]]), z[tag + "X_var"]) <= RTOL
+            assert abs(g["Beta"].qb - float(z[tag + "beta_b"])) <= RTOL * abs(float(z[tag + "beta_b"]))
+            ref = z[tag + "elbo_parts"].sum()
+            assert abs(net.llb - ref) <= RTOL * abs(ref)
+            # the accessor the example prints (PCA_missing_data.py:92)
+            assert abs(g["Beta"].pass_down_Ex()[0, 0] - float(z[tag + "beta_a"]) / float(z[tag + "beta_b"])) <= 1e-8 * g["Beta"].pass_down_Ex()[0, 0]
