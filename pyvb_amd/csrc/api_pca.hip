@@ -49,7 +49,7 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     h->DP = (d + 15) & ~15; h->QP = (q + 15) & ~15; h->DT = h->DP / 16; h->QT = h->QP / 16;
     h->SL = pca_stats_layout(h->DP, h->QP);
     h->world = 1;
-    long nchunk = (2048 + h->DT - 1) / h->DT;
+    long nchunk = (16384 + h->DT - 1) / h->DT;      // pass 2 runs nchunk x DT wavefronts, pass 1 nchunk x 4
     const long ntile = (N + 15) / 16;
     if (nchunk > ntile) nchunk = ntile;
     if (nchunk < 1) nchunk = 1;
@@ -74,7 +74,7 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     TRY(alloc_d(&h->Gz, (size_t)h->QT * (DP / 4) * 64)); TRY(alloc_d(&h->g0, QP));
     TRY(alloc_d(&h->part, (size_t)h->nchunk * (h->SL.total + h->DT)));
     TRY(alloc_d(&h->stats, h->SL.total));
-    TRY(alloc_d(&h->aux, (size_t)h->nchunk * QP + QP + DP));
+    TRY(alloc_d(&h->aux, (size_t)4 * h->nchunk * QP + QP + DP));
     TRY(alloc_d(&h->elbo, 8));
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int))); TRYHIP(hipMemset(h->status, 0, sizeof(int)));
 #undef TRY
@@ -236,7 +236,7 @@ int pyvb_pca_update_W(pyvb_pca* h) {
 // exchange [new sum z | delta of sum x] and fold it into the statistics
 static int exchange_lin(pyvb_pca* h) {
     int rc;
-    double* v = h->aux + (size_t)h->nchunk * h->QP;
+    double* v = h->aux + (size_t)4 * h->nchunk * h->QP;
     if (h->comm && (rc = pyvb_allreduce_f64(h->comm, v, (size_t)h->QP + h->DP, h->stream))) return rc;
     return pca_launch_small(h, PCA_APPLY);
 }
@@ -248,7 +248,7 @@ int pyvb_pca_update_Z(pyvb_pca* h) {
     if ((rc = pca_launch_small(h, PCA_PREPZ))) return rc;
     if ((rc = pca_launch_pass1(h))) return rc;
     if ((rc = pca_launch_reduce(h, 1))) return rc;
-    HIPCHK(hipMemsetAsync(h->aux + (size_t)h->nchunk * h->QP + h->QP, 0, h->DP * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->aux + (size_t)4 * h->nchunk * h->QP + h->QP, 0, h->DP * sizeof(double), h->stream));
     if ((rc = exchange_lin(h))) return rc;
     h->full_valid = false; h->lin_valid = had_lin;
     return PYVB_OK;
@@ -261,9 +261,9 @@ int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi) {
     int rc;
     if (lo == 0 && hi == 1) {        // Xs[0] alone: keep sum x current without a pass over all rows
         if (!h->lin_valid && (rc = ensure_full(h))) return rc;
-        HIPCHK(hipMemcpyAsync(h->aux + (size_t)h->nchunk * h->QP, h->stats + h->SL.osz, h->QP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->aux + (size_t)4 * h->nchunk * h->QP, h->stats + h->SL.osz, h->QP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         if (h->comm && h->rank != 0)    // the sum of z travels once: every rank but 0 contributes zero to it
-            HIPCHK(hipMemsetAsync(h->aux + (size_t)h->nchunk * h->QP, 0, h->QP * sizeof(double), h->stream));
+            HIPCHK(hipMemsetAsync(h->aux + (size_t)4 * h->nchunk * h->QP, 0, h->QP * sizeof(double), h->stream));
         if ((rc = pca_launch_small(h, PCA_X0))) return rc;
         if ((rc = exchange_lin(h))) return rc;
         h->full_valid = false;

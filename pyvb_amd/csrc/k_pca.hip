@@ -45,14 +45,18 @@ __device__ __forceinline__ size_t gz_pos(int i, int k, int DS) {
 // pass 1: Z <- X Gz^T - g0 for a chunk of rows; partial column sums of the new Z
 // ---------------------------------------------------------------------------------------------------
 template <int QT>
-__global__ void __launch_bounds__(64) k_pca_pass1(PcaArgs a) {
-    extern __shared__ double gl[];                       // Gz^T as B operands [QT][DS][64]
-    const int lane = threadIdx.x, c = lane & 15, qk = lane >> 4;
+__global__ void __launch_bounds__(256) k_pca_pass1(PcaArgs a) {
+    extern __shared__ double gl[];                       // Gz^T as B operands [QT][DS][64], shared by the 4 wavefronts
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, qk = lane >> 4;
     const int DP = a.DP, QP = a.QP, DS = DP / 4;
-    for (int i = lane; i < QT * DS * 64; i += 64) gl[i] = a.Gz[i];
+    for (int i = threadIdx.x; i < QT * DS * 64; i += 256) gl[i] = a.Gz[i];
     __syncthreads();
-    const long r0 = (long)blockIdx.x * a.chunk_rows;
-    const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
+    // the chunk's rows are split over the 4 wavefronts in multiples of 16
+    const long c0 = (long)blockIdx.x * a.chunk_rows;
+    const long c1 = (c0 + a.chunk_rows < a.N) ? c0 + a.chunk_rows : a.N;
+    const long rpw = (((a.chunk_rows + 3) / 4) + 15) & ~15L;
+    const long r0 = c0 + wave * rpw;
+    const long r1 = (r0 + rpw < c1) ? r0 + rpw : c1;
     double g0c[QT], szc[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) { g0c[t] = a.g0[16 * t + c]; szc[t] = 0.0; }
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(64) k_pca_pass1(PcaArgs a) {
     for (int t = 0; t < QT; ++t) {
         double s = szc[t];
         s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-        if (qk == 0) a.aux[(size_t)blockIdx.x * QP + 16 * t + c] = s;
+        if (qk == 0) a.aux[((size_t)blockIdx.x * 4 + wave) * QP + 16 * t + c] = s;
     }
 }
 
@@ -209,8 +213,8 @@ __global__ void __launch_bounds__(256) k_pca_reduce(PcaArgs a, int what) {
     if (what == 1) {
         if (idx >= (size_t)a.QP) return;
         double s = 0.0;
-        for (int ch = 0; ch < a.nchunk; ++ch) s += a.aux[(size_t)ch * a.QP + idx];
-        a.aux[(size_t)a.nchunk * a.QP + idx] = s;     // aux tail = [sz | delta sx]
+        for (int ch = 0; ch < 4 * a.nchunk; ++ch) s += a.aux[(size_t)ch * a.QP + idx];
+        a.aux[(size_t)4 * a.nchunk * a.QP + idx] = s;     // aux tail = [sz | delta sx]
         return;
     }
     if (idx >= a.SL.total) return;
@@ -456,7 +460,7 @@ static PcaArgs pca_args(pyvb_pca* h) {
 
 int pca_launch_small(pyvb_pca* h, int mode) {
     PcaArgs a = pca_args(h); a.mode = mode;
-    if (mode == PCA_X0 || mode == PCA_APPLY) a.aux = h->aux + (size_t)h->nchunk * h->QP;    // the [sz | delta sx] vector
+    if (mode == PCA_X0 || mode == PCA_APPLY) a.aux = h->aux + (size_t)4 * h->nchunk * h->QP;    // the [sz | delta sx] vector
     hipLaunchKernelGGL(k_pca_small, dim3(1), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
@@ -465,8 +469,8 @@ int pca_launch_small(pyvb_pca* h, int mode) {
 int pca_launch_pass1(pyvb_pca* h) {
     PcaArgs a = pca_args(h);
     const size_t lds = (size_t)h->QT * (h->DP / 4) * 64 * sizeof(double);
-    if (h->QT == 1) hipLaunchKernelGGL(k_pca_pass1<1>, dim3(h->nchunk), dim3(64), lds, h->stream, a);
-    else hipLaunchKernelGGL(k_pca_pass1<2>, dim3(h->nchunk), dim3(64), lds, h->stream, a);
+    if (h->QT == 1) hipLaunchKernelGGL(k_pca_pass1<1>, dim3(h->nchunk), dim3(256), lds, h->stream, a);
+    else hipLaunchKernelGGL(k_pca_pass1<2>, dim3(h->nchunk), dim3(256), lds, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
