@@ -27,7 +27,7 @@ int pyvb_pca_destroy(pyvb_pca* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) pyvb_comm_free(h->comm);
     void* bufs[] = {h->X, h->M, h->xvar, h->nmiss, h->Z, h->W_mean, h->W_var, h->Mu_mean, h->Mu_var, h->Z_cov, h->qld_W, h->W_pm, h->W_pp,
-                    h->Mu_pm, h->Mu_pp, h->scal, h->Gz, h->g0, h->part, h->stats, h->aux, h->elbo, h->status};
+                    h->Mu_pm, h->Mu_pp, h->scal, h->Gz, h->g0, h->part, h->stats, h->aux, h->elbo, h->status, h->red2};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -74,6 +74,7 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     TRY(alloc_d(&h->Gz, (size_t)h->QT * (DP / 4) * 64)); TRY(alloc_d(&h->g0, QP));
     TRY(alloc_d(&h->part, (size_t)h->nchunk * (h->SL.total + h->DT)));
     TRY(alloc_d(&h->stats, h->SL.total));
+    TRY(alloc_d(&h->red2, (size_t)32 * h->SL.total));
     TRY(alloc_d(&h->aux, (size_t)4 * h->nchunk * QP + QP + DP));
     TRY(alloc_d(&h->elbo, 8));
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int))); TRYHIP(hipMemset(h->status, 0, sizeof(int)));

@@ -207,26 +207,37 @@ __global__ void __launch_bounds__(64) k_pca_pass2(PcaArgs a) {
     }
 }
 
-// sum the per-chunk partials: what = 0: full statistics of pass 2 -> stats;  what = 1: [sz (QP)] of pass 1 -> aux2
-__global__ void __launch_bounds__(256) k_pca_reduce(PcaArgs a, int what) {
+// sum the per-chunk partials in two deterministic stages (no atomics: results must not depend on timing)
+//   what = 0: full statistics of pass 2 -> stats;  what = 1: [sum z (QP)] of pass 1 -> tail of aux
+//   stage 0: slice y of the chunks -> red2[y][idx];  stage 1: the PCA_RED slices -> destination
+#define PCA_RED 32
+__global__ void __launch_bounds__(256) k_pca_reduce(PcaArgs a, int what, int stage, double* red2) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (what == 1) {
-        if (idx >= (size_t)a.QP) return;
+    const size_t n = what == 1 ? (size_t)a.QP : a.SL.total;
+    if (idx >= n) return;
+    if (stage == 1) {
         double s = 0.0;
-        for (int ch = 0; ch < 4 * a.nchunk; ++ch) s += a.aux[(size_t)ch * a.QP + idx];
-        a.aux[(size_t)4 * a.nchunk * a.QP + idx] = s;     // aux tail = [sz | delta sx]
+        for (int y = 0; y < PCA_RED; ++y) s += red2[(size_t)y * n + idx];
+        if (what == 1) a.aux[(size_t)4 * a.nchunk * a.QP + idx] = s; else a.stats[idx] = s;
         return;
     }
-    if (idx >= a.SL.total) return;
-    const size_t stride = a.SL.total + a.DT;
+    const int y = blockIdx.y;
+    const int nch = what == 1 ? 4 * a.nchunk : a.nchunk;
+    const int per = (nch + PCA_RED - 1) / PCA_RED;
+    const int c0 = y * per, c1 = (c0 + per < nch) ? c0 + per : nch;
     double s = 0.0;
-    if (idx == a.SL.osxx) {
-        for (int ch = 0; ch < a.nchunk; ++ch)
-            for (int m = 0; m < a.DT; ++m) s += a.part[(size_t)ch * stride + a.SL.total + m];
+    if (what == 1) {
+        for (int ch = c0; ch < c1; ++ch) s += a.aux[(size_t)ch * a.QP + idx];
     } else {
-        for (int ch = 0; ch < a.nchunk; ++ch) s += a.part[(size_t)ch * stride + idx];
+        const size_t stride = a.SL.total + a.DT;
+        if (idx == a.SL.osxx) {
+            for (int ch = c0; ch < c1; ++ch)
+                for (int m = 0; m < a.DT; ++m) s += a.part[(size_t)ch * stride + a.SL.total + m];
+        } else {
+            for (int ch = c0; ch < c1; ++ch) s += a.part[(size_t)ch * stride + idx];
+        }
     }
-    a.stats[idx] = s;
+    red2[(size_t)y * n + idx] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -486,7 +497,9 @@ int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
 int pca_launch_reduce(pyvb_pca* h, int what) {
     PcaArgs a = pca_args(h);
     const size_t n = what == 1 ? (size_t)h->QP : h->SL.total;
-    hipLaunchKernelGGL(k_pca_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a, what);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_pca_reduce, dim3(nb, PCA_RED), dim3(256), 0, h->stream, a, what, 0, h->red2);
+    hipLaunchKernelGGL(k_pca_reduce, dim3(nb), dim3(256), 0, h->stream, a, what, 1, h->red2);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

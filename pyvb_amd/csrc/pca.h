@@ -37,6 +37,7 @@ struct pyvb_pca {
     double *part; int nchunk; long chunk_rows;   // [nchunk][DT+1][stats.total] partial statistics
     double *stats;                       // [stats.total] reduced (global after the all-reduce)
     double *aux;                         // [nchunk][QP] pass-1 partials, then [QP + DP]: new sum z | delta of sum x
+    double *red2;                        // [32][stats.total] second-stage partials of the reductions
     double *elbo;                        // [5]
     int *status;
     PcaStatsLayout SL;

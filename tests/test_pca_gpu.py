@@ -99,3 +99,27 @@ def test_iterate_equals_individual_calls():
         assert np.array_equal(ga[k], gb[k]), k
     assert np.array_equal(a.elbo(), b.elbo())
     a.close(); b.close()
+
+
+def test_single_rank_communicator_is_transparent():
+    """With a one-rank RCCL communicator attached every statistics exchange goes through ncclAllReduce
+    (sum over one rank = identity): the results must not change."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    from pyvb_amd.pca import PCABatch
+    from pyvb_amd.lds import LDSBatch
+    N, d, q = 500, 40, 6
+    init, pri = G.pca_problem(N, d, q, seed=77)
+    a = PCABatch.from_problem(init, pri)
+    b = PCABatch(N, d, q)
+    b.comm_init(LDSBatch.comm_unique_id(), 0, 1)
+    b.set_priors(pri)
+    b.set_data(np.where(init["obs"], init["X"], np.nan))
+    b.set_state(X_missing=init["X"], W_mean=init["W_mean"], Z=init["Z"], Z_cov=init["Z_cov"], Mu_mean=init["Mu_mean"], beta_b=float(init["beta_b"]))
+    a.iterate(3); b.iterate(3)
+    ga, gb = a.get_state(), b.get_state()
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+    assert np.array_equal(a.elbo(), b.elbo())
+    a.close(); b.close()
