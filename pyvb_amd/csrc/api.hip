@@ -282,7 +282,7 @@ int pyvb_lds_set_state(pyvb_lds* h, const double* X, const double* A_mean, const
     if ((rc = h2d(h, h->Q_b, Q_b, N * D))) return rc;
     if ((rc = h2d(h, h->R_b, R_b, N * K))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (X) states_changed(h);
+    if (X) { states_changed(h); h->u_valid = false; }
     if (A_mean || A_colvar || C_mean || C_colvar || Q_b || R_b) { params_changed(h); h->resQ_valid = h->resR_valid = false; }
     return PYVB_OK;
 }
@@ -401,6 +401,7 @@ int pyvb_lds_update_x(pyvb_lds* h, int t) {
     int rc = ensure_gains(h);
     if (rc) return rc;
     if ((rc = launch_step(h, t))) return rc;
+    h->u_valid = false;
     if (!h->fresh[t]) {
         h->fresh[t] = 1;
         if (++h->fresh_count == h->T) { adopt_classes(h); h->mixed_cov = false; }

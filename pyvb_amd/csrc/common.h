@@ -85,7 +85,7 @@ struct pyvb_lds {
     double *scratch;                // [N][2][DP][DP] (M_C, M_A + M_C)
     int *warm;                      // [N][2]
     double *trash;                  // [N][128] dump rows for masked-out stores of the sweep
-    double *U; bool u_valid;        // [N][T][DP] G y_t written by the forward sweep for the backward one
+    double *U; bool u_valid;        // [N][T][DP] c_t = F mu_{t-1} + G y_t written by the forward sweep for the backward one that follows it
     double *stats; int nchunk, chunk_len;   // [N][nchunk][L.stats_total]
     double *mom;                    // [N][3 D^2 + K D + D] second moments (k_moments)
     double *resQ, *resR;            // [N][D], [N][K]

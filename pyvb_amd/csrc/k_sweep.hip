@@ -20,7 +20,7 @@
 struct SweepArgs {
     const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
     double* trash;      // [N][128]: where lanes of inactive columns aim their (unconditional) stores
-    double* U;          // [N][T][DP]: u_t = G y_t of the interior nodes, in accumulator order (see MODE)
+    double* U;          // [N][T][DP]: c_t = F mu_{t-1} + G y_t of the interior nodes, in accumulator order (see MODE)
     int N, T, D, K, dir;
     Layout L;
 };
@@ -28,11 +28,14 @@ struct SweepArgs {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 // FULL: D == 16*DT and K == 16*KT (no padded rows/columns, 16-byte aligned rows)
-// MODE: G y_t does not depend on the direction, and the parameters are frozen between the two
-// sweeps of an iteration.  MODE 1 (forward) stores u_t = G y_t after computing it, MODE 2 (the
-// backward sweep that follows) reads it back instead of y_t and skips a third of the MFMAs at the
-// price of one extra [N][T][D] write.  MODE 0 computes it and keeps nothing.  U rows are stored in
-// accumulator order, [tile m][lane group q][register r], so a lane moves 32 contiguous bytes per tile.
+// MODE: the parameters are frozen between the two sweeps of an iteration, and the backward update
+//   mu_t <- B mu_{t+1}(new) + F mu_{t-1}(forward result) + G y_t
+// contains c_t = F mu_{t-1} + G y_t, which the forward sweep has just formed on its way to mu_t
+// (its recurrent term plus its observation term).  MODE 1 (forward) stores c_t, MODE 2 (the
+// backward sweep that follows directly) reads it back instead of y_t and the forward state and
+// runs ONE product per step instead of three; MODE 0 computes everything and keeps nothing.
+// c rows are stored in accumulator order, [tile m][lane group q][register r], so a lane moves 32
+// contiguous bytes per tile.
 template <int DT, int KT, bool FULL, int MODE>
 __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     constexpr int DS = 4 * DT, KS = 4 * KT, DP = 16 * DT;
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
 #pragma unroll
             for (int s = 0; s < DS; ++s) {
                 rn[m][s] = Rn[(m * DS + s) * 64 + lane];
-                ip[m][s] = Ip[(m * DS + s) * 64 + lane];
+                ip[m][s] = (MODE == 2) ? 0.0 : Ip[(m * DS + s) * 64 + lane];
             }
         if constexpr (MODE != 2) {
             const double* Gp = g + L.oGp;
@@ -150,14 +153,14 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
         // loop head sees the same number of younger operations on both incoming edges and the wait
         // for the first loads does not also cover the stores behind them.
         if constexpr (MODE == 2) load_u(jstart); else load_y(jstart, yv);
-        if constexpr (MODE == 1) store_x(trash + 64);  // stands for the u_t store
         store_x(trash);
-        load_o(jstart, mo);
+        if constexpr (MODE == 1) store_x(trash + 64);  // stands for the c_t store
+        if constexpr (MODE != 2) load_o(jstart, mo);
         for (int j = jstart; j < Lseg; ++j) {
             d4 acc[DT];
             if constexpr (MODE == 2) {
 #pragma unroll
-                for (int m = 0; m < DT; ++m) acc[m] = uv[m];                 // G y_t from the forward sweep
+                for (int m = 0; m < DT; ++m) acc[m] = uv[m];                 // c_t from the forward sweep
                 __builtin_amdgcn_sched_barrier(0);
                 load_u(j + 1);
                 store_x(out_pending);
@@ -173,34 +176,38 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
                     for (int m = 0; m < DT; ++m) acc[m] = MFMA(gl[(m * KS + s) * 64 + goff], yv[s >> 1][s & 1], acc[m]);
-                // Next step's y goes into the registers just consumed; it has the I and R blocks
-                // (2/3 of a step) to arrive.  The stores of the PREVIOUS step's state (and of u_t)
-                // are issued right behind those loads: vector-memory operations retire in order, so
-                // a wait for the loads never includes the stores, and the stores get a whole step
-                // to drain before the next loads queue up behind them.
+                // Next step's y goes into the registers just consumed; it has the R and I blocks
+                // (2/3 of a step) to arrive.  The store of the PREVIOUS step's state is issued right
+                // behind those loads: vector-memory operations retire in order, so a wait for the
+                // loads never includes the stores, and the stores get a whole step to drain before
+                // the next loads queue up behind them.
                 __builtin_amdgcn_sched_barrier(0);
                 load_y(j + 1, yv);
-                if constexpr (MODE == 1) {
-                    double* ur = u_row(j);
-#pragma unroll
-                    for (int m = 0; m < DT; ++m) *reinterpret_cast<d4*>(ur + (m * 4 + q) * 4) = acc[m];
-                }
                 store_x(out_pending);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // I mu_{t+dir} (old)
-#pragma unroll
-            for (int s = 0; s < DS; ++s)
-#pragma unroll
-                for (int m = 0; m < DT; ++m) acc[m] = MFMA(ip[m][s], mo[s >> 2][s & 3], acc[m]);
-            __builtin_amdgcn_sched_barrier(0);
-            load_o(j + 1, mo);
-            __builtin_amdgcn_sched_barrier(0);
             // R mu_{t-dir} (new): the previous accumulators are the B operands
 #pragma unroll
             for (int s = 0; s < DS; ++s)
 #pragma unroll
                 for (int m = 0; m < DT; ++m) acc[m] = MFMA(rn[m][s], x[s >> 2][s & 3], acc[m]);
+            if constexpr (MODE != 2) {
+                if constexpr (MODE == 1) {      // c_t = G y_t + R mu_{t-1} for the backward sweep
+                    __builtin_amdgcn_sched_barrier(0);
+                    double* ur = u_row(j);
+#pragma unroll
+                    for (int m = 0; m < DT; ++m) *reinterpret_cast<d4*>(ur + (m * 4 + q) * 4) = acc[m];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // I mu_{t+dir} (old)
+#pragma unroll
+                for (int s = 0; s < DS; ++s)
+#pragma unroll
+                    for (int m = 0; m < DT; ++m) acc[m] = MFMA(ip[m][s], mo[s >> 2][s & 3], acc[m]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_o(j + 1, mo);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const bool act = active(j);
 #pragma unroll
             for (int m = 0; m < DT; ++m)
@@ -294,7 +301,8 @@ int launch_sweep(pyvb_lds* h, int direction) {
     }
     HIPCHK(hipGetLastError());
     h->cur = 1 - h->cur;
-    if (direction == PYVB_FORWARD) h->u_valid = true;      // U now holds G y_t for the current gains
+    // U holds c_t for the current gains and for THIS forward result; any other change of X drops it
+    h->u_valid = (direction == PYVB_FORWARD);
     return PYVB_OK;
 }
 
