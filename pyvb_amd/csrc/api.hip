@@ -100,7 +100,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRY(dev_alloc(&h->qld_x, n * 3)); TRY(dev_alloc(&h->qld_x_new, n * 3));
     TRY(dev_alloc(&h->gains, n * L.gains_total));
     TRY(dev_alloc(&h->scratch, n * 2 * D * D));
-    TRY(dev_alloc(&h->trash, n * 128));
+    TRY(dev_alloc(&h->trash, n * 256));
     TRY(dev_alloc(&h->U, n * T * L.DP));
     TRYHIP(hipMalloc((void**)&h->warm, n * 2 * sizeof(int)));
     TRYHIP(hipMemset(h->warm, 0, n * 2 * sizeof(int)));
@@ -384,15 +384,19 @@ static int ensure_resid(pyvb_lds* h, int which) {
     return PYVB_OK;
 }
 
-int pyvb_lds_sweep(pyvb_lds* h, int direction) {
-    ENTER(h);
-    ARGCHK(direction == PYVB_FORWARD || direction == PYVB_BACKWARD, "direction must be PYVB_FORWARD or PYVB_BACKWARD");
+static int sweep(pyvb_lds* h, int direction, bool keep_x) {
     int rc = ensure_gains(h);
     if (rc) return rc;
-    if ((rc = launch_sweep(h, direction))) return rc;
+    if ((rc = launch_sweep(h, direction, keep_x))) return rc;
     mark_all_fresh(h);
     states_changed(h);
     return PYVB_OK;
+}
+
+int pyvb_lds_sweep(pyvb_lds* h, int direction) {
+    ENTER(h);
+    ARGCHK(direction == PYVB_FORWARD || direction == PYVB_BACKWARD, "direction must be PYVB_FORWARD or PYVB_BACKWARD");
+    return sweep(h, direction, true);
 }
 
 int pyvb_lds_update_x(pyvb_lds* h, int t) {
@@ -464,8 +468,9 @@ int pyvb_lds_iterate(pyvb_lds* h, int niters) {
     ARGCHK(niters >= 0, "niters must be >= 0");
     int rc;
     for (int it = 0; it < niters; ++it) {
-        if ((rc = pyvb_lds_sweep(h, PYVB_FORWARD))) return rc;
-        if ((rc = pyvb_lds_sweep(h, PYVB_BACKWARD))) return rc;
+        // the backward sweep follows at once and reads c_t, not the forward states: those are not written out
+        if ((rc = sweep(h, PYVB_FORWARD, false))) return rc;
+        if ((rc = sweep(h, PYVB_BACKWARD, true))) return rc;
         // A and C are independent given the statistics, and so are Q and R given A and C: the pairs
         // share launches here (same arithmetic as update_A, update_C, update_Q, update_R in turn)
         if ((rc = ensure_stats(h))) return rc;

@@ -84,7 +84,7 @@ struct pyvb_lds {
     double *gains;                  // [N][L.gains_total]
     double *scratch;                // [N][2][DP][DP] (M_C, M_A + M_C)
     int *warm;                      // [N][2]
-    double *trash;                  // [N][128] dump rows for masked-out stores of the sweep
+    double *trash;                  // [N][256] dump rows for masked-out stores of the sweep
     double *U; bool u_valid;        // [N][T][DP] c_t = F mu_{t-1} + G y_t written by the forward sweep for the backward one that follows it
     double *stats; int nchunk, chunk_len;   // [N][nchunk][L.stats_total]
     double *mom;                    // [N][3 D^2 + K D + D] second moments (k_moments)
@@ -101,7 +101,7 @@ struct pyvb_lds {
 
 // ---- launchers implemented in the kernel translation units ----
 int launch_prep(pyvb_lds* h);
-int launch_sweep(pyvb_lds* h, int direction);
+int launch_sweep(pyvb_lds* h, int direction, bool keep_x = true);
 int launch_step(pyvb_lds* h, int t);
 int launch_syy(pyvb_lds* h);
 int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal);

@@ -19,9 +19,10 @@
 
 struct SweepArgs {
     const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
-    double* trash;      // [N][128]: where lanes of inactive columns aim their (unconditional) stores
+    double* trash;      // [N][256]: where lanes of inactive columns aim their (unconditional) stores
     double* U;          // [N][T][DP]: c_t = F mu_{t-1} + G y_t of the interior nodes, in accumulator order (see MODE)
     int N, T, D, K, dir;
+    int keep_x;         // 0: the sweep that follows reads only c_t and the rows next to the far boundary, so the interior rows of Xnew are not written
     Layout L;
 };
 
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
         // time index of this column at loop index j:  t = tbase + sgn * j
         const int tbase = fwd ? (1 + cL) : (T - 2 - cL);
         const int tsafe = fwd ? 1 : T - 2;      // an interior row that always exists: what inactive columns read
-        auto active = [&](int j) { int tt = cL + j; return j >= jc && tt < Tint; };
+        auto active = [&](int j) { int tt = cL + j; return j >= jc && j < Lseg && tt < Tint; };
         // input registers: y_t and the old neighbour mean, as B operands in permuted k order.
         // Loads are unconditional and unmasked: an inactive column reads a valid row and computes
         // a value that the select after the step discards (MFMA columns do not mix), and padded
@@ -137,35 +138,62 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
         // Stores are unconditional too (a branch around them would make the compiler's in-order
         // vmcnt bookkeeping conservative and stall on loads just issued): lanes with nothing to
         // store write to a per-replicate trash row.
-        double* const trash = a.trash + (size_t)n * 128;
+        double* const trash = a.trash + (size_t)n * 256;
         double* out_pending = trash;
         // u_t rows (MODE 1 writes, MODE 2 reads), in accumulator order
         double* const Un = a.U + (size_t)n * T * DP;
         auto u_row = [&](int j) { return (active(j) && j >= 0) ? Un + (size_t)(tbase + sgn * j) * DP : trash; };
-        d4 uv[DT];
-        auto load_u = [&](int j) {
+        auto load_u = [&](int j, d4* dst) {
             const double* p = Un + (size_t)(active(j) ? tbase + sgn * j : tsafe) * DP;
 #pragma unroll
-            for (int m = 0; m < DT; ++m) uv[m] = *reinterpret_cast<const d4*>(p + (m * 4 + q) * 4);
+            for (int m = 0; m < DT; ++m) dst[m] = *reinterpret_cast<const d4*>(p + (m * 4 + q) * 4);
         };
+        auto finish_step = [&](int j, const d4* acc) {
+            const bool act = active(j);
+#pragma unroll
+            for (int m = 0; m < DT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[m][r] = act ? acc[m][r] : x[m][r];
+            out_pending = (act && j >= 0 && (a.keep_x || cL + j == Tint - 1)) ? Xn + (size_t)(tbase + sgn * j) * DP : trash;
+        };
+        if constexpr (MODE == 2) {
+            // One product per step: the sweep is bound by the c_t stream, so c rows are fetched PF
+            // steps ahead into a ring of registers (the loop is unrolled PF times so that every
+            // load has a fixed destination).  The prologue issues the same load/store sequence as
+            // PF loop steps (see below).
+            constexpr int PF = 3;
+            d4 ub[PF][DT];
+#pragma unroll
+            for (int p = 0; p < PF; ++p) { load_u(jstart + p, ub[p]); store_x(trash + 64 * p); }
+            for (int j = jstart; j < Lseg; j += PF) {
+#pragma unroll
+                for (int p = 0; p < PF; ++p) {
+                    d4 acc[DT];
+#pragma unroll
+                    for (int m = 0; m < DT; ++m) acc[m] = ub[p][m];
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_u(j + p + PF, ub[p]);
+                    store_x(out_pending);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < DS; ++s)
+#pragma unroll
+                        for (int m = 0; m < DT; ++m) acc[m] = MFMA(rn[m][s], x[s >> 2][s & 3], acc[m]);
+                    finish_step(j + p, acc);
+                }
+            }
+        } else {
         // Prologue: the same sequence of vector-memory operations as one loop iteration (loads, stores
         // -- into the trash row -- , loads), so that the compiler's in-order vmcnt bookkeeping at the
         // loop head sees the same number of younger operations on both incoming edges and the wait
         // for the first loads does not also cover the stores behind them.
-        if constexpr (MODE == 2) load_u(jstart); else load_y(jstart, yv);
+        load_y(jstart, yv);
         store_x(trash);
         if constexpr (MODE == 1) store_x(trash + 64);  // stands for the c_t store
-        if constexpr (MODE != 2) load_o(jstart, mo);
+        load_o(jstart, mo);
         for (int j = jstart; j < Lseg; ++j) {
             d4 acc[DT];
-            if constexpr (MODE == 2) {
-#pragma unroll
-                for (int m = 0; m < DT; ++m) acc[m] = uv[m];                 // c_t from the forward sweep
-                __builtin_amdgcn_sched_barrier(0);
-                load_u(j + 1);
-                store_x(out_pending);
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
+            {
 #pragma unroll
                 for (int m = 0; m < DT; ++m) acc[m] = d4{0.0, 0.0, 0.0, 0.0};
                 // G y_t.  The LDS offset is made opaque per iteration: G is loop invariant and the
@@ -191,7 +219,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
             for (int s = 0; s < DS; ++s)
 #pragma unroll
                 for (int m = 0; m < DT; ++m) acc[m] = MFMA(rn[m][s], x[s >> 2][s & 3], acc[m]);
-            if constexpr (MODE != 2) {
+            {
                 if constexpr (MODE == 1) {      // c_t = G y_t + R mu_{t-1} for the backward sweep
                     __builtin_amdgcn_sched_barrier(0);
                     double* ur = u_row(j);
@@ -208,12 +236,8 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                 load_o(j + 1, mo);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const bool act = active(j);
-#pragma unroll
-            for (int m = 0; m < DT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[m][r] = act ? acc[m][r] : x[m][r];
-            out_pending = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * DP : trash;
+            finish_step(j, acc);
+        }
         }
         store_x(out_pending);
         // the column that holds the last interior node hands its state to the closing boundary step
@@ -279,8 +303,9 @@ static int launch_sweep_t(pyvb_lds* h, const SweepArgs& a) {
     return PYVB_OK;
 }
 
-int launch_sweep(pyvb_lds* h, int direction) {
+int launch_sweep(pyvb_lds* h, int direction, bool keep_x) {
     SweepArgs a;
+    a.keep_x = (keep_x || direction != PYVB_FORWARD) ? 1 : 0;
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
     a.trash = h->trash; a.U = h->U;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
