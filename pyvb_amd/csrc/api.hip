@@ -474,11 +474,9 @@ int pyvb_lds_iterate(pyvb_lds* h, int niters) {
         // A and C are independent given the statistics, and so are Q and R given A and C: the pairs
         // share launches here (same arithmetic as update_A, update_C, update_Q, update_R in turn)
         if ((rc = ensure_stats(h))) return rc;
-        if ((rc = launch_cols(h, 2, 0, h->D))) return rc;
+        if ((rc = launch_cols(h, 2, 0, h->D, 3))) return rc;       // columns, residuals and noise update in one launch
         params_changed(h);
-        if ((rc = launch_resid(h, 2))) return rc;
         h->resQ_valid = h->resR_valid = true;
-        if ((rc = launch_noise(h, 2))) return rc;
         if ((rc = pyvb_lds_elbo(h))) return rc;
     }
     return PYVB_OK;

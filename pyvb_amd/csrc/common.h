@@ -108,7 +108,7 @@ int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal)
 int launch_stats(pyvb_lds* h);
 int launch_moments(pyvb_lds* h);
 int launch_observe(pyvb_lds* h);
-int launch_cols(pyvb_lds* h, int which, int c0, int c1);      // which: 0 = A, 1 = C; columns [c0, c1)
+int launch_cols(pyvb_lds* h, int which, int c0, int c1, int fuse = 0);   // which: 0 = A, 1 = C, 2 = both; columns [c0, c1); fuse: see k_cols.hip
 int launch_resid(pyvb_lds* h, int which);     // 0 = Q, 1 = R
 int launch_noise(pyvb_lds* h, int which);
 int launch_elbo(pyvb_lds* h);

@@ -8,48 +8,7 @@
 // With diagonal noise precisions and diagonal column priors every row of A (of C) only
 // interacts with itself, so the Gauss-Seidel pass over the columns is sequential in the
 // column index but parallel over rows.
-#include "common.h"
-
-#define LN2PI 1.8378770664093453
-
-struct ParamArgs {
-    // statistics
-    const double* part; int nchunk; const double* Sigma; const double* qld_x; const double* X; const double* Syy;
-    double* mom;            // [N][mom_total]: see k_moments
-    // parameters
-    double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *qld_A, *qld_C;
-    double *resQ, *resR, *elbo;
-    Priors pri;
-    int N, T, D, K, noise;
-    int c0, c1;             // k_cols: columns [c0, c1) are updated
-    int which0;             // blockIdx.y + which0 selects the matrix / noise node (0: A, Q; 1: C, R)
-    Layout L;
-};
-
-// layout of the per-replicate moment block written by k_moments (all row-major, no padding)
-//   GA [D][D]  = sum_{t=0}^{T-2} <x x^T>      (children of hstack A: Mult(A, X_t))
-//   GC [D][D]  = sum_{t=0}^{T-1} <x x^T>      (children of hstack C)
-//   HA [D][D]  = sum_t mu_{t+1} mu_t^T        HC [K][D] = sum_t y_t mu_t^T
-//   dp [D]     = diag sum_{t=1}^{T-1} <x x^T> (children of Q)
-__host__ __device__ static inline size_t mom_total(int D, int K) { return (size_t)3 * D * D + (size_t)K * D + D; }
-#define MOM_GA(D, K) ((size_t)0)
-#define MOM_GC(D, K) ((size_t)(D) * (D))
-#define MOM_HA(D, K) ((size_t)2 * (D) * (D))
-#define MOM_HC(D, K) ((size_t)3 * (D) * (D))
-#define MOM_DP(D, K) ((size_t)3 * (D) * (D) + (size_t)(K) * (D))
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// value of v in lane j (j wave-uniform) for every lane: two v_readlane_b32, no LDS
-__device__ __forceinline__ double bcast(double v, int j) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
-    return __hiloint2double(hi, lo);
-}
+#include "params.h"
 
 // k_moments: reduce the chunk partials of k_stats and add the covariance classes
 // (<x x^T> = qmu qmu^T + qcov, gaussian.py:162-168), once per statistics pass, fully parallel.
@@ -81,128 +40,6 @@ __global__ void __launch_bounds__(256) k_moments(ParamArgs a) {
         for (int ch = 0; ch < a.nchunk; ++ch) h += P[(size_t)ch * a.L.stats_total + a.L.oSyx + (size_t)k * DP + j];
         mo[MOM_HC(D, K) + idx] = h;
     }
-}
-
-// [a.update() for a in As] (WHICH = 0) / [c.update() for c in Cs] (WHICH = 1).
-// Lane k owns row k of the matrix; its row lives in LDS (Mb[col][lane]) together with its row of
-// H.  Row i of G is fetched one column ahead with one coalesced load and broadcast by readlane.
-__global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
-    const int WHICH = a.which0 + blockIdx.y;
-    __shared__ double Mb[64 * 64];     // Mb[col * 64 + row]
-    const int n = blockIdx.x, lane = threadIdx.x, D = a.D, K = a.K;
-    const int rows = WHICH == 0 ? D : K;
-    double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
-    double* V = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
-    double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
-    const double* pm = WHICH == 0 ? a.pri.A_pm : a.pri.C_pm;    // [row][col]
-    const double* pp = WHICH == 0 ? a.pri.A_pp : a.pri.C_pp;    // [col][row]
-    const double* mo = a.mom + (size_t)n * mom_total(D, K);
-    const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
-    const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
-    const bool live = lane < rows;
-    const int lc = lane < D ? lane : D - 1;         // clamped column for the coalesced row loads
-    for (int k0 = 0; k0 < rows; k0 += 8) {          // transpose the rows of M into LDS, 8 rows of loads in flight
-        double m[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u < rows ? k0 + u : rows - 1;
-            m[u] = M[(size_t)k * D + lc];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (k0 + u < rows) Mb[lc * 64 + k0 + u] = m[u];
-    }
-    const double lam = live ? (WHICH == 0 ? a.Q_a[(size_t)n * D + lane] / a.Q_b[(size_t)n * D + lane]
-                                          : a.R_a[(size_t)n * K + lane] / a.R_b[(size_t)n * K + lane]) : 0.0;
-    const int lr = live ? lane : 0;                 // clamped row for the per-lane prior loads
-    double grow_n = G[(size_t)a.c0 * D + lc], p0_n = pp[(size_t)a.c0 * rows + lr], pm_n = pm[(size_t)lr * D + a.c0];
-    double h_n = H[(size_t)lr * D + a.c0];          // this lane's H[row][col], fetched one column ahead
-    const double* obs = WHICH == 0 ? a.pri.A_obs : a.pri.C_obs;     // [row][col], NaN = not observed
-    double obs_n = obs[(size_t)lr * D + a.c0];
-    __syncthreads();
-    for (int i = a.c0; i < a.c1; ++i) {
-        const double grow = grow_n, p0 = p0_n, m0 = pm_n, hki = h_n;
-        const int in = i + 1 < a.c1 ? i + 1 : i;
-        h_n = H[(size_t)lr * D + in];
-        grow_n = G[(size_t)in * D + lc];
-        p0_n = pp[(size_t)in * rows + lr];
-        pm_n = pm[(size_t)lr * D + in];
-        double acc = 0.0;
-#pragma unroll 8
-        for (int j = 0; j < D; ++j) acc += Mb[j * 64 + lane] * bcast(grow, j);
-        const double gii = bcast(grow, i);
-        acc -= Mb[i * 64 + lane] * gii;                                        // j != i only
-        const double prec = p0 + lam * gii;                                    // qprec  gaussian.py:117
-        const double num = p0 * m0 + lam * (hki - acc);
-        double val = num / prec, var = 1.0 / prec;                             // qmu, qcov  gaussian.py:119-123
-        // known entries (Gaussian.observe on a column, LDS_knowns_in_A.py:73-74): conditioning a diagonal
-        // Gaussian on them (gaussian.py:125-134) pins those entries and leaves the others alone; a column
-        // whose entries are all known is thereby never changed (gaussian.py:109-110)
-        const double ob = obs_n;
-        obs_n = obs[(size_t)lr * D + in];
-        const bool known = live && (ob == ob);
-        if (known) { val = ob; var = 0.0; }
-        double lp = 0.0;
-        if (live) {
-            Mb[i * 64 + lane] = val;
-            V[(size_t)i * rows + lane] = var;
-            lp = 0.5 * log(prec);                                              // log of the Cholesky diagonal
-        }
-        lp = wave_sum(lp);
-        const int nknown = (int)wave_sum(known ? 1.0 : 0.0);
-        if (lane == 0 && nknown < rows) qld[i] = 0.5 / lp;                     // gaussian.py:120 (quirk Q1)
-    }
-    __syncthreads();
-    if (lane < D)
-        for (int k = 0; k < rows; ++k) M[(size_t)k * D + lane] = Mb[lane * 64 + k];
-}
-
-// res[k] = 1/2 own[k] + 1/2 <mu mu^T>[k,k] - (H M^T)[k,k]  for the children of Q (WHICH = 0) / R (1)
-__global__ void __launch_bounds__(64) k_resid(ParamArgs a) {
-    const int WHICH = a.which0 + blockIdx.y;
-    __shared__ double Mb[64 * 64];
-    const int n = blockIdx.x, lane = threadIdx.x, D = a.D, K = a.K;
-    const int rows = WHICH == 0 ? D : K;
-    const double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
-    const double* V = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
-    const double* mo = a.mom + (size_t)n * mom_total(D, K);
-    const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
-    const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
-    const bool live = lane < rows;
-    const int lc = lane < D ? lane : D - 1, lr = live ? lane : 0;
-    double hm = 0.0;                                // (H M^T)[k,k] ends up in lane k
-    for (int k0 = 0; k0 < rows; k0 += 8) {
-        double m[8], hh[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u < rows ? k0 + u : rows - 1;
-            m[u] = M[(size_t)k * D + lc];
-            hh[u] = H[(size_t)k * D + lc];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u;
-            if (k < rows) Mb[lc * 64 + k] = m[u];
-            const double s = wave_sum(lane < D ? m[u] * hh[u] : 0.0);
-            hm = (lane == k) ? s : hm;
-        }
-    }
-    const double own = WHICH == 0 ? mo[MOM_DP(D, K) + lr] : a.Syy[(size_t)n * K + lr];
-    double grow_n = G[lc], v_n = V[lr];
-    __syncthreads();
-    // <mu mu^T>[k,k] = sum_ij M[k,i] G[i,j] M[k,j] + sum_i var_i[k] G[i,i]      node.py:260-271
-    double e = 0.0;
-    for (int i = 0; i < D; ++i) {
-        const double grow = grow_n, vi = v_n;
-        const int in = i + 1 < D ? i + 1 : i;
-        grow_n = G[(size_t)in * D + lc];
-        v_n = V[(size_t)in * rows + lr];
-        double t = 0.0;
-#pragma unroll 8
-        for (int j = 0; j < D; ++j) t += bcast(grow, j) * Mb[j * 64 + lane];
-        e += Mb[i * 64 + lane] * t + vi * bcast(grow, i);
-    }
-    if (live) (WHICH == 0 ? a.resQ : a.resR)[(size_t)n * rows + lane] = 0.5 * own + 0.5 * e - hm;
 }
 
 __global__ void __launch_bounds__(64) k_noise(ParamArgs a) {
@@ -342,13 +179,13 @@ __global__ void __launch_bounds__(64) k_observe(ParamArgs a) {
     }
 }
 
-static ParamArgs make_args(pyvb_lds* h) {
+ParamArgs make_args(pyvb_lds* h) {
     ParamArgs a;
     a.part = h->stats; a.nchunk = h->nchunk; a.mom = h->mom; a.Sigma = h->Sigma; a.qld_x = h->qld_x; a.X = h->X[h->cur]; a.Syy = h->Syy;
     a.A_mean = h->A_mean; a.A_var = h->A_var; a.C_mean = h->C_mean; a.C_var = h->C_var;
     a.Q_a = h->Q_a; a.Q_b = h->Q_b; a.R_a = h->R_a; a.R_b = h->R_b; a.qld_A = h->qld_A; a.qld_C = h->qld_C;
     a.resQ = h->resQ; a.resR = h->resR; a.elbo = h->elbo; a.pri = h->pri;
-    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L; a.c0 = 0; a.c1 = h->D; a.which0 = 0;
+    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L; a.c0 = 0; a.c1 = h->D; a.which0 = 0; a.fuse = 0;
     return a;
 }
 
@@ -368,24 +205,6 @@ int launch_moments(pyvb_lds* h) {
 }
 
 // which: 0 = A / Q, 1 = C / R, 2 = both in one launch (they are independent given the statistics)
-int launch_cols(pyvb_lds* h, int which, int c0, int c1) {
-    ParamArgs a = make_args(h);
-    a.c0 = c0; a.c1 = c1; a.which0 = which == 1 ? 1 : 0;
-    TimedLaunch tl(h, PYVB_K_PARAMS);
-    hipLaunchKernelGGL(k_cols, dim3(h->N, which == 2 ? 2 : 1), dim3(64), 0, h->stream, a);
-    HIPCHK(hipGetLastError());
-    return PYVB_OK;
-}
-
-int launch_resid(pyvb_lds* h, int which) {
-    ParamArgs a = make_args(h);
-    a.which0 = which == 1 ? 1 : 0;
-    TimedLaunch tl(h, PYVB_K_PARAMS);
-    hipLaunchKernelGGL(k_resid, dim3(h->N, which == 2 ? 2 : 1), dim3(64), 0, h->stream, a);
-    HIPCHK(hipGetLastError());
-    return PYVB_OK;
-}
-
 int launch_noise(pyvb_lds* h, int which) {
     ParamArgs a = make_args(h);
     a.which0 = which == 1 ? 1 : 0;
