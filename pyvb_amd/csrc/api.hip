@@ -120,7 +120,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int)));
     TRYHIP(hipMemset(h->status, 0, sizeof(int)));
     // priors block: x0_mean D, x0_prec D*D, A_pm D*D, A_pp D*D, C_pm K*D, C_pp D*K, Q_a0 D, Q_b0 D, R_a0 K, R_b0 K
-    size_t pn = (size_t)D + 3 * (size_t)D * D + 2 * (size_t)K * D + 2 * (size_t)D + 2 * (size_t)K + (size_t)D * D + (size_t)K * D;
+    size_t pn = (size_t)D + 3 * (size_t)D * D + 2 * (size_t)K * D + 2 * (size_t)D + 2 * (size_t)K + (size_t)D * D + (size_t)K * D + 2 * (size_t)D;
     TRY(dev_alloc(&h->pri_block, pn));
     double* p = h->pri_block;
     h->pri.x0_mean = p; p += D; h->pri.x0_prec = p; p += D * D;
@@ -128,6 +128,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     h->pri.C_pm = p; p += K * D; h->pri.C_pp = p; p += D * K;
     h->pri.Q_a0 = p; p += D; h->pri.Q_b0 = p; p += D; h->pri.R_a0 = p; p += K; h->pri.R_b0 = p; p += K;
     h->pri.A_obs = p; p += D * D; h->pri.C_obs = p; p += K * D;
+    h->pri.A_pld = p; p += D; h->pri.C_pld = p; p += D;
     TRYHIP(hipMemset(h->pri.A_obs, 0xFF, ((size_t)D * D + (size_t)K * D) * sizeof(double)));     // all-ones bytes = NaN = nothing observed
     h->fresh = (unsigned char*)calloc(T, 1);
     h->world = 1;
@@ -221,6 +222,15 @@ int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_pre
     if ((rc = h2d(h, h->pri.A_pp, A_pp, (size_t)D * D))) return rc;
     if ((rc = h2d(h, h->pri.C_pm, C_pm, (size_t)K * D))) return rc;
     if ((rc = h2d(h, h->pri.C_pp, C_pp, (size_t)D * K))) return rc;
+    {   // ln det of the diagonal prior precision of every column (Constant.lndet of the parents, node.py:301-302)
+        std::vector<double> ld(2 * (size_t)D, 0.0);
+        for (int i = 0; i < D; ++i) {
+            for (int k = 0; k < D; ++k) ld[i] += log(A_pp[(size_t)i * D + k]);
+            for (int k = 0; k < K; ++k) ld[D + i] += log(C_pp[(size_t)i * K + k]);
+        }
+        HIPCHK(hipMemcpyAsync(h->pri.A_pld, ld.data(), 2 * (size_t)D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     if ((rc = h2d(h, h->pri.Q_a0, Q_a0, D))) return rc;
     if ((rc = h2d(h, h->pri.Q_b0, Q_b0, D))) return rc;
     if ((rc = h2d(h, h->pri.R_a0, R_a0, K))) return rc;

@@ -57,6 +57,7 @@ static inline Layout make_layout(int D, int K) {
 struct Priors {          // device pointers, shared by all replicates
     double *x0_mean, *x0_prec, *A_pm, *A_pp, *C_pm, *C_pp, *Q_a0, *Q_b0, *R_a0, *R_b0;
     double *A_obs, *C_obs;   // observed entries of the matrices, [row][col], NaN = not observed
+    double *A_pld, *C_pld;   // [D] ln det of each column's diagonal prior precision
     double x0_lndet;     // ln det of x0_prec (Constant.lndet, node.py:301-302)
 };
 

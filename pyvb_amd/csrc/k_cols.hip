@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
         d4 acc[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
         for (int s = 0; s < ns; ++s) {
             const double bop = Gb[c * GS + 4 * s + q];
 #pragma unroll
@@ -119,6 +120,17 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
             __syncthreads();
             product();
             __syncthreads();
+            // everything that does not depend on the columns renewed in this block, so that the chain from
+            // one column to the next is a handful of multiply-adds
+            double gd[16], var[16], base[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                gd[u] = Gb[u * GS + 16 * b + u];
+                const double prec = p0[u] + lam * gd[u];                                // qprec  gaussian.py:117
+                var[u] = 1.0 / prec;                                                    // qcov   gaussian.py:118-119
+                base[u] = p0[u] * m0[u] + lam * hk[u];
+                p0[u] = prec;
+            }
             double dl[16];
             int mynk = 0;
 #pragma unroll
@@ -127,26 +139,23 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
                 dl[u] = 0.0;
                 if (i >= a.c0 && i < a.c1) {            // wave-uniform
                     const double xo = Mb[i * MS + lane];
-                    const double gii = Gb[u * GS + i];
-                    double acc = Sb[u * GS + lane] - xo * gii;
+                    double acc = Sb[u * GS + lane] - xo * gd[u];
 #pragma unroll
                     for (int v = 0; v < u; ++v) acc += dl[v] * Gb[u * GS + 16 * b + v];
-                    const double prec = p0[u] + lam * gii;                              // qprec  gaussian.py:117
-                    const double num = p0[u] * m0[u] + lam * (hk[u] - acc);
-                    double val = num / prec, var = 1.0 / prec;                          // qmu, qcov  gaussian.py:119-123
+                    double val = (base[u] - lam * acc) * var[u], vr = var[u];           // qmu  gaussian.py:119-123
                     // known entries (Gaussian.observe on a column, LDS_knowns_in_A.py:73-74): conditioning a
                     // diagonal Gaussian on them (gaussian.py:125-134) pins those entries and leaves the others
                     // alone; a column whose entries are all known is thereby never changed (gaussian.py:109-110)
                     const bool known = live && (ob[u] == ob[u]);
-                    if (known) { val = ob[u]; var = 0.0; }
+                    if (known) { val = ob[u]; vr = 0.0; }
                     const int nknown = __popcll(__ballot(known));
                     mynk = (lane == u) ? nknown : mynk;
                     if (live) {
                         dl[u] = val - xo;
                         Mb[i * MS + lane] = val;
-                        V[(size_t)i * rows + lane] = var;
+                        V[(size_t)i * rows + lane] = vr;
                     }
-                    Sb[u * GS + lane] = live ? prec : 1.0;
+                    Sb[u * GS + lane] = live ? p0[u] : 1.0;
                 } else {
                     Sb[u * GS + lane] = 1.0;
                     mynk = (lane == u) ? rows : mynk;   // no q_ln_det for a column that was not updated

@@ -121,26 +121,44 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
     if (lane < D) {
         const int i = lane;   // column i
         auto column = [&](int rows, const double* pp, const double* pm, const double* M, const double* V,
-                          const double* obs, double qld) {
-            double lndet = 0.0, tr = 0.0, lvar = 0.0;
+                          const double* obs, double qld, double lndet) {
+            // this lane's rows of pp and V are contiguous, the columns of M, pm and obs are coalesced across lanes
+            const double* ppi = pp + (size_t)i * rows;
+            const double* Vi = V + (size_t)i * rows;
+            double tr0 = 0.0, tr1 = 0.0, lvar = 0.0;
             int missing = 0;
-#pragma unroll 8
-            for (int k = 0; k < rows; ++k) {
-                const double p = pp[(size_t)i * rows + k], m = M[(size_t)k * D + i], m0 = pm[(size_t)k * D + i];
-                const double v = V[(size_t)i * rows + k], ob = obs[(size_t)k * D + i];
-                lndet += log(p);
-                tr += p * (m * m + v + m0 * m0 - 2.0 * m * m0);
-                if (!(ob == ob)) { ++missing; lvar += log(v); }
+            for (int k0 = 0; k0 < rows; k0 += 8) {
+                double p[8], v[8], m[8], m0[8], ob[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u < rows ? k0 + u : rows - 1;
+                    p[u] = ppi[k]; v[u] = Vi[k];
+                    m[u] = M[(size_t)k * D + i]; m0[u] = pm[(size_t)k * D + i]; ob[u] = obs[(size_t)k * D + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + u < rows) {
+                        const double t = p[u] * (m[u] * m[u] + v[u] + m0[u] * m0[u] - 2.0 * m[u] * m0[u]);
+                        if (u & 1) tr1 += t; else tr0 += t;
+                        if (!(ob[u] == ob[u])) ++missing;
+                    }
+                }
             }
-            double r = -0.5 * rows * LN2PI + 0.5 * lndet - 0.5 * tr;
+            double r = -0.5 * rows * LN2PI + 0.5 * lndet - 0.5 * (tr0 + tr1);
             if (missing == rows) r += 0.5 * rows * LN2PI + 0.5 * qld + 0.5 * rows;
-            else if (missing > 0) r -= 0.5 * missing * LN2PI - 0.5 * lvar - 0.5 * missing;
+            else if (missing > 0) {     // part of the column is known (rare): ln of the variances of the rest
+                for (int k = 0; k < rows; ++k) {
+                    const double ob = obs[(size_t)k * D + i];
+                    if (!(ob == ob)) lvar += log(Vi[k]);
+                }
+                r -= 0.5 * missing * LN2PI - 0.5 * lvar - 0.5 * missing;
+            }
             return r;
         };
         la = column(D, a.pri.A_pp, a.pri.A_pm, a.A_mean + (size_t)n * D * D, a.A_var + (size_t)n * D * D, a.pri.A_obs,
-                    a.qld_A[(size_t)n * D + i]);
+                    a.qld_A[(size_t)n * D + i], a.pri.A_pld[i]);
         lc = column(K, a.pri.C_pp, a.pri.C_pm, a.C_mean + (size_t)n * K * D, a.C_var + (size_t)n * D * K, a.pri.C_obs,
-                    a.qld_C[(size_t)n * D + i]);
+                    a.qld_C[(size_t)n * D + i], a.pri.C_pld[i]);
     }
     const double LA = wave_sum(la), LC = wave_sum(lc);
     if (lane == 0) {
