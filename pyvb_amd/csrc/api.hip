@@ -101,6 +101,8 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRY(dev_alloc(&h->gains, n * L.gains_total));
     TRY(dev_alloc(&h->scratch, n * 2 * D * D));
     TRY(dev_alloc(&h->trash, n * 256));
+    TRY(dev_alloc(&h->zeros, 64));
+    TRYHIP(hipMemset(h->zeros, 0, 64 * sizeof(double)));
     TRY(dev_alloc(&h->U, n * T * L.DP));
     TRYHIP(hipMalloc((void**)&h->warm, n * 2 * sizeof(int)));
     TRYHIP(hipMemset(h->warm, 0, n * 2 * sizeof(int)));
@@ -152,7 +154,7 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     pyvb_lds_comm_destroy(h);
     double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
-                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->mom, h->U};
+                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->U};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
     if (h->status) (void)hipFree(h->status);

@@ -85,6 +85,7 @@ struct pyvb_lds {
     double *gains;                  // [N][L.gains_total]
     double *scratch;                // [N][2][DP][DP] (M_C, M_A + M_C)
     int *warm;                      // [N][2]
+    double *zeros;                  // [64] zeros: the row that k_stats reads where there is no row
     double *trash;                  // [N][256] dump rows for masked-out stores of the sweep
     double *U; bool u_valid;        // [N][T][DP] c_t = F mu_{t-1} + G y_t written by the forward sweep for the backward one that follows it
     double *stats; int nchunk, chunk_len;   // [N][nchunk][L.stats_total]

@@ -14,6 +14,7 @@
 
 struct StatsArgs {
     const double* X; const double* Y; double* part;
+    const double* zeros;    // 64 zeros
     int N, T, D, K, nchunk, chunk_len;
     Layout L;
 };
@@ -22,46 +23,57 @@ struct StatsArgs {
 
 // The 42 accumulator tiles of the D = K = 64 case (10 of Sxx by symmetry, 16 of Sx1x, 16 of Syx) do not
 // fit one wavefront's registers next to the operands, so a workgroup is two wavefronts that split them:
-//   wave 0: Sxx (upper tiles) + the first KA row tiles of Syx      wave 1: Sx1x + the remaining Syx row tiles
-// with KA chosen to balance the MFMA counts (22 / 20 at D = K = 64).  Both read the same rows at the same
-// time (a barrier per k-step keeps them together), so the second read of a row is an L1 hit.
+//   wave 0: Sxx (upper tiles) + the first NA tiles of Syx      wave 1: Sx1x + the remaining Syx tiles
+// (Syx tiles counted row tile by row tile), NA chosen to give both the same number of MFMAs (21 / 21 at
+// D = K = 64).  Both read the same rows at about the same time (a barrier per PF k-steps keeps them
+// together), so the second read of a row is an L1 hit.
 template <int DT, int KT>
 struct StatsSplit {
-    static constexpr int NXX = DT * (DT + 1) / 2, TOTAL = NXX + DT * DT + KT * DT;
-    static constexpr int KA_RAW = (TOTAL - 2 * NXX + DT) / (2 * DT);      // round((TOTAL/2 - NXX) / DT)
-    static constexpr int KA = KA_RAW < 0 ? 0 : (KA_RAW > KT ? KT : KA_RAW);
+    static constexpr int NXX = DT * (DT + 1) / 2, NYX = KT * DT, TOTAL = NXX + DT * DT + NYX;
+    static constexpr int NA_RAW = (TOTAL + 1) / 2 - NXX;
+    static constexpr int NA = NA_RAW < 0 ? 0 : (NA_RAW > NYX ? NYX : NA_RAW);     // Syx tiles of wave 0
+    static constexpr int MA = (NA + DT - 1) / DT;       // wave 0 needs y row tiles [0, MA)
+    static constexpr int MB0 = NA / DT;                 // wave 1 needs y row tiles [MB0, KT)
 };
 
+#ifndef STATS_OCC
+#define STATS_OCC 2      // two wavefronts per SIMD run the fp64 matrix pipe faster than one (profiles/r01/microbench_f64.txt)
+#endif
+#ifndef STATS_PF
+#define STATS_PF 1      // k-steps per half of the operand ring (registers: 2 * PF * 10 doubles next to 168 of accumulators)
+#endif
+
 template <int DT, int KT>
-__global__ void __launch_bounds__(128, 2) k_stats(StatsArgs a) {
-    constexpr int DP = 16 * DT;
-    constexpr int KA = StatsSplit<DT, KT>::KA, KB = KT - KA;
+__global__ void __launch_bounds__(128, STATS_OCC) k_stats(StatsArgs a) {
+    constexpr int DP = 16 * DT, PF = STATS_PF;
+    using SP = StatsSplit<DT, KT>;
+    constexpr int NA = SP::NA, MA = SP::MA, MB0 = SP::MB0, MB = KT - MB0;
     const int ch = blockIdx.x, n = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const int T = a.T, D = a.D, K = a.K;
+    const int T = a.T, K = a.K;
     const double* X = a.X + (size_t)n * T * DP;        // rows: stride DP, accumulator order
     const double* Y = a.Y + (size_t)n * T * K;
+    const double* Z = a.zeros;                         // a row of zeros: what rows outside the chunk read as
     const int t0 = ch * a.chunk_len;
     const int t1 = (t0 + a.chunk_len < T) ? t0 + a.chunk_len : T;
     double* P = a.part + ((size_t)n * a.nchunk + ch) * a.L.stats_total;
 
-    // Rows are read from clamped (always valid) addresses and zeroed by selects when they lie outside
-    // [t0, t1) (or, for mu_{t+1}, beyond the chain).  Padded dimensions are not masked: they only reach
-    // padded rows/columns of the results, which no consumer reads.
-    // raw (unmasked) loads are issued ahead of a k-step's MFMAs, the masks are applied after them
-    auto row_x = [&](int t, bool valid, double* dst) {
-        const int tc = valid ? t : t0;
+    // Rows are fetched two halves of PF k-steps ahead into a ring of registers (the loop is unrolled so
+    // that every load has a fixed destination) and feed the MFMAs straight from there: a row outside
+    // [t0, t1) (or, for mu_{t+1}, beyond the chain) is read from the zero row instead, so no operand
+    // needs masking.  Padded dimensions are not masked either: they only reach padded rows/columns of the
+    // results, which no consumer reads.  A slot is refilled right behind the MFMAs that read it.
+    int xoff[DT];
 #pragma unroll
-        for (int m = 0; m < DT; ++m) {
-            const int dim = 16 * m + r;
-            dst[m] = X[(size_t)tc * DP + xpos(dim)];      // padded positions hold zeros
-        }
+    for (int m = 0; m < DT; ++m) xoff[m] = xpos(16 * m + r);      // padded positions hold zeros
+    auto row_x = [&](int t, double* dst) {
+        const double* p = t < t1 ? X + (size_t)t * DP : Z;
+#pragma unroll
+        for (int m = 0; m < DT; ++m) dst[m] = p[xoff[m]];
     };
-    auto row_y = [&](int t, bool valid, int m0, int cnt, double* dst) {
-        const int tc = valid ? t : t0;
-        for (int m = 0; m < cnt; ++m) {
-            const int dim = 16 * (m0 + m) + r;
-            dst[m] = Y[(size_t)tc * K + (dim < K ? dim : K - 1)];
-        }
+    auto row_x1 = [&](int t, double* dst) {             // row t + 1 for the lanes of row t
+        const double* p = (t < t1 && t + 1 < T) ? X + (size_t)(t + 1) * DP : Z;
+#pragma unroll
+        for (int m = 0; m < DT; ++m) dst[m] = p[xoff[m]];
     };
     auto store_tile = [&](size_t base, int m, int k, const d4& acc, bool mirror) {
 #pragma unroll
@@ -73,107 +85,136 @@ __global__ void __launch_bounds__(128, 2) k_stats(StatsArgs a) {
     };
 
     if (wave == 0) {
-        d4 sxx[DT][DT], syx[KA > 0 ? KA : 1][DT];
+        constexpr int MY = MA > 0 ? MA : 1;
+        d4 sxx[DT][DT], syx[MY][DT];
 #pragma unroll
         for (int m = 0; m < DT; ++m)
 #pragma unroll
             for (int k = 0; k < DT; ++k) sxx[m][k] = d4{0, 0, 0, 0};
 #pragma unroll
-        for (int m = 0; m < KA; ++m)
+        for (int m = 0; m < MY; ++m)
 #pragma unroll
             for (int k = 0; k < DT; ++k) syx[m][k] = d4{0, 0, 0, 0};
-        double xa[DT], ya[KA > 0 ? KA : 1];
-        {
-            const bool v = t0 + q < t1;
-            row_x(t0 + q, v, xa);
-            row_y(t0 + q, v, 0, KA, ya);
+        int yoff[MY];
 #pragma unroll
-            for (int m = 0; m < DT; ++m) xa[m] = v ? xa[m] : 0.0;
+        for (int m = 0; m < MY; ++m) { const int dim = 16 * m + r; yoff[m] = dim < K ? dim : K - 1; }
+        auto row_y = [&](int t, double* dst) {
+            const double* p = t < t1 ? Y + (size_t)t * K : Z;
 #pragma unroll
-            for (int m = 0; m < KA; ++m) ya[m] = v ? ya[m] : 0.0;
-        }
-        for (int tb = t0; tb < t1; tb += 4) {
-            double xa_n[DT], ya_n[KA > 0 ? KA : 1];
-            const bool v = tb + 4 + q < t1;
-            row_x(tb + 4 + q, v, xa_n);
+            for (int m = 0; m < MA; ++m) dst[m] = p[yoff[m]];
+        };
+        double xr[2][PF][DT], yr[2][PF][MY];
+        auto fill = [&](int h, int tb) {        // the PF k-steps that start at row tb, into half h of the ring
 #pragma unroll
-            for (int m = 0; m < KA; ++m) { const int dim = 16 * m + r; ya_n[m] = Y[(size_t)(v ? tb + 4 + q : t0) * K + (dim < K ? dim : K - 1)]; }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int p = 0; p < PF; ++p) {
+                row_x(tb + 4 * p + q, xr[h][p]);
+                row_y(tb + 4 * p + q, yr[h][p]);
+            }
+        };
+        // same order of loads as the loop issues them: the compiler's in-order vmcnt waits at the loop head
+        // are the minimum over both incoming edges
+        fill(0, t0);
+        __builtin_amdgcn_sched_barrier(0);
+        fill(1, t0 + 4 * PF);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int tb = t0; tb < t1; tb += 8 * PF) {
 #pragma unroll
-            for (int m = 0; m < DT; ++m)
+            for (int h = 0; h < 2; ++h) {
+                // tile by tile, the PF k-steps of a tile back to back: a chain of dependent MFMAs on one
+                // accumulator runs faster than the same MFMAs spread over many (profiles/r01/microbench_f64.txt)
 #pragma unroll
-                for (int k = m; k < DT; ++k) sxx[m][k] = MFMA(xa[m], xa[k], sxx[m][k]);
+                for (int m = 0; m < DT; ++m)
 #pragma unroll
-            for (int m = 0; m < KA; ++m)
+                    for (int k = m; k < DT; ++k)
 #pragma unroll
-                for (int k = 0; k < DT; ++k) syx[m][k] = MFMA(ya[m], xa[k], syx[m][k]);
-            __builtin_amdgcn_sched_barrier(0);
+                        for (int p = 0; p < PF; ++p) sxx[m][k] = MFMA(xr[h][p][m], xr[h][p][k], sxx[m][k]);
 #pragma unroll
-            for (int m = 0; m < DT; ++m) xa[m] = v ? xa_n[m] : 0.0;
+                for (int m = 0; m < MA; ++m)
 #pragma unroll
-            for (int m = 0; m < KA; ++m) ya[m] = v ? ya_n[m] : 0.0;
-            __syncthreads();
+                    for (int k = 0; k < DT; ++k)
+                        if (m * DT + k < NA) {
+#pragma unroll
+                            for (int p = 0; p < PF; ++p) syx[m][k] = MFMA(yr[h][p][m], xr[h][p][k], syx[m][k]);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+                fill(h, tb + (h + 2) * 4 * PF);     // refilled behind the MFMAs that read it; a whole half to arrive
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_barrier();     // lock-step only (L1 reuse between the two waves): no fence, the loads in flight stay in flight
         }
 #pragma unroll
         for (int m = 0; m < DT; ++m)
 #pragma unroll
             for (int k = m; k < DT; ++k) store_tile(a.L.oSxx, m, k, sxx[m][k], k > m);
 #pragma unroll
-        for (int m = 0; m < KA; ++m)
+        for (int m = 0; m < MA; ++m)
 #pragma unroll
-            for (int k = 0; k < DT; ++k) store_tile(a.L.oSyx, m, k, syx[m][k], false);
+            for (int k = 0; k < DT; ++k)
+                if (m * DT + k < NA) store_tile(a.L.oSyx, m, k, syx[m][k], false);
     } else {
-        d4 sx1[DT][DT], syx[KB > 0 ? KB : 1][DT];
+        constexpr int MY = MB > 0 ? MB : 1;
+        d4 sx1[DT][DT], syx[MY][DT];
 #pragma unroll
         for (int m = 0; m < DT; ++m)
 #pragma unroll
             for (int k = 0; k < DT; ++k) sx1[m][k] = d4{0, 0, 0, 0};
 #pragma unroll
-        for (int m = 0; m < KB; ++m)
+        for (int m = 0; m < MY; ++m)
 #pragma unroll
             for (int k = 0; k < DT; ++k) syx[m][k] = d4{0, 0, 0, 0};
-        double xa[DT], xb[DT], ya[KB > 0 ? KB : 1];
-        {
-            const bool v = t0 + q < t1, v1 = v && (t0 + q + 1 < T);
-            row_x(t0 + q, v, xa);
-            row_x(t0 + q + 1, v1, xb);
-            row_y(t0 + q, v, KA, KB, ya);
+        int yoff[MY];
 #pragma unroll
-            for (int m = 0; m < DT; ++m) { xa[m] = v ? xa[m] : 0.0; xb[m] = v1 ? xb[m] : 0.0; }
+        for (int m = 0; m < MY; ++m) { const int dim = 16 * (MB0 + m) + r; yoff[m] = dim < K ? dim : K - 1; }
+        auto row_y = [&](int t, double* dst) {
+            const double* p = t < t1 ? Y + (size_t)t * K : Z;
 #pragma unroll
-            for (int m = 0; m < KB; ++m) ya[m] = v ? ya[m] : 0.0;
-        }
-        for (int tb = t0; tb < t1; tb += 4) {
-            double xa_n[DT], xb_n[DT], ya_n[KB > 0 ? KB : 1];
-            const bool v = tb + 4 + q < t1, v1 = v && (tb + 5 + q < T);
-            row_x(tb + 4 + q, v, xa_n);
-            row_x(tb + 5 + q, v1, xb_n);
+            for (int m = 0; m < MB; ++m) dst[m] = p[yoff[m]];
+        };
+        double xr[2][PF][DT], x1r[2][PF][DT], yr[2][PF][MY];
+        auto fill = [&](int h, int tb) {
 #pragma unroll
-            for (int m = 0; m < KB; ++m) { const int dim = 16 * (KA + m) + r; ya_n[m] = Y[(size_t)(v ? tb + 4 + q : t0) * K + (dim < K ? dim : K - 1)]; }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int p = 0; p < PF; ++p) {
+                row_x(tb + 4 * p + q, xr[h][p]);
+                row_x1(tb + 4 * p + q, x1r[h][p]);
+                row_y(tb + 4 * p + q, yr[h][p]);
+            }
+        };
+        fill(0, t0);
+        __builtin_amdgcn_sched_barrier(0);
+        fill(1, t0 + 4 * PF);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int tb = t0; tb < t1; tb += 8 * PF) {
 #pragma unroll
-            for (int m = 0; m < DT; ++m)
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int k = 0; k < DT; ++k) sx1[m][k] = MFMA(xb[m], xa[k], sx1[m][k]);
+                for (int m = 0; m < DT; ++m)
 #pragma unroll
-            for (int m = 0; m < KB; ++m)
+                    for (int k = 0; k < DT; ++k)
 #pragma unroll
-                for (int k = 0; k < DT; ++k) syx[m][k] = MFMA(ya[m], xa[k], syx[m][k]);
-            __builtin_amdgcn_sched_barrier(0);
+                        for (int p = 0; p < PF; ++p) sx1[m][k] = MFMA(x1r[h][p][m], xr[h][p][k], sx1[m][k]);
 #pragma unroll
-            for (int m = 0; m < DT; ++m) { xa[m] = v ? xa_n[m] : 0.0; xb[m] = v1 ? xb_n[m] : 0.0; }
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int m = 0; m < KB; ++m) ya[m] = v ? ya_n[m] : 0.0;
-            __syncthreads();
+                    for (int k = 0; k < DT; ++k)
+                        if ((MB0 + m) * DT + k >= NA) {
+#pragma unroll
+                            for (int p = 0; p < PF; ++p) syx[m][k] = MFMA(yr[h][p][m], xr[h][p][k], syx[m][k]);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+                fill(h, tb + (h + 2) * 4 * PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_barrier();
         }
 #pragma unroll
         for (int m = 0; m < DT; ++m)
 #pragma unroll
             for (int k = 0; k < DT; ++k) store_tile(a.L.oSx1x, m, k, sx1[m][k], false);
 #pragma unroll
-        for (int m = 0; m < KB; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int k = 0; k < DT; ++k) store_tile(a.L.oSyx, KA + m, k, syx[m][k], false);
+            for (int k = 0; k < DT; ++k)
+                if ((MB0 + m) * DT + k >= NA) store_tile(a.L.oSyx, MB0 + m, k, syx[m][k], false);
     }
 }
 
@@ -205,7 +246,7 @@ static void launch_stats_t(pyvb_lds* h, const StatsArgs& a) {
 
 int launch_stats(pyvb_lds* h) {
     StatsArgs a;
-    a.X = h->X[h->cur]; a.Y = h->Y; a.part = h->stats;
+    a.X = h->X[h->cur]; a.Y = h->Y; a.part = h->stats; a.zeros = h->zeros;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.nchunk = h->nchunk; a.chunk_len = h->chunk_len; a.L = h->L;
     {
         TimedLaunch tl(h, PYVB_K_STATS);
