@@ -30,6 +30,29 @@ __global__ void __launch_bounds__(256) k_mfma(double* out, int iters, double a0,
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// NACC accumulators, each updated CH times back to back before the next (CH = 1: round robin).
+// Operands change every pass so that nothing is loop invariant.  WPS = waves per SIMD the launch is sized for.
+template <int NACC, int CH, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_mfma_many(double* out, int iters, double a0, double b0) {
+    d4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = d4{0, 0, 0, 0};
+    double a[CH], b[CH];
+    for (int c = 0; c < CH; ++c) { a[c] = a0 + threadIdx.x * 1e-9 + c; b[c] = b0 + c; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], b[c], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) a[c] += 1e-9;
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void __launch_bounds__(256) k_fma(double* out, int iters, double a0, double b0) {
     double acc[8];
     for (int i = 0; i < 8; ++i) acc[i] = threadIdx.x * 1e-9 + i;
@@ -129,6 +152,27 @@ int main() {
         double flv = (double)blocks * 256 * iters * 16 * 2.0;
         ms = time_ms([&] { k_fma<<<blocks, 256>>>(out, iters, 1.0000001, 1e-3); }, 5);
         printf("v_fma_f64 indep8         waves/SIMD=%d: %.3f ms  %.2f TFLOP/s  (%.2f cyc/FMA/SIMD @2.4GHz)\n", wps, ms, flv / ms * 1e-9, ms * 1e-3 * 2.4e9 / (iters * 16.0 * wps));
+    }
+    // sustained rates: ~1 s of back-to-back launches each (the short runs above see boost clocks)
+    {
+        const int it2 = 2000;
+        auto sustained = [&](const char* name, auto launch, double flops_per_launch) {
+            for (int i = 0; i < 3; ++i) launch();
+            CK(hipDeviceSynchronize());
+            double ms1 = time_ms(launch, 5);
+            int reps = (int)(1000.0 / ms1) + 1;
+            double ms = time_ms(launch, reps);
+            printf("sustained %-44s %.3f ms/launch x %d  %.2f TFLOP/s\n", name, ms, reps, flops_per_launch / ms * 1e-9);
+        };
+        sustained("21 acc round robin, 1 wave/SIMD", [&] { k_mfma_many<21, 1, 1><<<cus, 256>>>(out, it2, 1.0, 1e-3); }, (double)cus * 4 * it2 * 21 * 2048.0);
+        sustained("21 acc chains of 4, 1 wave/SIMD", [&] { k_mfma_many<21, 4, 1><<<cus, 256>>>(out, it2 / 4, 1.0, 1e-3); }, (double)cus * 4 * (it2 / 4) * 21 * 4 * 2048.0);
+        sustained("21 acc round robin, 2 waves/SIMD", [&] { k_mfma_many<21, 1, 2><<<cus * 2, 256>>>(out, it2, 1.0, 1e-3); }, (double)cus * 2 * 4 * it2 * 21 * 2048.0);
+        sustained("21 acc chains of 4, 2 waves/SIMD", [&] { k_mfma_many<21, 4, 2><<<cus * 2, 256>>>(out, it2 / 4, 1.0, 1e-3); }, (double)cus * 2 * 4 * (it2 / 4) * 21 * 4 * 2048.0);
+        sustained("4 acc chains of 16, 1 wave/SIMD", [&] { k_mfma_many<4, 16, 1><<<cus, 256>>>(out, it2 / 4, 1.0, 1e-3); }, (double)cus * 4 * (it2 / 4) * 4 * 16 * 2048.0);
+        sustained("4 acc round robin, 1 wave/SIMD", [&] { k_mfma_many<4, 1, 1><<<cus, 256>>>(out, it2 * 4, 1.0, 1e-3); }, (double)cus * 4 * (it2 * 4) * 4 * 2048.0);
+        sustained("1 acc (dependent), 1 wave/SIMD", [&] { k_mfma_many<1, 16, 1><<<cus, 256>>>(out, it2, 1.0, 1e-3); }, (double)cus * 4 * it2 * 16 * 2048.0);
+        sustained("1 acc (dependent), 2 waves/SIMD", [&] { k_mfma_many<1, 16, 2><<<cus * 2, 256>>>(out, it2, 1.0, 1e-3); }, (double)cus * 2 * 4 * it2 * 16 * 2048.0);
+        sustained("4 acc chains of 16, 2 waves/SIMD", [&] { k_mfma_many<4, 16, 2><<<cus * 2, 256>>>(out, it2 / 4, 1.0, 1e-3); }, (double)cus * 2 * 4 * (it2 / 4) * 4 * 16 * 2048.0);
     }
     {
         int blocks = cus;
