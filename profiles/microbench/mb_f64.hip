@@ -53,6 +53,42 @@ __global__ void __launch_bounds__(256, WPS) k_mfma_many(double* out, int iters, 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The MFMA stream of k_stats' second wavefront (16 tiles x1 x^T + 5 tiles y x^T per k-step, operands in
+// ten distinct registers), without memory (LOADS = 0) or with the ten operand loads of a k-step from an
+// L1-resident buffer, issued in a burst behind the MFMAs (LOADS = 1) or one between every two (LOADS = 2).
+template <int WPS, int LOADS>
+__global__ void __launch_bounds__(256, WPS) k_mfma_stats(double* out, const double* buf, int iters) {
+    d4 acc[21];
+    for (int i = 0; i < 21; ++i) acc[i] = d4{0, 0, 0, 0};
+    double op[2][10];
+    const double* p = buf + (threadIdx.x & 63);
+    for (int j = 0; j < 10; ++j) { op[0][j] = p[64 * j]; op[1][j] = p[64 * (j + 10)]; }
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 21; ++i) {
+                const int m = i < 16 ? 4 + i / 4 : 8 + (i - 16) / 4, k = i % 4;       // x1 in 4..7, y in 8..9, x in 0..3
+                acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[h][m], op[h][k], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (LOADS == 2 && (i & 1) && i / 2 < 10) { op[h ^ 1][i / 2] = p[64 * (i / 2) + 640 * ((it + h) & 1)]; __builtin_amdgcn_sched_barrier(0); }
+            }
+            if (LOADS == 1) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) op[h ^ 1][j] = p[64 * j + 640 * ((it + h) & 1)];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 21; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_stream(const d4* __restrict__ src, d4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 __global__ void __launch_bounds__(256) k_fma(double* out, int iters, double a0, double b0) {
     double acc[8];
     for (int i = 0; i < 8; ++i) acc[i] = threadIdx.x * 1e-9 + i;
@@ -164,6 +200,39 @@ int main() {
             double ms = time_ms(launch, reps);
             printf("sustained %-44s %.3f ms/launch x %d  %.2f TFLOP/s\n", name, ms, reps, flops_per_launch / ms * 1e-9);
         };
+        double* buf; CK(hipMalloc(&buf, 1 << 16));
+        {   // random operands: an all-zero stream draws less power and sustains a higher clock than real data
+            std::vector<double> hb((1 << 16) / 8);
+            unsigned long long st = 88172645463325252ull;
+            for (auto& v : hb) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = getenv("MB_ZERO") ? 0.0 : (double)(st >> 11) / 9007199254740992.0 * 2.0 - 1.0; }
+            CK(hipMemcpy(buf, hb.data(), 1 << 16, hipMemcpyHostToDevice));
+        }
+        const double fs1 = (double)cus * 4 * it2 * 21 * 2048.0;
+        sustained("stats stream, no loads, 1 wave/SIMD", [&] { k_mfma_stats<1, 0><<<cus, 256>>>(out, buf, it2); }, fs1);
+        sustained("stats stream, no loads, 2 waves/SIMD", [&] { k_mfma_stats<2, 0><<<cus * 2, 256>>>(out, buf, it2); }, 2 * fs1);
+        sustained("stats stream, load burst, 1 wave/SIMD", [&] { k_mfma_stats<1, 1><<<cus, 256>>>(out, buf, it2); }, fs1);
+        sustained("stats stream, load burst, 2 waves/SIMD", [&] { k_mfma_stats<2, 1><<<cus * 2, 256>>>(out, buf, it2); }, 2 * fs1);
+        sustained("stats stream, loads spread, 1 wave/SIMD", [&] { k_mfma_stats<1, 2><<<cus, 256>>>(out, buf, it2); }, fs1);
+        sustained("stats stream, loads spread, 2 waves/SIMD", [&] { k_mfma_stats<2, 2><<<cus * 2, 256>>>(out, buf, it2); }, 2 * fs1);
+        {   // does HBM traffic between the MFMA launches lower the clock the MFMA launches see?
+            const size_t nb = (size_t)4 << 30;      // 4 GiB read + 4 GiB written per k_stream launch
+            d4 *sa, *sb; CK(hipMalloc(&sa, nb)); CK(hipMalloc(&sb, nb)); CK(hipMemset(sa, 1, nb));
+            hipEvent_t ev[4]; for (auto& x : ev) CK(hipEventCreate(&x));
+            double tm = 0, ts = 0; const int reps = 200;
+            for (int i = 0; i < reps + 20; ++i) {
+                CK(hipEventRecord(ev[0]));
+                k_mfma_stats<2, 2><<<cus * 2, 256>>>(out, buf, it2);
+                CK(hipEventRecord(ev[1]));
+                k_stream<<<cus * 8, 256>>>(sa, sb, nb / 32);
+                CK(hipEventRecord(ev[2]));
+                CK(hipEventSynchronize(ev[2]));
+                float a, b; CK(hipEventElapsedTime(&a, ev[0], ev[1])); CK(hipEventElapsedTime(&b, ev[1], ev[2]));
+                if (i >= 20) { tm += a; ts += b; }
+            }
+            printf("alternating with an 8 GiB stream kernel: stats stream (loads spread, 2 waves/SIMD) %.3f ms  %.2f TFLOP/s;  stream %.3f ms  %.2f TB/s\n",
+                   tm / reps, 2 * fs1 / (tm / reps) * 1e-9, ts / reps, 2.0 * nb / (ts / reps) * 1e-9);
+            CK(hipFree(sa)); CK(hipFree(sb));
+        }
         sustained("21 acc round robin, 1 wave/SIMD", [&] { k_mfma_many<21, 1, 1><<<cus, 256>>>(out, it2, 1.0, 1e-3); }, (double)cus * 4 * it2 * 21 * 2048.0);
         sustained("21 acc chains of 4, 1 wave/SIMD", [&] { k_mfma_many<21, 4, 1><<<cus, 256>>>(out, it2 / 4, 1.0, 1e-3); }, (double)cus * 4 * (it2 / 4) * 21 * 4 * 2048.0);
         sustained("21 acc round robin, 2 waves/SIMD", [&] { k_mfma_many<21, 1, 2><<<cus * 2, 256>>>(out, it2, 1.0, 1e-3); }, (double)cus * 2 * 4 * it2 * 21 * 2048.0);
