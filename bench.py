@@ -52,7 +52,7 @@ def cpu_baseline_and_parity(T, D, K, device):
     from oracle import lds_closed_form as O
     from pyvb_amd import synth
     from pyvb_amd.lds import LDSBatch
-    n_s, iters = 2, 3
+    n_s, iters = 4, 8        # about 12 s of numpy on the GPU box's host cores
     Y, st0, pri = synth.make_problem(T, D, K, n_s, seed=99)
     st = O.expand_state(st0, pri, T)
     t0 = time.perf_counter()
@@ -170,6 +170,9 @@ def main():
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel": "k_sweep", "launches": sweep_n, "mean_launch_ms": mean_ms,
+                # the backward launch reuses c_t = F mu_{t-1} + G y_t of the forward one and executes a third of
+                # its algorithmic FLOPs: executed / algorithmic over a forward+backward pair
+                "executed_over_algorithmic_flops": (3.0 + 1.0) / 6.0,
                 "hbm_algorithmic_GBs": bytes_per_launch / (mean_ms * 1e-3) / 1e9 if sweep_n else 0.0}
 
     if rank == 0:
