@@ -301,6 +301,22 @@ def test_headline_shape_against_oracle():
     big.close()
 
 
+def test_baseline_config2_single_long_chain():
+    """BASELINE configs[1]: T = 10^4, D = K = 16, one replicate, three full iterations against the oracle
+    (the segmented sweeps run with 624 interior nodes per segment and a data-driven warm-up)."""
+    T, D, K = 10000, 16, 16
+    Y, st0, pri = synth.make_problem(T, D, K, 1, seed=2)
+    st = O.expand_state(st0, pri, T)
+    b = _batch(Y, st0, pri)
+    for it in range(3):
+        parts = O.iterate(st, pri, Y)
+        b.iterate(1)
+        _close(b.get_state(("X",))["X"], st["X"], "X (config 2, iteration %d)" % it)
+        _close(b.elbo().sum(1), parts.sum(1), "elbo (config 2, iteration %d)" % it)
+    _compare_params(b, st, "config 2 ")
+    b.close()
+
+
 def test_rccl_communicator_single_rank():
     """The RCCL leg of pyvb_lds_elbo_total (dlopen of librccl, unique id, communicator, all-reduce on
     the handle's stream) with a one-rank communicator: the sum over ranks is the local sum."""
