@@ -7,8 +7,8 @@
 //   qprec = pprec + sum m1 ; cho_factor ; cho_solve gaussian.py:117-119
 //   q_ln_det (quirk Q1)                             gaussian.py:120
 //
-// One 256-thread workgroup per replicate, every matrix in LDS (row stride DP+2 doubles, which
-// makes the MFMA A-operand reads bank-conflict free).  All D x D products run on
+// One 256-thread workgroup per replicate, the work matrices in LDS (row stride DP+2 doubles, which
+// makes the MFMA A-operand reads bank-conflict free), <A> and <C> read from global memory.  All D x D products run on
 // v_mfma_f64_16x16x4_f64, one row tile per wavefront.  The posterior precisions are inverted in
 // place by Gauss-Jordan elimination without pivoting (they are symmetric positive definite); its
 // pivots are the squares of the Cholesky diagonal, which gives the reference's q_ln_det.
@@ -45,6 +45,7 @@ __device__ __forceinline__ void mm(int wave, int lane, FA a_at, FB b_at, FS stor
         d4 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = d4{0, 0, 0, 0};
+#pragma unroll 4
         for (int s = 0; s < KS; ++s) {
             const double av = a_at(16 * m + r, 4 * s + q);
 #pragma unroll
@@ -163,8 +164,9 @@ __device__ static int warmup_length(double* W1, double* W2, int LD, int D, int t
 template <int DT, int KT>
 __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     constexpr int DP = 16 * DT, KP = 16 * KT, DS = 4 * DT, KS = 4 * KT, LD = DP + 2;
-    __shared__ double sA[DP * LD];       // <A>  [row k][col i], zero padded
-    __shared__ double sC[KP * LD];       // <C>  [row k][col i], zero padded
+    // <A> and <C> are MFMA operands straight from global memory (L2-resident, 32 KB each): keeping them in
+    // LDS too would put the workgroup over half of the CU's 160 KB and halve the occupancy of a kernel
+    // that is all latency.  Zero padded by the accessors.
     __shared__ double P[DP * LD];        // posterior precision -> covariance
     __shared__ double W[DP * LD];        // work
     __shared__ double qbar[64], rbar[64], rowp[64], colp[64], vec[64], gjbuf[768 + 192];
@@ -182,15 +184,11 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
         rbar[tid] = (tid < K) ? a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid] : 0.0;
     }
     for (int idx = tid; idx < DP * LD; idx += PREP_THREADS) {
-        const int i = idx / LD, j = idx % LD;
-        sA[idx] = (i < D && j < D) ? Am[i * D + j] : 0.0;
         W[idx] = 0.0;
         P[idx] = 0.0;
     }
-    for (int idx = tid; idx < KP * LD; idx += PREP_THREADS) {
-        const int i = idx / LD, j = idx % LD;
-        sC[idx] = (i < K && j < D) ? Cm[i * D + j] : 0.0;
-    }
+    auto A_at = [&](int i, int j) { const double v = Am[(i < D ? i : D - 1) * D + (j < D ? j : D - 1)]; return (i < D && j < D) ? v : 0.0; };
+    auto C_at = [&](int k, int j) { const double v = Cm[(k < K ? k : K - 1) * D + (j < D ? j : D - 1)]; return (k < K && j < D) ? v : 0.0; };
     __syncthreads();
     // traces of the column covariances against the noise expectations (diagonal of node.py:223-227)
     if (tid < D) {
@@ -202,13 +200,13 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     __syncthreads();
     // <C^T R C> -> W;  <C^T R C> + <A^T Q A> -> P     (node.py:213-227)
     mm<DT, DT, KS>(wave, lane,
-                   [&](int i, int k) { return sC[k * LD + i] * rbar[k]; },
-                   [&](int k, int j) { return sC[k * LD + j]; },
+                   [&](int i, int k) { return C_at(k, i) * rbar[k]; },
+                   [&](int k, int j) { return C_at(k, j); },
                    [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += rowp[i]; W[i * LD + j] = v; } });
     __syncthreads();
     mm<DT, DT, DS>(wave, lane,
-                   [&](int i, int k) { return sA[k * LD + i] * qbar[k]; },
-                   [&](int k, int j) { return sA[k * LD + j]; },
+                   [&](int i, int k) { return A_at(k, i) * qbar[k]; },
+                   [&](int k, int j) { return A_at(k, j); },
                    [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += colp[i]; P[i * LD + j] = W[i * LD + j] + v; } });
     __syncthreads();
 
@@ -273,7 +271,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
         if (cls != 0)       // Sigma <Q><A>: multiplies the mean of X_{t-1}
             mm<DT, DT, DS>(wave, lane,
                            [&](int i, int k) { return P[i * LD + k]; },
-                           [&](int k, int j) { return qbar[k] * sA[k * LD + j]; },
+                           [&](int k, int j) { return qbar[k] * A_at(k, j); },
                            [&](int i, int j, double v) {
                                if (i < D && j < D) {
                                    FT[(size_t)j * DP + i] = v;
@@ -283,7 +281,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
         if (cls != 2)       // Sigma <A>^T<Q>: multiplies the mean of X_{t+1}
             mm<DT, DT, DS>(wave, lane,
                            [&](int i, int k) { return P[i * LD + k]; },
-                           [&](int k, int j) { return sA[j * LD + k] * qbar[j]; },
+                           [&](int k, int j) { return A_at(j, k) * qbar[j]; },
                            [&](int i, int j, double v) {
                                if (i < D && j < D) {
                                    BT[(size_t)j * DP + i] = v;
@@ -293,7 +291,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
         // Sigma <C>^T<R>: multiplies y_t
         mm<DT, KT, DS>(wave, lane,
                        [&](int i, int k) { return P[i * LD + k]; },
-                       [&](int k, int l) { return sC[l * LD + k] * rbar[l]; },
+                       [&](int k, int l) { return C_at(l, k) * rbar[l]; },
                        [&](int i, int l, double v) {
                            if (i < D && l < K) {
                                GT[(size_t)l * DP + i] = v;
