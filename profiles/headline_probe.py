@@ -15,4 +15,6 @@ b = LDSBatch.from_problem(Y, st0, pri)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 b.iterate(2); b.sync(); b.timing(True)
 b.iterate(iters); b.sync()
-print({k: round(v[0] / iters, 3) for k, v in b.kernel_times().items()}, "warm-up", np.bincount(b.warmup().ravel())[1:].nonzero()[0] + 1 if hasattr(b, "warmup") else "")
+w = b.get_warmup()
+print({k: round(v[0] / iters, 3) for k, v in b.kernel_times().items()},
+      "warm-up forward", dict(zip(*np.unique(w[:, 0], return_counts=True))), "backward", dict(zip(*np.unique(w[:, 1], return_counts=True))))

@@ -119,44 +119,65 @@ __device__ static void gj_inverse(double (&v)[NP][4 * DT], int D, int tid, doubl
     __syncthreads();
 }
 
+// max_i sum_j |A_ij|: four threads per row (16 columns each), rows and then wavefronts combined by
+// shuffles; two barriers.  red: 4 doubles of LDS.
 __device__ static double inf_norm(const double* A, int LD, int D, int tid, double* red) {
-    if (tid < D) {
-        double s = 0.0;
-        for (int j = 0; j < D; ++j) s += fabs(A[tid * LD + j]);
-        red[tid] = s;
+    const int row = tid >> 2, part = tid & 3;
+    double s = 0.0;
+    if (row < D) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = 16 * part + u;
+            if (j < D) s += fabs(A[row * LD + j]);
+        }
     }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) s = fmax(s, __shfl_xor(s, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    double m = 0.0;
-    for (int i = 0; i < D; ++i) m = fmax(m, red[i]);
+    const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     __syncthreads();
     return m;
 }
 
 // Number of recurrence steps after which the influence of the starting state of
-// x_t = M x_{t-1} + c_t is below 1e-18 relative: ||M^J|| <= ||M^(2^k)||^(J/2^k) (any induced norm).
+// x_t = M x_{t-1} + c_t is below 1e-18 relative.  Any induced norm is submultiplicative, so with
+// n_k = ||M^(2^k)|| (k = 2..5, from repeated squaring) every J = 4 a + 8 b + 16 c + 32 d has
+// ||M^J|| <= n_2^a n_3^b n_4^c n_5^d; the smallest such J under the tolerance is taken.
 // M is in W1 (padded with zeros) on entry; W1/W2 are clobbered.
 template <int DT>
 __device__ static int warmup_length(double* W1, double* W2, int LD, int D, int tid, double* red) {
     constexpr int DS = 4 * DT;
     const double lntol = -41.4465316738928;   // ln(1e-18)
     const int wave = tid >> 6, lane = tid & 63;
-    int best = 1 << 30;
+    double l2 = 1.0, l3 = 1.0, l4 = 1.0, l5 = 1.0;   // ln n_k; +1 marks "not contracting at this power"
     double* src = W1; double* dst = W2;
+#pragma unroll
     for (int k = 1; k <= 5; ++k) {
         mm<DT, DT, DS>(wave, lane,
                        [&](int i, int kk) { return src[i * LD + kk]; },
                        [&](int kk, int j) { return src[kk * LD + j]; },
                        [&](int i, int j, double v) { dst[i * LD + j] = v; });      // M^(2^k)
         __syncthreads();
-        if (k >= 3) {
+        if (k >= 2) {
             const double nrm = inf_norm(dst, LD, D, tid, red);
-            if (nrm < 1.0) {
-                const double steps = (nrm > 0.0) ? ceil(lntol / log(nrm)) : 1.0;
-                const double J = (double)(1 << k) * steps;
-                if (J < (double)best) best = (int)J;
-            }
+            const double l = nrm < 1.0 ? ((nrm > 0.0) ? log(nrm) : -1e300) : 1.0;
+            if (k == 2) l2 = l; else if (k == 3) l3 = l; else if (k == 4) l4 = l; else l5 = l;
         }
         double* t = src; src = dst; dst = t;
+    }
+    int best = 1 << 30;
+    if (tid == 0) {         // only thread 0 stores the result
+        for (int d = 0; d <= 16; ++d)
+            for (int abc = 0; abc < 8; ++abc) {
+                const int a = abc & 1, b = (abc >> 1) & 1, c = abc >> 2;
+                if ((a && l2 > 0.0) || (b && l3 > 0.0) || (c && l4 > 0.0) || (d && l5 > 0.0)) continue;
+                const double bound = (a ? l2 : 0.0) + (b ? l3 : 0.0) + (c ? l4 : 0.0) + (d ? d * l5 : 0.0);
+                const int J = 4 * a + 8 * b + 16 * c + 32 * d;
+                if (J > 0 && bound <= lntol && J < best) best = J;
+            }
     }
     return best;
 }
