@@ -12,8 +12,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // k_prep once per parameter change and read by the sweep / step kernels.
 //   Sigma_c = posterior covariance of class c (0: X_0, 1: interior, 2: X_{T-1})
 //   F  = Sigma_1 <Q><A>      B  = Sigma_1 <A>^T<Q>     G  = Sigma_1 <C>^T<R>
-//   B0 = Sigma_0 <A>^T<Q>    G0 = Sigma_0 <C>^T<R>     h0 = Sigma_0 L0 m0
-//   FL = Sigma_2 <Q><A>      GL = Sigma_2 <C>^T<R>
+// The two boundary nodes are single matrix-vector chains, mu = Sigma_c (sum of the messages), so for them
+// the block holds the pieces instead of products: S0 = Sigma_0, S2 = Sigma_2 ([row][DP]), qr = <Q> diagonal
+// (64) then <R> diagonal (64), w0 = L0 m0 (the Constant parents of X_0).
 // "n"/"p" blocks are laid out as v_mfma_f64_16x16x4 A-operands: element [(m*S+s)*64+lane]
 // = M[16m + (lane&15)][kidx(s, lane>>4)], kidx natural = 4s+q (F, B: they meet states, which come in
 // accumulator order), permuted = 8(s>>1)+2q+(s&1) (G: it meets rows of Y read 16 bytes per lane).
@@ -21,7 +22,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 struct Layout {
     int D, K, DT, KT, DP, KP, DS, KS;
     size_t oFn, oBn, oGp;
-    size_t oFT, oBT, oGT, oB0T, oG0T, oh0, oFLT, oGLT;
+    size_t oFT, oBT, oGT, oS0, oS2, oqr, ow0;
     size_t gains_total;     // doubles per replicate
     size_t stats_total;     // doubles per replicate per chunk: Sxx[DP][DP], Sx1x[DP][DP], Syx[KP][DP]
     size_t oSxx, oSx1x, oSyx;
@@ -46,8 +47,7 @@ static inline Layout make_layout(int D, int K) {
     L.oFn = o; o += dd; L.oBn = o; o += dd; L.oGp = o; o += dk;
     size_t tdd = (size_t)L.DP * L.DP, tkd = (size_t)L.KP * L.DP;
     L.oFT = o; o += tdd; L.oBT = o; o += tdd; L.oGT = o; o += tkd;
-    L.oB0T = o; o += tdd; L.oG0T = o; o += tkd; L.oh0 = o; o += L.DP;
-    L.oFLT = o; o += tdd; L.oGLT = o; o += tkd;
+    L.oS0 = o; o += tdd; L.oS2 = o; o += tdd; L.oqr = o; o += 128; L.ow0 = o; o += L.DP;
     L.gains_total = o;
     L.oSxx = 0; L.oSx1x = tdd; L.oSyx = 2 * tdd;
     L.stats_total = 2 * tdd + tkd;

@@ -184,13 +184,13 @@ __device__ static int warmup_length(double* W1, double* W2, int LD, int D, int t
 
 template <int DT, int KT>
 __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
-    constexpr int DP = 16 * DT, KP = 16 * KT, DS = 4 * DT, KS = 4 * KT, LD = DP + 2;
+    constexpr int DP = 16 * DT, DS = 4 * DT, KS = 4 * KT, LD = DP + 2;
     // <A> and <C> are MFMA operands straight from global memory (L2-resident, 32 KB each): keeping them in
     // LDS too would put the workgroup over half of the CU's 160 KB and halve the occupancy of a kernel
     // that is all latency.  Zero padded by the accessors.
     __shared__ double P[DP * LD];        // posterior precision -> covariance
     __shared__ double W[DP * LD];        // work
-    __shared__ double qbar[64], rbar[64], rowp[64], colp[64], vec[64], gjbuf[768 + 192];
+    __shared__ double qbar[64], rbar[64], rowp[64], colp[64], gjbuf[768 + 192];
     const int n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
     const int wave = tid >> 6, lane = tid & 63, tj = tid & 63, ti = tid >> 6;
     const Layout& L = a.L;
@@ -270,71 +270,56 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
             if (i < D && tj < D) a.Sigma[((size_t)n * 3 + c) * D * D + i * D + tj] = sig[c][u];
         }
 
-    const int order[3] = {0, 2, 1};
-    for (int oi = 0; oi < 3; ++oi) {
-        const int cls = order[oi];
+    // the boundary classes are used as they are (one matrix-vector chain per sweep, k_sweep.hip): Sigma_0,
+    // Sigma_2, the noise expectations and L0 m0 go into the block
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            if (c == cls) {
+    for (int u = 0; u < NU; ++u) {
+        const int i = ti + 4 * u;
+        if (i < DP && tj < DP) {
+            g[L.oS0 + (size_t)i * DP + tj] = (i < D && tj < D) ? sig[0][u] : 0.0;
+            g[L.oS2 + (size_t)i * DP + tj] = (i < D && tj < D) ? sig[2][u] : 0.0;
+        }
+    }
+    if (tid < 64) { g[L.oqr + tid] = qbar[tid]; g[L.oqr + 64 + tid] = rbar[tid]; }
+    if (tid < DP) {      // L0 m0: the Constant mean parent of X_0 through its Constant precision
+        double s = 0.0;
+        if (tid < D) for (int j = 0; j < D; ++j) s += a.x0_prec[tid * D + j] * a.x0_mean[j];
+        g[L.ow0 + tid] = s;
+    }
+    // gains of the interior class
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int i = ti + 4 * u;
-                    if (i < D && tj < D) P[i * LD + tj] = sig[c][u];
-                }
-            }
-        __syncthreads();
-
-        // gains of this class
-        double* FT = g + (cls == 1 ? L.oFT : L.oFLT);
-        double* BT = g + (cls == 1 ? L.oBT : L.oB0T);
-        double* GT = g + (cls == 1 ? L.oGT : (cls == 0 ? L.oG0T : L.oGLT));
-        if (!(a.skip & 1)) {
-        if (cls != 0)       // Sigma <Q><A>: multiplies the mean of X_{t-1}
-            mm<DT, DT, DS>(wave, lane,
-                           [&](int i, int k) { return P[i * LD + k]; },
-                           [&](int k, int j) { return qbar[k] * A_at(k, j); },
-                           [&](int i, int j, double v) {
-                               if (i < D && j < D) {
-                                   FT[(size_t)j * DP + i] = v;
-                                   if (cls == 1) { g[L.oFn + pos_nat(i, j, DS)] = v; W[i * LD + j] = v; }
-                               }
-                           });
-        if (cls != 2)       // Sigma <A>^T<Q>: multiplies the mean of X_{t+1}
-            mm<DT, DT, DS>(wave, lane,
-                           [&](int i, int k) { return P[i * LD + k]; },
-                           [&](int k, int j) { return A_at(j, k) * qbar[j]; },
-                           [&](int i, int j, double v) {
-                               if (i < D && j < D) {
-                                   BT[(size_t)j * DP + i] = v;
-                                   if (cls == 1) { g[L.oBn + pos_nat(i, j, DS)] = v; }
-                               }
-                           });
+    for (int u = 0; u < NU; ++u) {
+        const int i = ti + 4 * u;
+        if (i < D && tj < D) P[i * LD + tj] = sig[1][u];
+    }
+    __syncthreads();
+    if (!(a.skip & 1)) {
+        double* FT = g + L.oFT;
+        double* BT = g + L.oBT;
+        double* GT = g + L.oGT;
+        // Sigma <Q><A>: multiplies the mean of X_{t-1}
+        mm<DT, DT, DS>(wave, lane,
+                       [&](int i, int k) { return P[i * LD + k]; },
+                       [&](int k, int j) { return qbar[k] * A_at(k, j); },
+                       [&](int i, int j, double v) {
+                           if (i < D && j < D) { FT[(size_t)j * DP + i] = v; g[L.oFn + pos_nat(i, j, DS)] = v; W[i * LD + j] = v; }
+                       });
+        // Sigma <A>^T<Q>: multiplies the mean of X_{t+1}
+        mm<DT, DT, DS>(wave, lane,
+                       [&](int i, int k) { return P[i * LD + k]; },
+                       [&](int k, int j) { return A_at(j, k) * qbar[j]; },
+                       [&](int i, int j, double v) {
+                           if (i < D && j < D) { BT[(size_t)j * DP + i] = v; g[L.oBn + pos_nat(i, j, DS)] = v; }
+                       });
         // Sigma <C>^T<R>: multiplies y_t
         mm<DT, KT, DS>(wave, lane,
                        [&](int i, int k) { return P[i * LD + k]; },
                        [&](int k, int l) { return C_at(l, k) * rbar[l]; },
                        [&](int i, int l, double v) {
-                           if (i < D && l < K) {
-                               GT[(size_t)l * DP + i] = v;
-                               if (cls == 1) g[L.oGp + pos_perm(i, l, KS)] = v;
-                           }
+                           if (i < D && l < K) { GT[(size_t)l * DP + i] = v; g[L.oGp + pos_perm(i, l, KS)] = v; }
                        });
-        }
-        if (cls == 0) {     // h0 = Sigma_0 (L0 m0): the Constant mean parent of X_0
-            if (tid < D) {
-                double s = 0.0;
-                for (int j = 0; j < D; ++j) s += a.x0_prec[tid * D + j] * a.x0_mean[j];
-                vec[tid] = s;
-            }
-            __syncthreads();
-            if (tid < D) {
-                double s = 0.0;
-                for (int k = 0; k < D; ++k) s += P[tid * LD + k] * vec[k];
-                g[L.oh0 + tid] = s;
-            }
-        }
-        __syncthreads();
     }
+    __syncthreads();
 
     // warm-up lengths of the segmented sweeps.  W holds F (forward recurrence matrix); the backward
     // one, B, is read back transposed (powers of B^T in the inf-norm = powers of B in the 1-norm).

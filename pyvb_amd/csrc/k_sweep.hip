@@ -19,6 +19,7 @@
 
 struct SweepArgs {
     const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
+    const double *A_mean, *C_mean;      // the boundary nodes read <A>, <C> themselves
     double* trash;      // [N][256]: where lanes of inactive columns aim their (unconditional) stores
     double* U;          // [N][T][DP]: c_t = F mu_{t-1} + G y_t of the interior nodes, in accumulator order (see MODE)
     int N, T, D, K, dir;
@@ -27,6 +28,39 @@ struct SweepArgs {
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// Xs[0].update() / Xs[T-1].update() (Gaussian.update gaussian.py:102-123 with the messages of
+// Multiplication.pass_up_m1_m2 / pass_down_Ex, node.py:182-242), lane = row, one wavefront:
+//   t = 0   : v = L0 m0 + <A>^T<Q> mu_1 + <C>^T<R> y_0         mu_0     = Sigma_0 v
+//   t = T-1 : v = <Q><A> mu_{T-2}       + <C>^T<R> y_{T-1}     mu_{T-1} = Sigma_2 v
+// i.e. qmu = qcov (sum of the m2 messages), as the reference has it.  nb(j) is entry j of the one
+// neighbour's mean, vs 64 doubles of LDS.
+template <class NB>
+__device__ __forceinline__ double boundary_update(bool first, const double* g, const Layout& L, const double* Am, const double* Cm,
+                                                  int D, int K, int lane, NB nb, const double* y, double* vs) {
+    const double* qb = g + L.oqr;
+    const double* rb = qb + 64;
+    double v = 0.0;
+    if (lane < D) {
+        if (first) {
+            v = g[L.ow0 + lane];
+            for (int i = 0; i < D; ++i) v += Am[(size_t)i * D + lane] * (qb[i] * nb(i));
+        } else {
+            double s = 0.0;
+            for (int j = 0; j < D; ++j) s += Am[(size_t)lane * D + j] * nb(j);
+            v = qb[lane] * s;
+        }
+        for (int k = 0; k < K; ++k) v += Cm[(size_t)k * D + lane] * (rb[k] * y[k]);
+    }
+    vs[lane] = v;
+    __syncthreads();
+    const double* S = g + (first ? L.oS0 : L.oS2);
+    double s = 0.0;
+    if (lane < D)
+        for (int j = 0; j < D; ++j) s += S[(size_t)j * L.DP + lane] * vs[j];      // Sigma is symmetric
+    __syncthreads();
+    return s;
+}
 
 // FULL: D == 16*DT and K == 16*KT (no padded rows/columns, 16-byte aligned rows)
 // MODE: the parameters are frozen between the two sweeps of an iteration, and the backward update
@@ -42,6 +76,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     constexpr int DS = 4 * DT, KS = 4 * KT, DP = 16 * DT;
     __shared__ double gl[MODE == 2 ? 64 : DT * KS * 64];     // G as MFMA A operands
     __shared__ double xs[64];               // boundary state exchange
+    __shared__ double vs[64];               // boundary_update scratch
     const int n = blockIdx.x, lane = threadIdx.x, c = lane & 15, q = lane >> 4;
     const int T = a.T, D = a.D, K = a.K;
     const bool fwd = (a.dir == 0);
@@ -72,14 +107,12 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
 
     // ---- first boundary node (t = 0 forward, T-1 backward): only the old neighbour
     const int t_first = fwd ? 0 : T - 1, t_last = fwd ? T - 1 : 0;
+    const double* Am = a.A_mean + (size_t)n * D * D;
+    const double* Cm = a.C_mean + (size_t)n * K * D;
     {
-        const double* E1 = g + (fwd ? L.oB0T : L.oFLT);
-        const double* G1 = g + (fwd ? L.oG0T : L.oGLT);
         const double* xo = Xo + (size_t)(t_first + sgn) * DP;
-        const double* y = Yn + (size_t)t_first * K;
-        double s = fwd ? g[L.oh0 + lane % DP] : 0.0;
-        for (int j = 0; j < D; ++j) s += E1[j * DP + lane % DP] * xo[xpos(j)];
-        for (int k = 0; k < K; ++k) s += G1[k * DP + lane % DP] * y[k];
+        const double s = boundary_update(fwd, g, L, Am, Cm, D, K, lane, [&](int j) { return xo[xpos(j)]; },
+                                         Yn + (size_t)t_first * K, vs);
         if (lane < DP) Xn[(size_t)t_first * DP + xpos(lane)] = (lane < D) ? s : 0.0;
         xs[lane] = (lane < D) ? s : 0.0;
     }
@@ -256,19 +289,15 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
 
     // ---- closing boundary node (t = T-1 forward, 0 backward): only the new neighbour
     {
-        const double* E2 = g + (fwd ? L.oFLT : L.oB0T);
-        const double* G2 = g + (fwd ? L.oGLT : L.oG0T);
-        const double* y = Yn + (size_t)t_last * K;
-        double s = fwd ? 0.0 : g[L.oh0 + lane % DP];
-        for (int j = 0; j < D; ++j) s += E2[j * DP + lane % DP] * xs[j];
-        for (int k = 0; k < K; ++k) s += G2[k * DP + lane % DP] * y[k];
+        const double s = boundary_update(!fwd, g, L, Am, Cm, D, K, lane, [&](int j) { return xs[j]; },
+                                         Yn + (size_t)t_last * K, vs);
         if (lane < DP) Xn[(size_t)t_last * DP + xpos(lane)] = (lane < D) ? s : 0.0;
     }
 }
 
 // Xs[t].update() alone, in place in the current buffer (neighbours as they are now).
 struct StepArgs {
-    double* X; const double* Y; const double* gains;
+    double* X; const double* Y; const double* gains; const double *A_mean, *C_mean;
     int N, T, D, K, t;
     Layout L;
 };
@@ -281,13 +310,21 @@ __global__ void __launch_bounds__(64) k_step(StepArgs a) {
     double* X = a.X + (size_t)n * T * DP;
     const double* y = a.Y + ((size_t)n * T + t) * K;
     const int cls = (t == 0) ? 0 : (t == T - 1 ? 2 : 1);
-    const double* FT = g + (cls == 1 ? L.oFT : L.oFLT);
-    const double* BT = g + (cls == 1 ? L.oBT : L.oB0T);
-    const double* GT = g + (cls == 1 ? L.oGT : (cls == 0 ? L.oG0T : L.oGLT));
     const int row = lane % DP;
-    double s = (cls == 0) ? g[L.oh0 + row] : 0.0;
-    if (t > 0) for (int j = 0; j < D; ++j) s += FT[j * DP + row] * X[(size_t)(t - 1) * DP + xpos(j)];
-    if (t < T - 1) for (int j = 0; j < D; ++j) s += BT[j * DP + row] * X[(size_t)(t + 1) * DP + xpos(j)];
+    if (cls != 1) {
+        __shared__ double vs[64];
+        const double* nbr = X + (size_t)(cls == 0 ? 1 : T - 2) * DP;
+        const double s = boundary_update(cls == 0, g, L, a.A_mean + (size_t)n * D * D, a.C_mean + (size_t)n * K * D, D, K, lane,
+                                         [&](int j) { return nbr[xpos(j)]; }, y, vs);
+        if (lane < DP) X[(size_t)t * DP + xpos(lane)] = (lane < D) ? s : 0.0;
+        return;
+    }
+    const double* FT = g + L.oFT;
+    const double* BT = g + L.oBT;
+    const double* GT = g + L.oGT;
+    double s = 0.0;
+    for (int j = 0; j < D; ++j) s += FT[j * DP + row] * X[(size_t)(t - 1) * DP + xpos(j)];
+    for (int j = 0; j < D; ++j) s += BT[j * DP + row] * X[(size_t)(t + 1) * DP + xpos(j)];
     for (int k = 0; k < K; ++k) s += GT[k * DP + row] * y[k];
     if (lane < DP) X[(size_t)t * DP + xpos(lane)] = (lane < D) ? s : 0.0;
 }
@@ -307,7 +344,7 @@ int launch_sweep(pyvb_lds* h, int direction, bool keep_x) {
     SweepArgs a;
     a.keep_x = (keep_x || direction != PYVB_FORWARD) ? 1 : 0;
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
-    a.trash = h->trash; a.U = h->U;
+    a.trash = h->trash; a.U = h->U; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
     {
         TimedLaunch tl(h, PYVB_K_SWEEP);
@@ -350,7 +387,7 @@ int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal)
 
 int launch_step(pyvb_lds* h, int t) {
     StepArgs a;
-    a.X = h->X[h->cur]; a.Y = h->Y; a.gains = h->gains;
+    a.X = h->X[h->cur]; a.Y = h->Y; a.gains = h->gains; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.t = t; a.L = h->L;
     TimedLaunch tl(h, PYVB_K_STEP);
     hipLaunchKernelGGL(k_step, dim3(h->N), dim3(64), 0, h->stream, a);
