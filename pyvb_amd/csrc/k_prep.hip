@@ -59,62 +59,76 @@ __device__ __forceinline__ void mm(int wave, int lane, FA a_at, FB b_at, FS stor
 }
 
 // Inverses of NP symmetric positive definite D x D matrices at once, by Gauss-Jordan elimination
-// without pivoting, entirely in registers: thread (ti = tid/64, tj = tid%64) owns elements
-// (ti + 4u, tj), u < 4*DT, of every matrix.  Step p of each:  P_ij -= P_ip P_pj / piv  off row and
-// column p, row p *= 1/piv, column p *= -1/piv, pivot -> 1/piv.  The general update is one FMA per
-// element; row p and column p are then overwritten by the few threads that own them.  Row p+1 and
-// column p+1 are stashed into double-buffered LDS vectors as they are produced, so a step costs one
-// barrier, and the NP independent eliminations interleave to cover its latency.
-// rc: scratch [NP][2][128] + pivots [NP][64].  On return v holds the inverses and pivs the pivots,
+// without pivoting, entirely in registers.  Thread (a = tid/16, b = tid%16) owns the 4 x 4 tile of
+// elements (4a + ra, 4b + cb) of every matrix (padded to 64 x 64 with the identity), v[c][4 ra + cb].
+// Step p of each:  P_ij -= P_ip P_pj / piv  off row and column p, row p *= 1/piv, column p *= -1/piv,
+// pivot -> 1/piv.  A thread needs 4 entries of column p and 4 of row p per step (two 32-byte LDS reads
+// each); the loop over p is unrolled by four so that which of its rows / columns is the pivot one is
+// a compile-time index.  Row p+1, column p+1 and the reciprocal of the next pivot (computed once, by the
+// thread that owns it) are stashed into double-buffered LDS vectors as they are produced, so a step
+// costs one barrier, and the NP independent eliminations interleave to cover its latency.
+// rc: scratch [NP][2][GJ_BUF], pivs [NP][64].  On return v holds the inverses and pivs the pivots,
 // whose logs sum to 2 * sum log diag(chol(P)).
-template <int DT, int NP>
-__device__ static void gj_inverse(double (&v)[NP][4 * DT], int D, int tid, double* rc, double* pivs) {
-    constexpr int NU = 4 * DT;
-    const int tj = tid & 63, ti = tid >> 6;
+#define GJ_BUF 136      // row (64), column (64), 1/pivot, padding
+template <int NP>
+__device__ static void gj_inverse(double (&v)[NP][16], int D, int tid, double* rc, double* pivs) {
+    const int a = tid >> 4, b = tid & 15;
 #pragma unroll
-    for (int c = 0; c < NP; ++c)
+    for (int c = 0; c < NP; ++c) {
+        double* row = rc + (c * 2) * GJ_BUF;
+        if (a == 0) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int i = ti + 4 * u;
-            if (i == 0) rc[c * 256 + tj] = v[c][u];              // row 0
-            if (tj == 0) rc[c * 256 + 64 + i] = v[c][u];         // column 0
+            for (int cb = 0; cb < 4; ++cb) row[4 * b + cb] = v[c][cb];           // row 0
         }
+        if (b == 0) {
+#pragma unroll
+            for (int ra = 0; ra < 4; ++ra) row[64 + 4 * a + ra] = v[c][4 * ra];  // column 0
+        }
+        if (tid == 0) row[128] = 1.0 / v[c][0];
+    }
     int cur = 0;
-    for (int p = 0; p < D; ++p) {
-        __syncthreads();
-        const int u0 = p >> 2, t0 = p & 3, u1 = (p + 1) >> 2, t1 = (p + 1) & 3;     // wave-uniform
+    for (int P = 0; 4 * P < D; ++P) {
 #pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            const double* row = rc + c * 256 + cur * 128;
-            const double* col = row + 64;
-            double* nrow = rc + c * 256 + (cur ^ 1) * 128;
-            double* ncol = nrow + 64;
-            const double piv = row[p];
-            if (tid == 0) pivs[c * 64 + p] = piv;
-            const double d = 1.0 / piv;
-            const double rj = row[tj] * d;
+        for (int pp = 0; pp < 4; ++pp) {
+            const int p = 4 * P + pp;
+            if (p >= D) break;                                  // block-uniform
+            const int P1 = (pp == 3) ? P + 1 : P, q1 = (pp + 1) & 3;    // where row / column p + 1 live
+            __syncthreads();
 #pragma unroll
-            for (int u = 0; u < NU; ++u) v[c][u] -= col[ti + 4 * u] * rj;
-            if (tj == p) {                              // column p (4 threads)
+            for (int c = 0; c < NP; ++c) {
+                const double* row = rc + (c * 2 + cur) * GJ_BUF;
+                const double* col = row + 64;
+                double* nrow = rc + (c * 2 + (cur ^ 1)) * GJ_BUF;
+                double* ncol = nrow + 64;
+                const double d = row[128];
+                if (tid == 0) pivs[c * 64 + p] = row[p];
+                double rj[4], ci[4];
 #pragma unroll
-                for (int u = 0; u < NU; ++u) v[c][u] = -col[ti + 4 * u] * d;
+                for (int k = 0; k < 4; ++k) { rj[k] = row[4 * b + k] * d; ci[k] = col[4 * a + k]; }
+#pragma unroll
+                for (int ra = 0; ra < 4; ++ra)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) v[c][4 * ra + cb] -= ci[ra] * rj[cb];
+                if (b == P) {                                   // column p
+#pragma unroll
+                    for (int ra = 0; ra < 4; ++ra) v[c][4 * ra + pp] = -ci[ra] * d;
+                }
+                if (a == P) {                                   // row p
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) v[c][4 * pp + cb] = (b == P && cb == pp) ? d : rj[cb];
+                }
+                if (a == P1) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) nrow[4 * b + cb] = v[c][4 * q1 + cb];
+                }
+                if (b == P1) {
+#pragma unroll
+                    for (int ra = 0; ra < 4; ++ra) ncol[4 * a + ra] = v[c][4 * ra + q1];
+                }
+                if (a == P1 && b == P1) nrow[128] = 1.0 / v[c][4 * q1 + q1];
             }
-            if (ti == t0) {                             // row p (one wavefront)
-#pragma unroll
-                for (int u = 0; u < NU; ++u)
-                    if (u == u0) v[c][u] = (tj == p) ? d : rj;
-            }
-            if (tj == p + 1) {
-#pragma unroll
-                for (int u = 0; u < NU; ++u) ncol[ti + 4 * u] = v[c][u];
-            }
-            if (ti == t1) {
-#pragma unroll
-                for (int u = 0; u < NU; ++u)
-                    if (u == u1) nrow[tj] = v[c][u];
-            }
+            cur ^= 1;
         }
-        cur ^= 1;
     }
     __syncthreads();
 }
@@ -190,9 +204,9 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     // that is all latency.  Zero padded by the accessors.
     __shared__ double P[DP * LD];        // posterior precision -> covariance
     __shared__ double W[DP * LD];        // work
-    __shared__ double qbar[64], rbar[64], rowp[64], colp[64], gjbuf[768 + 192];
+    __shared__ double qbar[64], rbar[64], rowp[64], colp[64], gjbuf[3 * 2 * GJ_BUF + 192];
     const int n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
-    const int wave = tid >> 6, lane = tid & 63, tj = tid & 63, ti = tid >> 6;
+    const int wave = tid >> 6, lane = tid & 63;
     const Layout& L = a.L;
     const double* Am = a.A_mean + (size_t)n * D * D;
     const double* Av = a.A_var + (size_t)n * D * D;
@@ -233,27 +247,29 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
 
     // the three posterior precisions, qprec = pprec + (m1 from Mult(C,.) + m1 from Mult(A,.))  gaussian.py:117,
     // inverted together in registers (qcov, gaussian.py:118-119)
-    constexpr int NU = 4 * DT;
-    double sig[3][NU];
+    double sig[3][16];
+    const int ta = tid >> 4, tb = tid & 15;                         // owner of the 4 x 4 tile (4 ta + ra, 4 tb + cb)
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int i = ti + 4 * u;
-        const bool in = i < D && tj < D;
-        const double mc = in ? W[i * LD + tj] : 0.0, mac = in ? P[i * LD + tj] : 0.0;
-        const double qd = (in && i == tj) ? qbar[i] : 0.0;
-        const double pad = (!in && i == tj) ? 1.0 : 0.0;            // identity in the padding keeps pivots finite
-        sig[0][u] = (in ? a.x0_prec[i * D + tj] : 0.0) + mac + pad;
-        sig[1][u] = qd + mac + pad;
-        sig[2][u] = qd + mc + pad;
-    }
+    for (int ra = 0; ra < 4; ++ra)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int i = 4 * ta + ra, j = 4 * tb + cb, u = 4 * ra + cb;
+            const bool in = i < D && j < D;
+            const double mc = in ? W[i * LD + j] : 0.0, mac = in ? P[i * LD + j] : 0.0;
+            const double qd = (in && i == j) ? qbar[i] : 0.0;
+            const double pad = (!in && i == j) ? 1.0 : 0.0;         // identity in the padding keeps pivots finite
+            sig[0][u] = (in ? a.x0_prec[i * D + j] : 0.0) + mac + pad;
+            sig[1][u] = qd + mac + pad;
+            sig[2][u] = qd + mc + pad;
+        }
     __syncthreads();
-    if (!(a.skip & 2)) gj_inverse<DT, 3>(sig, D, tid, gjbuf, gjbuf + 768);
+    if (!(a.skip & 2)) gj_inverse<3>(sig, D, tid, gjbuf, gjbuf + 3 * 2 * GJ_BUF);
     if (tid < 64) {                                                 // q_ln_det, gaussian.py:120 (quirk Q1)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             double lp = 0.0;
             if (tid < D) {
-                const double piv = gjbuf[768 + c * 64 + tid];
+                const double piv = gjbuf[3 * 2 * GJ_BUF + c * 64 + tid];
                 if (!(piv > 0.0)) atomicOr(a.status, 1);
                 lp = log(piv);
             }
@@ -265,19 +281,28 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int i = ti + 4 * u;
-            if (i < D && tj < D) a.Sigma[((size_t)n * 3 + c) * D * D + i * D + tj] = sig[c][u];
-        }
+        for (int ra = 0; ra < 4; ++ra)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int i = 4 * ta + ra, j = 4 * tb + cb;
+                if (i < D && j < D) a.Sigma[((size_t)n * 3 + c) * D * D + i * D + j] = sig[c][4 * ra + cb];
+            }
 
     // the boundary classes are used as they are (one matrix-vector chain per sweep, k_sweep.hip): Sigma_0,
     // Sigma_2, the noise expectations and L0 m0 go into the block
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int i = ti + 4 * u;
-        if (i < DP && tj < DP) {
-            g[L.oS0 + (size_t)i * DP + tj] = (i < D && tj < D) ? sig[0][u] : 0.0;
-            g[L.oS2 + (size_t)i * DP + tj] = (i < D && tj < D) ? sig[2][u] : 0.0;
+    for (int ra = 0; ra < 4; ++ra) {
+        const int i = 4 * ta + ra, j0 = 4 * tb;
+        if (i < DP && j0 < DP) {
+            d4 s0, s2;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const bool in = i < D && j0 + cb < D;
+                s0[cb] = in ? sig[0][4 * ra + cb] : 0.0;
+                s2[cb] = in ? sig[2][4 * ra + cb] : 0.0;
+            }
+            *reinterpret_cast<d4*>(g + L.oS0 + (size_t)i * DP + j0) = s0;
+            *reinterpret_cast<d4*>(g + L.oS2 + (size_t)i * DP + j0) = s2;
         }
     }
     if (tid < 64) { g[L.oqr + tid] = qbar[tid]; g[L.oqr + 64 + tid] = rbar[tid]; }
@@ -288,10 +313,12 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     }
     // gains of the interior class
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int i = ti + 4 * u;
-        if (i < D && tj < D) P[i * LD + tj] = sig[1][u];
-    }
+    for (int ra = 0; ra < 4; ++ra)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int i = 4 * ta + ra, j = 4 * tb + cb;
+            if (i < D && j < D) P[i * LD + j] = sig[1][4 * ra + cb];
+        }
     __syncthreads();
     if (!(a.skip & 1)) {
         double* FT = g + L.oFT;
