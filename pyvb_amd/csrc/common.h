@@ -18,11 +18,11 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // "n"/"p" blocks are laid out as v_mfma_f64_16x16x4 A-operands: element [(m*S+s)*64+lane]
 // = M[16m + (lane&15)][kidx(s, lane>>4)], kidx natural = 4s+q (F, B: they meet states, which come in
 // accumulator order), permuted = 8(s>>1)+2q+(s&1) (G: it meets rows of Y read 16 bytes per lane).
-// "T" blocks are transposed plain matrices [col][DP] for the lane-per-row scalar code.
+// (pos_nat / pos_perm below give the position of element (i, j) in such a block.)
 struct Layout {
     int D, K, DT, KT, DP, KP, DS, KS;
     size_t oFn, oBn, oGp;
-    size_t oFT, oBT, oGT, oS0, oS2, oqr, ow0;
+    size_t oS0, oS2, oqr, ow0;
     size_t gains_total;     // doubles per replicate
     size_t stats_total;     // doubles per replicate per chunk: Sxx[DP][DP], Sx1x[DP][DP], Syx[KP][DP]
     size_t oSxx, oSx1x, oSyx;
@@ -33,6 +33,15 @@ struct Layout {
 // v_mfma_f64_16x16x4 accumulator -- and also its B operand of k-step 4m + r.  A lane therefore moves
 // four contiguous doubles per tile, for the state stores as well as for the neighbour loads.
 __host__ __device__ static inline int xpos(int d) { return (d & ~15) | ((d & 3) << 2) | ((d >> 2) & 3); }
+
+// position of matrix element (i, j) in an MFMA A-operand block with S k-steps
+__host__ __device__ static inline size_t pos_nat(int i, int j, int S) {
+    return ((size_t)((i >> 4) * S + (j >> 2)) * 64) + (j & 3) * 16 + (i & 15);
+}
+__host__ __device__ static inline size_t pos_perm(int i, int j, int S) {
+    int s = 2 * (j >> 3) + (j & 1), q = (j & 7) >> 1;
+    return ((size_t)((i >> 4) * S + s) * 64) + q * 16 + (i & 15);
+}
 
 static inline int tiles16(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : 4); }
 
@@ -46,7 +55,6 @@ static inline Layout make_layout(int D, int K) {
     size_t dd = (size_t)L.DT * L.DS * 64, dk = (size_t)L.DT * L.KS * 64;
     L.oFn = o; o += dd; L.oBn = o; o += dd; L.oGp = o; o += dk;
     size_t tdd = (size_t)L.DP * L.DP, tkd = (size_t)L.KP * L.DP;
-    L.oFT = o; o += tdd; L.oBT = o; o += tdd; L.oGT = o; o += tkd;
     L.oS0 = o; o += tdd; L.oS2 = o; o += tdd; L.oqr = o; o += 128; L.ow0 = o; o += L.DP;
     L.gains_total = o;
     L.oSxx = 0; L.oSx1x = tdd; L.oSyx = 2 * tdd;

@@ -26,15 +26,6 @@ struct PrepArgs {
 #define PREP_THREADS 256
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-// position of matrix element (i, j) in an MFMA A-operand block with S k-steps (see common.h)
-__device__ __forceinline__ size_t pos_nat(int i, int j, int S) {
-    return ((size_t)((i >> 4) * S + (j >> 2)) * 64) + (j & 3) * 16 + (i & 15);
-}
-__device__ __forceinline__ size_t pos_perm(int i, int j, int S) {
-    int s = 2 * (j >> 3) + (j & 1), q = (j & 7) >> 1;
-    return ((size_t)((i >> 4) * S + s) * 64) + q * 16 + (i & 15);
-}
-
 // C = A * B on the matrix cores: C is [16*MT x 16*NT], the contraction runs over 4*KS.
 // a_at(i, k) / b_at(k, j) fetch operand elements (from LDS), store(i, j, v) consumes results.
 // Wavefront w owns row tiles w, w+4, ...
@@ -321,29 +312,26 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
         }
     __syncthreads();
     if (!(a.skip & 1)) {
-        double* FT = g + L.oFT;
-        double* BT = g + L.oBT;
-        double* GT = g + L.oGT;
         // Sigma <Q><A>: multiplies the mean of X_{t-1}
         mm<DT, DT, DS>(wave, lane,
                        [&](int i, int k) { return P[i * LD + k]; },
                        [&](int k, int j) { return qbar[k] * A_at(k, j); },
                        [&](int i, int j, double v) {
-                           if (i < D && j < D) { FT[(size_t)j * DP + i] = v; g[L.oFn + pos_nat(i, j, DS)] = v; W[i * LD + j] = v; }
+                           if (i < D && j < D) { g[L.oFn + pos_nat(i, j, DS)] = v; W[i * LD + j] = v; }
                        });
         // Sigma <A>^T<Q>: multiplies the mean of X_{t+1}
         mm<DT, DT, DS>(wave, lane,
                        [&](int i, int k) { return P[i * LD + k]; },
                        [&](int k, int j) { return A_at(j, k) * qbar[j]; },
                        [&](int i, int j, double v) {
-                           if (i < D && j < D) { BT[(size_t)j * DP + i] = v; g[L.oBn + pos_nat(i, j, DS)] = v; }
+                           if (i < D && j < D) g[L.oBn + pos_nat(i, j, DS)] = v;
                        });
         // Sigma <C>^T<R>: multiplies y_t
         mm<DT, KT, DS>(wave, lane,
                        [&](int i, int k) { return P[i * LD + k]; },
                        [&](int k, int l) { return C_at(l, k) * rbar[l]; },
                        [&](int i, int l, double v) {
-                           if (i < D && l < K) { GT[(size_t)l * DP + i] = v; g[L.oGp + pos_perm(i, l, KS)] = v; }
+                           if (i < D && l < K) g[L.oGp + pos_perm(i, l, KS)] = v;
                        });
     }
     __syncthreads();
@@ -356,7 +344,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     __syncthreads();
     for (int idx = tid; idx < DP * LD; idx += PREP_THREADS) {
         const int i = idx / LD, j = idx % LD;
-        W[idx] = (i < D && j < D) ? g[L.oBT + (size_t)i * DP + j] : 0.0;
+        W[idx] = (i < D && j < D) ? g[L.oBn + pos_nat(j, i, DS)] : 0.0;       // B^T
     }
     __syncthreads();
     J = warmup_length<DT>(W, P, LD, D, tid, rowp);

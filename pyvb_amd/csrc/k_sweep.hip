@@ -319,13 +319,12 @@ __global__ void __launch_bounds__(64) k_step(StepArgs a) {
         if (lane < DP) X[(size_t)t * DP + xpos(lane)] = (lane < D) ? s : 0.0;
         return;
     }
-    const double* FT = g + L.oFT;
-    const double* BT = g + L.oBT;
-    const double* GT = g + L.oGT;
+    // interior node: rows of F, B, G picked out of the MFMA operand blocks (this is the rare path)
+    const int DS = L.DS, KS = L.KS;
     double s = 0.0;
-    for (int j = 0; j < D; ++j) s += FT[j * DP + row] * X[(size_t)(t - 1) * DP + xpos(j)];
-    for (int j = 0; j < D; ++j) s += BT[j * DP + row] * X[(size_t)(t + 1) * DP + xpos(j)];
-    for (int k = 0; k < K; ++k) s += GT[k * DP + row] * y[k];
+    for (int j = 0; j < D; ++j) s += g[L.oFn + pos_nat(row, j, DS)] * X[(size_t)(t - 1) * DP + xpos(j)];
+    for (int j = 0; j < D; ++j) s += g[L.oBn + pos_nat(row, j, DS)] * X[(size_t)(t + 1) * DP + xpos(j)];
+    for (int k = 0; k < K; ++k) s += g[L.oGp + pos_perm(row, k, KS)] * y[k];
     if (lane < DP) X[(size_t)t * DP + xpos(lane)] = (lane < D) ? s : 0.0;
 }
 
