@@ -13,13 +13,12 @@
 // place by Gauss-Jordan elimination without pivoting (they are symmetric positive definite); its
 // pivots are the squares of the Cholesky diagonal, which gives the reference's q_ln_det.
 #include "common.h"
-#include <cstdlib>
 
 struct PrepArgs {
     const double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *x0_mean, *x0_prec;
     double *Sigma, *qld, *gains, *scratch;
     int *warm, *status;
-    int N, T, D, K, skip;   // skip: debug bits (1 = products of the classes, 2 = inversion, 4 = warm-up powers); results are then invalid
+    int N, T, D, K;
     Layout L;
 };
 
@@ -254,7 +253,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
             sig[2][u] = qd + mc + pad;
         }
     __syncthreads();
-    if (!(a.skip & 2)) gj_inverse<3>(sig, D, tid, gjbuf, gjbuf + 3 * 2 * GJ_BUF);
+    gj_inverse<3>(sig, D, tid, gjbuf, gjbuf + 3 * 2 * GJ_BUF);
     if (tid < 64) {                                                 // q_ln_det, gaussian.py:120 (quirk Q1)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -311,7 +310,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
             if (i < D && j < D) P[i * LD + j] = sig[1][4 * ra + cb];
         }
     __syncthreads();
-    if (!(a.skip & 1)) {
+    {
         // Sigma <Q><A>: multiplies the mean of X_{t-1}
         mm<DT, DT, DS>(wave, lane,
                        [&](int i, int k) { return P[i * LD + k]; },
@@ -338,7 +337,6 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
 
     // warm-up lengths of the segmented sweeps.  W holds F (forward recurrence matrix); the backward
     // one, B, is read back transposed (powers of B^T in the inf-norm = powers of B in the 1-norm).
-    if (a.skip & 4) { if (tid == 0) { a.warm[n * 2] = 48; a.warm[n * 2 + 1] = 48; } return; }
     int J = warmup_length<DT>(W, P, LD, D, tid, rowp);
     if (tid == 0) a.warm[n * 2 + 0] = J;
     __syncthreads();
@@ -364,7 +362,6 @@ int launch_prep(pyvb_lds* h) {
     a.Sigma = h->Sigma_new; a.qld = h->qld_x_new; a.gains = h->gains; a.scratch = h->scratch;
     a.warm = h->warm; a.status = h->status;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.L = h->L;
-    { const char* e = getenv("PYVB_PREP_SKIP"); a.skip = e ? atoi(e) : 0; }
     {
         TimedLaunch tl(h, PYVB_K_PREP);
         switch (h->L.DT * 10 + h->L.KT) {
