@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
     const int lr = live ? lane : 0;                 // clamped row for the per-lane loads
     const int lc = lane < D ? lane : D - 1;         // clamped column for the coalesced row loads
     const bool vec = (D & 3) == 0;
-    const int nb = (D + 15) >> 4, ns = (D + 3) >> 2;
+    const int nb = (D + 15) >> 4;
     const double* Mrow = M + (size_t)lr * D;
     const double* Hrow = H + (size_t)lr * D;
 
@@ -91,8 +91,9 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
         d4 acc[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
+        // all 16 k-steps whatever D is: Mb and Gb are zero beyond it, and a fixed trip count unrolls
 #pragma unroll 4
-        for (int s = 0; s < ns; ++s) {
+        for (int s = 0; s < 16; ++s) {
             const double bop = Gb[c * GS + 4 * s + q];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA(Mb[(4 * s + q) * MS + 16 * rt + c], bop, acc[rt]);
