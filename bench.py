@@ -173,6 +173,9 @@ def main():
                 # the backward launch reuses c_t = F mu_{t-1} + G y_t of the forward one and executes a third of
                 # its algorithmic FLOPs: executed / algorithmic over a forward+backward pair
                 "executed_over_algorithmic_flops": (3.0 + 1.0) / 6.0,
+                # ... and uses its idle matrix pipe for Sxx = sum_t mu_t mu_t^T, 10 of the 42 statistics tiles, which are
+                # NOT counted in `achieved` (algorithmic FLOPs of the fused part per backward launch, for reference):
+                "fused_statistics_flops_per_backward_launch": float(N) * T * 2 * D * D,
                 "hbm_algorithmic_GBs": bytes_per_launch / (mean_ms * 1e-3) / 1e9 if sweep_n else 0.0}
 
     if rank == 0:

@@ -117,6 +117,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     h->nchunk = nchunk; h->chunk_len = clen;
     TRY(dev_alloc(&h->stats, n * nchunk * L.stats_total));
     TRY(dev_alloc(&h->mom, n * ((size_t)3 * D * D + (size_t)K * D + D)));
+    TRY(dev_alloc(&h->sxx, n * (size_t)L.DP * L.DP));
     TRY(dev_alloc(&h->resQ, n * D)); TRY(dev_alloc(&h->resR, n * K));
     TRY(dev_alloc(&h->elbo, n * 6)); TRY(dev_alloc(&h->elbo_sum, 8));
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int)));
@@ -154,7 +155,7 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     pyvb_lds_comm_destroy(h);
     double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
-                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->U};
+                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->sxx, h->U};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
     if (h->status) (void)hipFree(h->status);
@@ -294,7 +295,7 @@ int pyvb_lds_set_state(pyvb_lds* h, const double* X, const double* A_mean, const
     if ((rc = h2d(h, h->Q_b, Q_b, N * D))) return rc;
     if ((rc = h2d(h, h->R_b, R_b, N * K))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (X) { states_changed(h); h->u_valid = false; }
+    if (X) { states_changed(h); h->u_valid = false; h->sxx_valid = false; }
     if (A_mean || A_colvar || C_mean || C_colvar || Q_b || R_b) { params_changed(h); h->resQ_valid = h->resR_valid = false; }
     return PYVB_OK;
 }
@@ -379,9 +380,9 @@ static int ensure_stats(pyvb_lds* h) {
                        h->fresh_count, h->T);
         return PYVB_E_STALE;
     }
-    int rc = launch_stats(h);
+    int rc = launch_stats(h, !h->sxx_valid);
     if (rc) return rc;
-    if ((rc = launch_moments(h))) return rc;
+    if ((rc = launch_moments(h, h->sxx_valid))) return rc;
     h->stats_valid = true;
     return PYVB_OK;
 }
@@ -418,6 +419,7 @@ int pyvb_lds_update_x(pyvb_lds* h, int t) {
     if (rc) return rc;
     if ((rc = launch_step(h, t))) return rc;
     h->u_valid = false;
+    h->sxx_valid = false;
     if (!h->fresh[t]) {
         h->fresh[t] = 1;
         if (++h->fresh_count == h->T) { adopt_classes(h); h->mixed_cov = false; }

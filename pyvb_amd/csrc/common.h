@@ -97,6 +97,7 @@ struct pyvb_lds {
     double *trash;                  // [N][256] dump rows for masked-out stores of the sweep
     double *U; bool u_valid;        // [N][T][DP] c_t = F mu_{t-1} + G y_t written by the forward sweep for the backward one that follows it
     double *stats; int nchunk, chunk_len;   // [N][nchunk][L.stats_total]
+    double *sxx; bool sxx_valid;    // [N][DP][DP] interior sum of mu mu^T from the backward sweep (valid while X is that sweep's result)
     double *mom;                    // [N][3 D^2 + K D + D] second moments (k_moments)
     double *resQ, *resR;            // [N][D], [N][K]
     double *elbo, *elbo_sum;        // [N][6], [6]
@@ -115,8 +116,8 @@ int launch_sweep(pyvb_lds* h, int direction, bool keep_x = true);
 int launch_step(pyvb_lds* h, int t);
 int launch_syy(pyvb_lds* h);
 int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal);
-int launch_stats(pyvb_lds* h);
-int launch_moments(pyvb_lds* h);
+int launch_stats(pyvb_lds* h, bool with_sxx);   // with_sxx = false: Sxx comes from the backward sweep (h->sxx)
+int launch_moments(pyvb_lds* h, bool sxx_from_sweep);
 int launch_observe(pyvb_lds* h);
 int launch_cols(pyvb_lds* h, int which, int c0, int c1, int fuse = 0);   // which: 0 = A, 1 = C, 2 = both; columns [c0, c1); fuse: see k_cols.hip
 int launch_resid(pyvb_lds* h, int which);     // 0 = Q, 1 = R

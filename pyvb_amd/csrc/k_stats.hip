@@ -27,9 +27,10 @@ struct StatsArgs {
 // (Syx tiles counted row tile by row tile), NA chosen to give both the same number of MFMAs (21 / 21 at
 // D = K = 64).  Both read the same rows at about the same time (a barrier per PF k-steps keeps them
 // together), so the second read of a row is an L1 hit.
-template <int DT, int KT>
+// XX = false: Sxx is not computed here (the backward sweep has it, k_sweep.hip MODE 2): 16 + 16 tiles.
+template <int DT, int KT, bool XX>
 struct StatsSplit {
-    static constexpr int NXX = DT * (DT + 1) / 2, NYX = KT * DT, TOTAL = NXX + DT * DT + NYX;
+    static constexpr int NXX = XX ? DT * (DT + 1) / 2 : 0, NYX = KT * DT, TOTAL = NXX + DT * DT + NYX;
     static constexpr int NA_RAW = (TOTAL + 1) / 2 - NXX;
     static constexpr int NA = NA_RAW < 0 ? 0 : (NA_RAW > NYX ? NYX : NA_RAW);     // Syx tiles of wave 0
     static constexpr int MA = (NA + DT - 1) / DT;       // wave 0 needs y row tiles [0, MA)
@@ -43,10 +44,10 @@ struct StatsSplit {
 #define STATS_PF 1      // k-steps per half of the operand ring (registers: 2 * PF * 10 doubles next to 168 of accumulators)
 #endif
 
-template <int DT, int KT>
+template <int DT, int KT, bool XX>
 __global__ void __launch_bounds__(128, STATS_OCC) k_stats(StatsArgs a) {
     constexpr int DP = 16 * DT, PF = STATS_PF;
-    using SP = StatsSplit<DT, KT>;
+    using SP = StatsSplit<DT, KT, XX>;
     constexpr int NA = SP::NA, MA = SP::MA, MB0 = SP::MB0, MB = KT - MB0;
     const int ch = blockIdx.x, n = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int T = a.T, K = a.K;
@@ -122,12 +123,14 @@ __global__ void __launch_bounds__(128, STATS_OCC) k_stats(StatsArgs a) {
             for (int h = 0; h < 2; ++h) {
                 // tile by tile, the PF k-steps of a tile back to back: a chain of dependent MFMAs on one
                 // accumulator runs faster than the same MFMAs spread over many (profiles/r01/microbench_f64.txt)
+                if constexpr (XX) {
 #pragma unroll
-                for (int m = 0; m < DT; ++m)
+                    for (int m = 0; m < DT; ++m)
 #pragma unroll
-                    for (int k = m; k < DT; ++k)
+                        for (int k = m; k < DT; ++k)
 #pragma unroll
-                        for (int p = 0; p < PF; ++p) sxx[m][k] = MFMA(xr[h][p][m], xr[h][p][k], sxx[m][k]);
+                            for (int p = 0; p < PF; ++p) sxx[m][k] = MFMA(xr[h][p][m], xr[h][p][k], sxx[m][k]);
+                }
 #pragma unroll
                 for (int m = 0; m < MA; ++m)
 #pragma unroll
@@ -142,10 +145,12 @@ __global__ void __launch_bounds__(128, STATS_OCC) k_stats(StatsArgs a) {
             }
             __builtin_amdgcn_s_barrier();     // lock-step only (L1 reuse between the two waves): no fence, the loads in flight stay in flight
         }
+        if constexpr (XX) {
 #pragma unroll
-        for (int m = 0; m < DT; ++m)
+            for (int m = 0; m < DT; ++m)
 #pragma unroll
-            for (int k = m; k < DT; ++k) store_tile(a.L.oSxx, m, k, sxx[m][k], k > m);
+                for (int k = m; k < DT; ++k) store_tile(a.L.oSxx, m, k, sxx[m][k], k > m);
+        }
 #pragma unroll
         for (int m = 0; m < MA; ++m)
 #pragma unroll
@@ -240,26 +245,27 @@ __global__ void __launch_bounds__(256) k_syy(SyyArgs a) {
 }
 
 template <int DT, int KT>
-static void launch_stats_t(pyvb_lds* h, const StatsArgs& a) {
-    hipLaunchKernelGGL((k_stats<DT, KT>), dim3(h->nchunk, h->N), dim3(128), 0, h->stream, a);
+static void launch_stats_t(pyvb_lds* h, const StatsArgs& a, bool with_sxx) {
+    if (with_sxx) hipLaunchKernelGGL((k_stats<DT, KT, true>), dim3(h->nchunk, h->N), dim3(128), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_stats<DT, KT, false>), dim3(h->nchunk, h->N), dim3(128), 0, h->stream, a);
 }
 
-int launch_stats(pyvb_lds* h) {
+int launch_stats(pyvb_lds* h, bool with_sxx) {
     StatsArgs a;
     a.X = h->X[h->cur]; a.Y = h->Y; a.part = h->stats; a.zeros = h->zeros;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.nchunk = h->nchunk; a.chunk_len = h->chunk_len; a.L = h->L;
     {
         TimedLaunch tl(h, PYVB_K_STATS);
         switch (h->L.DT * 10 + h->L.KT) {
-            case 11: launch_stats_t<1, 1>(h, a); break;
-            case 12: launch_stats_t<1, 2>(h, a); break;
-            case 14: launch_stats_t<1, 4>(h, a); break;
-            case 21: launch_stats_t<2, 1>(h, a); break;
-            case 22: launch_stats_t<2, 2>(h, a); break;
-            case 24: launch_stats_t<2, 4>(h, a); break;
-            case 41: launch_stats_t<4, 1>(h, a); break;
-            case 42: launch_stats_t<4, 2>(h, a); break;
-            case 44: launch_stats_t<4, 4>(h, a); break;
+            case 11: launch_stats_t<1, 1>(h, a, with_sxx); break;
+            case 12: launch_stats_t<1, 2>(h, a, with_sxx); break;
+            case 14: launch_stats_t<1, 4>(h, a, with_sxx); break;
+            case 21: launch_stats_t<2, 1>(h, a, with_sxx); break;
+            case 22: launch_stats_t<2, 2>(h, a, with_sxx); break;
+            case 24: launch_stats_t<2, 4>(h, a, with_sxx); break;
+            case 41: launch_stats_t<4, 1>(h, a, with_sxx); break;
+            case 42: launch_stats_t<4, 2>(h, a, with_sxx); break;
+            case 44: launch_stats_t<4, 4>(h, a, with_sxx); break;
             default: pyvb_set_error("unsupported tile shape"); return PYVB_E_ARG;
         }
     }

@@ -22,6 +22,7 @@ struct SweepArgs {
     const double *A_mean, *C_mean;      // the boundary nodes read <A>, <C> themselves
     double* trash;      // [N][256]: where lanes of inactive columns aim their (unconditional) stores
     double* U;          // [N][T][DP]: c_t = F mu_{t-1} + G y_t of the interior nodes, in accumulator order (see MODE)
+    double* Sxx;        // [N][DP][DP]: sum over the interior nodes of mu_t mu_t^T, written by the MODE 2 sweep
     int N, T, D, K, dir;
     int keep_x;         // 0: the sweep that follows reads only c_t and the rows next to the far boundary, so the interior rows of Xnew are not written
     Layout L;
@@ -74,7 +75,7 @@ __device__ __forceinline__ double boundary_update(bool first, const double* g, c
 template <int DT, int KT, bool FULL, int MODE>
 __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     constexpr int DS = 4 * DT, KS = 4 * KT, DP = 16 * DT;
-    __shared__ double gl[MODE == 2 ? 64 : DT * KS * 64];     // G as MFMA A operands
+    __shared__ double gl[MODE == 2 ? DP * 17 : DT * KS * 64];     // G as MFMA A operands; MODE 2: the state tile, transposed (below)
     __shared__ double xs[64];               // boundary state exchange
     __shared__ double vs[64];               // boundary_update scratch
     const int n = blockIdx.x, lane = threadIdx.x, c = lane & 15, q = lane >> 4;
@@ -196,12 +197,41 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
             // PF loop steps (see below).
             constexpr int PF = 3;
             d4 ub[PF][DT];
+            // The matrix pipe is idle about half of the time here (the sweep waits for HBM), so the sweep
+            // also forms Sxx = sum_t mu_t mu_t^T over the interior nodes, which k_stats then does not have
+            // to.  The 16 columns of a step are 16 time points: the sum over them is a product with the
+            // time index as the MFMA k dimension, X X^T with X = [DP x 16].  Its operands want lane = row,
+            // the state has lane = column: the tile goes through LDS (tl[row][17]: written in accumulator
+            // order, read back in operand order one step later, while the step's own MFMAs run).
+            double* const tl = gl;
+            for (int i = lane; i < DP * 17; i += 64) tl[i] = 0.0;
+            d4 sxx[DT][DT];
+#pragma unroll
+            for (int m = 0; m < DT; ++m)
+#pragma unroll
+                for (int k = 0; k < DT; ++k) sxx[m][k] = d4{0.0, 0.0, 0.0, 0.0};
+            auto tile_read = [&](double (*xt)[4]) {
+#pragma unroll
+                for (int m = 0; m < DT; ++m)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) xt[m][s4] = tl[(16 * m + c) * 17 + 4 * s4 + q];       // row 16m + lane%16, column 4 s + lane/16
+            };
+            auto tile_accumulate = [&](double (*xt)[4]) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int m = 0; m < DT; ++m)
+#pragma unroll
+                        for (int k = m; k < DT; ++k) sxx[m][k] = MFMA(xt[m][s4], xt[k][s4], sxx[m][k]);
+            };
 #pragma unroll
             for (int p = 0; p < PF; ++p) { load_u(jstart + p, ub[p]); store_x(trash + 64 * p); }
             for (int j = jstart; j < Lseg; j += PF) {
 #pragma unroll
                 for (int p = 0; p < PF; ++p) {
                     d4 acc[DT];
+                    double xt[DT][4];
+                    tile_read(xt);                      // the previous step's states
 #pragma unroll
                     for (int m = 0; m < DT; ++m) acc[m] = ub[p][m];
                     __builtin_amdgcn_sched_barrier(0);
@@ -212,9 +242,31 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                     for (int s = 0; s < DS; ++s)
 #pragma unroll
                         for (int m = 0; m < DT; ++m) acc[m] = MFMA(rn[m][s], x[s >> 2][s & 3], acc[m]);
+                    tile_accumulate(xt);
                     finish_step(j + p, acc);
+                    const bool keep = active(j + p) && j + p >= 0;      // warm-up steps and idle columns do not count
+#pragma unroll
+                    for (int m = 0; m < DT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tl[(16 * m + 4 * r + q) * 17 + c] = keep ? x[m][r] : 0.0;
                 }
             }
+            {
+                double xt[DT][4];
+                tile_read(xt);
+                tile_accumulate(xt);
+            }
+            double* Sn = a.Sxx + (size_t)n * DP * DP;
+#pragma unroll
+            for (int m = 0; m < DT; ++m)
+#pragma unroll
+                for (int k = m; k < DT; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = 16 * m + 4 * e + q, col = 16 * k + c;     // accumulator element (row, col)
+                        Sn[(size_t)row * DP + col] = sxx[m][k][e];
+                        if (k > m) Sn[(size_t)col * DP + row] = sxx[m][k][e];
+                    }
         } else {
         // Prologue: the same sequence of vector-memory operations as one loop iteration (loads, stores
         // -- into the trash row -- , loads), so that the compiler's in-order vmcnt bookkeeping at the
@@ -343,7 +395,7 @@ int launch_sweep(pyvb_lds* h, int direction, bool keep_x) {
     SweepArgs a;
     a.keep_x = (keep_x || direction != PYVB_FORWARD) ? 1 : 0;
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
-    a.trash = h->trash; a.U = h->U; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
+    a.trash = h->trash; a.U = h->U; a.Sxx = h->sxx; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
     {
         TimedLaunch tl(h, PYVB_K_SWEEP);
@@ -363,6 +415,7 @@ int launch_sweep(pyvb_lds* h, int direction, bool keep_x) {
     HIPCHK(hipGetLastError());
     h->cur = 1 - h->cur;
     // U holds c_t for the current gains and for THIS forward result; any other change of X drops it
+    h->sxx_valid = direction == PYVB_BACKWARD && h->u_valid;     // that launch was the MODE 2 kernel: h->sxx is Sxx of the new states
     h->u_valid = (direction == PYVB_FORWARD);
     return PYVB_OK;
 }

@@ -8,6 +8,7 @@ struct ParamArgs {
     // statistics
     const double* part; int nchunk; const double* Sigma; const double* qld_x; const double* X; const double* Syy;
     double* mom;            // [N][mom_total]: see k_moments
+    const double* sxx;      // k_moments: [N][DP][DP] interior sum of mu mu^T from the backward sweep, or null (then from part)
     // parameters
     double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *qld_A, *qld_C;
     double *resQ, *resR, *elbo;
