@@ -177,6 +177,12 @@ def main():
                 # NOT counted in `achieved` (algorithmic FLOPs of the fused part per backward launch, for reference):
                 "fused_statistics_flops_per_backward_launch": float(N) * T * 2 * D * D,
                 "hbm_algorithmic_GBs": bytes_per_launch / (mean_ms * 1e-3) / 1e9 if sweep_n else 0.0}
+    # the whole iteration against the same peak: SURVEY.md section 8(d) work model (sweeps + statistics) over the wall time
+    # of a step -- independent of which kernel a piece of the work is fused into
+    iter_flops = float(N) * T * (12 * D * D + 6 * D * K + 2 * K)
+    roofline["iteration"] = {"algorithmic_flops": iter_flops, "achieved": iter_flops / (dt / args.steps) / 1e12,
+                             "frac": iter_flops / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             "algorithmic_bytes": float(N) * 16 * T * (K + 2 * D)}
 
     if rank == 0:
         cpu, rel = (None, None)
