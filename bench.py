@@ -113,6 +113,10 @@ def main():
     if world > 1:
         # the one collective of the data path: all-reduce of the 6 lower-bound parts, over RCCL inside the library
         uid, ok = None, 0.0
+        # one node: RCCL's bootstrap (sockets, not the data path) over loopback, like the rendezvous above --
+        # the container's hostname / outward interface may not be usable
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if rank == 0:
             try:
                 uid = LDSBatch.comm_unique_id()
