@@ -156,7 +156,7 @@ int pyvb_pca_set_data(pyvb_pca* h, const double* X) {
         HIPCHK(hipMemcpy(counts, h->elbo, sizeof(counts), hipMemcpyDeviceToHost));
     }
     h->n_part_missing = (long)counts[0]; h->n_none_rows = (long)counts[1]; h->n_part_rows = (long)counts[2];
-    h->full_valid = h->lin_valid = false;
+    h->full_valid = h->lin_valid = false; h->res_valid = false;
     return PYVB_OK;
 }
 
@@ -181,7 +181,7 @@ int pyvb_pca_set_state(pyvb_pca* h, const double* X_missing, const double* W_mea
     if ((rc = up(h, h->Mu_mean, Mu_mean, d))) return rc;
     if (beta_b) HIPCHK(hipMemcpyAsync(h->scal + PS_BETA_B, beta_b, sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->full_valid = h->lin_valid = false;
+    h->full_valid = h->lin_valid = false; h->res_valid = false;
     return PYVB_OK;
 }
 
@@ -231,6 +231,7 @@ int pyvb_pca_update_W(pyvb_pca* h) {
     ENTER(h);
     int rc = ensure_full(h);
     if (rc) return rc;
+    h->res_valid = false;
     return pca_launch_small(h, PCA_W);
 }
 
@@ -251,7 +252,7 @@ int pyvb_pca_update_Z(pyvb_pca* h) {
     if ((rc = pca_launch_reduce(h, 1))) return rc;
     HIPCHK(hipMemsetAsync(h->aux + (size_t)4 * h->nchunk * h->QP + h->QP, 0, h->DP * sizeof(double), h->stream));
     if ((rc = exchange_lin(h))) return rc;
-    h->full_valid = false; h->lin_valid = had_lin;
+    h->full_valid = false; h->lin_valid = had_lin; h->res_valid = false;
     return PYVB_OK;
 }
 
@@ -267,7 +268,7 @@ int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi) {
             HIPCHK(hipMemsetAsync(h->aux + (size_t)4 * h->nchunk * h->QP, 0, h->QP * sizeof(double), h->stream));
         if ((rc = pca_launch_small(h, PCA_X0))) return rc;
         if ((rc = exchange_lin(h))) return rc;
-        h->full_valid = false;
+        h->full_valid = false; h->res_valid = false;
         return PYVB_OK;
     }
     return full_stats(h, lo, hi);
@@ -277,6 +278,7 @@ int pyvb_pca_update_Mu(pyvb_pca* h) {
     ENTER(h);
     int rc;
     if (!h->lin_valid && (rc = ensure_full(h))) return rc;
+    h->res_valid = false;
     return pca_launch_small(h, PCA_MU);
 }
 
@@ -284,7 +286,9 @@ int pyvb_pca_update_Beta(pyvb_pca* h) {
     ENTER(h);
     int rc = ensure_full(h);
     if (rc) return rc;
-    return pca_launch_small(h, PCA_BETA);
+    if ((rc = pca_launch_small(h, PCA_BETA))) return rc;
+    h->res_valid = true;        // the residual does not depend on Beta: the lower bound can reuse it
+    return PYVB_OK;
 }
 
 int pyvb_pca_elbo(pyvb_pca* h, double parts[5]) {

@@ -25,6 +25,7 @@ struct PcaArgs {
     double* part; double* stats; double* aux; double* elbo; int* status;
     long N, N_total, chunk_rows, lo_upd, hi_upd, n_part_missing, n_none_rows, row_offset;
     int d, q, DP, QP, DT, QT, nchunk, mode;
+    int res_cached;     // PCA_ELBO: scal[PS_RES] holds the residual already
     PcaStatsLayout SL;
 };
 
@@ -267,8 +268,12 @@ __device__ static void wtw_lds(const PcaArgs& a, double* wtw) {
     for (int idx = threadIdx.x; idx < q * q; idx += 256) {
         const int i = idx / q, j = idx % q;
         double s = 0.0;
+#pragma unroll 8
         for (int k = 0; k < d; ++k) s += a.W_mean[(size_t)k * q + i] * a.W_mean[(size_t)k * q + j];
-        if (i == j) for (int k = 0; k < d; ++k) s += a.W_var[(size_t)i * d + k];
+        if (i == j) {
+#pragma unroll 8
+            for (int k = 0; k < d; ++k) s += a.W_var[(size_t)i * d + k];
+        }
         wtw[idx] = s;
     }
     __syncthreads();
@@ -309,24 +314,34 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         for (int idx = tid; idx < q * q; idx += 256) szz[idx] = S[a.SL.oSzz + (size_t)(idx / q) * QP + idx % q] + N * a.Z_cov[idx];
         __syncthreads();
         const int k = tid;
-        double w[64];
-        if (k < d) for (int i = 0; i < q; ++i) w[i] = a.W_mean[(size_t)k * q + i];
-        for (int i = 0; i < q; ++i) {
-            double lp = 0.0;
-            if (k < d) {
-                const double pp = a.W_pp[(size_t)i * d + k];
-                const double prec = pp + beta * szz[i * q + i];
-                double acc = 0.0;
-                for (int j = 0; j < q; ++j) acc += (j == i) ? 0.0 : szz[i * q + j] * w[j];
-                const double h = S[a.SL.oSxz + (size_t)k * QP + i] - a.Mu_mean[k] * S[a.SL.osz + i];
-                w[i] = (pp * a.W_pm[(size_t)k * q + i] + beta * (h - acc)) / prec;
-                a.W_var[(size_t)i * d + k] = 1.0 / prec;
-                lp = 0.5 * log(prec);
+        double w[32];                                       // q <= 32; constant indices keep the row in registers
+#pragma unroll
+        for (int i = 0; i < 32; ++i) w[i] = (k < d && i < q) ? a.W_mean[(size_t)k * q + (i < q ? i : 0)] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i < q) {                                    // block-uniform
+                double lp = 0.0;
+                if (k < d) {
+                    const double pp = a.W_pp[(size_t)i * d + k];
+                    const double prec = pp + beta * szz[i * q + i];
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 32; ++j)
+                        if (j != i && j < q) acc += szz[i * q + j] * w[j];
+                    const double h = S[a.SL.oSxz + (size_t)k * QP + i] - a.Mu_mean[k] * S[a.SL.osz + i];
+                    w[i] = (pp * a.W_pm[(size_t)k * q + i] + beta * (h - acc)) / prec;
+                    a.W_var[(size_t)i * d + k] = 1.0 / prec;
+                    lp = 0.5 * log(prec);
+                }
+                lp = bsum(lp, red);
+                if (tid == 0) a.qld_W[i] = 0.5 / lp;         // gaussian.py:120 (quirk Q1)
             }
-            lp = bsum(lp, red);
-            if (tid == 0) a.qld_W[i] = 0.5 / lp;             // gaussian.py:120 (quirk Q1)
         }
-        if (k < d) for (int i = 0; i < q; ++i) a.W_mean[(size_t)k * q + i] = w[i];
+        if (k < d) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (i < q) a.W_mean[(size_t)k * q + i] = w[i];
+        }
     } else if (a.mode == PCA_PREPZ) {
         // posterior of the Z_n: precision I + beta <W^T W>, shared by all n; Gz = beta Sigma_z <W>^T
         double* P = sm; double* Sg = sm + 64 * 64;
@@ -412,10 +427,15 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         // Beta.update(): Gamma, traces (nodes_todo.py:130-138)
         wtw_lds(a, sm);
         const double res = residual(a, sm, red);
-        if (tid == 0) a.scal[PS_BETA_B] = a.scal[PS_BETA_B0] + 0.5 * res;
+        if (tid == 0) { a.scal[PS_BETA_B] = a.scal[PS_BETA_B0] + 0.5 * res; a.scal[PS_RES] = res; }
     } else if (a.mode == PCA_ELBO) {
-        wtw_lds(a, sm);
-        const double res = residual(a, sm, red);
+        double res;
+        if (a.res_cached) {
+            res = a.scal[PS_RES];
+        } else {
+            wtw_lds(a, sm);
+            res = residual(a, sm, red);
+        }
         const double qa = a.scal[PS_BETA_A], qb = a.scal[PS_BETA_B];
         const double lnd_beta = d * (log(qa) - log(qb));                  // Gamma.pass_down_lndet (quirk Q2)
         // X_n (gaussian.py:136-151)
@@ -428,16 +448,18 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         tr = bsum(tr, red);
         const double LZ = N * (-0.5 * q * LN2PI) - 0.5 * tr + N * (0.5 * q * LN2PI + 0.5 * a.scal[PS_QLD_Z] + 0.5 * q);
         // W columns and Mu against their Constant parents
+        // one column after the other, thread = row (d <= 256): log and trace terms summed over the block
         double lw = 0.0;
-        if (tid < q) {
-            const int i = tid;
+        for (int i = 0; i < q; ++i) {
             double lndet = 0.0, t2 = 0.0;
-            for (int k = 0; k < d; ++k) {
+            if (tid < d) {
+                const int k = tid;
                 const double pp = a.W_pp[(size_t)i * d + k], w = a.W_mean[(size_t)k * q + i], pm = a.W_pm[(size_t)k * q + i];
-                lndet += log(pp);
-                t2 += pp * (w * w + a.W_var[(size_t)i * d + k] + pm * pm - 2.0 * w * pm);
+                lndet = log(pp);
+                t2 = pp * (w * w + a.W_var[(size_t)i * d + k] + pm * pm - 2.0 * w * pm);
             }
-            lw = -0.5 * d * LN2PI + 0.5 * lndet - 0.5 * t2 + 0.5 * d * LN2PI + 0.5 * a.qld_W[i] + 0.5 * d;
+            const double tot = bsum(0.5 * lndet - 0.5 * t2, red);
+            if (tid == 0) lw += -0.5 * d * LN2PI + tot + 0.5 * d * LN2PI + 0.5 * a.qld_W[i] + 0.5 * d;
         }
         const double LW = bsum(lw, red);
         double lm = 0.0;
@@ -466,6 +488,7 @@ static PcaArgs pca_args(pyvb_pca* h) {
     a.N = h->N; a.N_total = h->N_total; a.chunk_rows = h->chunk_rows; a.lo_upd = 0; a.hi_upd = 0;
     a.n_part_missing = h->n_part_missing; a.n_none_rows = h->n_none_rows; a.row_offset = h->row_offset;
     a.d = h->d; a.q = h->q; a.DP = h->DP; a.QP = h->QP; a.DT = h->DT; a.QT = h->QT; a.nchunk = h->nchunk; a.mode = 0; a.SL = h->SL;
+    a.res_cached = h->res_valid ? 1 : 0;
     return a;
 }
 

@@ -21,7 +21,7 @@ static inline PcaStatsLayout pca_stats_layout(int DP, int QP) {
 }
 
 // device scalars
-enum { PS_BETA_A = 0, PS_BETA_B, PS_QLD_Z, PS_QLD_X, PS_QLD_MU, PS_BETA_A0, PS_BETA_B0, PS_COUNT = 16 };
+enum { PS_BETA_A = 0, PS_BETA_B, PS_QLD_Z, PS_QLD_X, PS_QLD_MU, PS_BETA_A0, PS_BETA_B0, PS_RES, PS_COUNT = 16 };   // PS_RES: the residual of the last Beta update (see res_valid)
 
 struct pyvb_pca {
     int device; long N, N_total, row_offset; int d, q, DP, QP, DT, QT;
@@ -43,6 +43,7 @@ struct pyvb_pca {
     PcaStatsLayout SL;
     long n_part_missing, n_none_rows, n_part_rows;   // global counts (from the mask)
     bool full_valid, lin_valid;          // all statistics current / at least sum x and sum z current
+    bool res_valid;                      // scal[PS_RES] is the residual of the current W, Z, X, Mu (nothing but Beta updated since)
     void* comm; int rank, world;
 };
 
