@@ -117,7 +117,16 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     h->nchunk = nchunk; h->chunk_len = clen;
     TRY(dev_alloc(&h->stats, n * nchunk * L.stats_total));
     TRY(dev_alloc(&h->mom, n * ((size_t)3 * D * D + (size_t)K * D + D)));
-    TRY(dev_alloc(&h->sxx, n * (size_t)L.DP * L.DP));
+    // few replicates: the sweeps split the time axis over W wavefronts per replicate (k_sweep.hip), up to about one
+    // wavefront per SIMD on the chip and not below 256 interior nodes per wavefront
+    h->W = 1;
+    if (N < 512 && T - 2 >= 512) {
+        int wmax = 1024 / N, wlen = (T - 2) / 256;
+        h->W = wmax < wlen ? wmax : wlen;
+        if (h->W > 64) h->W = 64;
+        if (h->W < 1) h->W = 1;
+    }
+    TRY(dev_alloc(&h->sxx, n * (size_t)h->W * L.DP * L.DP));
     TRY(dev_alloc(&h->resQ, n * D)); TRY(dev_alloc(&h->resR, n * K));
     TRY(dev_alloc(&h->elbo, n * 6)); TRY(dev_alloc(&h->elbo_sum, 8));
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int)));

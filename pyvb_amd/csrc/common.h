@@ -97,7 +97,8 @@ struct pyvb_lds {
     double *trash;                  // [N][256] dump rows for masked-out stores of the sweep
     double *U; bool u_valid;        // [N][T][DP] c_t = F mu_{t-1} + G y_t written by the forward sweep for the backward one that follows it
     double *stats; int nchunk, chunk_len;   // [N][nchunk][L.stats_total]
-    double *sxx; bool sxx_valid;    // [N][DP][DP] interior sum of mu mu^T from the backward sweep (valid while X is that sweep's result)
+    int W;                          // wavefronts per replicate in the sweeps (time split; 1 unless N is small)
+    double *sxx; bool sxx_valid;    // [N][W][DP][DP] interior sum of mu mu^T from the backward sweep (valid while X is that sweep's result)
     double *mom;                    // [N][3 D^2 + K D + D] second moments (k_moments)
     double *resQ, *resR;            // [N][D], [N][K]
     double *elbo, *elbo_sum;        // [N][6], [6]

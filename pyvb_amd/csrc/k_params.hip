@@ -29,7 +29,10 @@ __global__ void __launch_bounds__(256) k_moments(ParamArgs a) {
             h += Pc[a.L.oSx1x + (size_t)i * DP + j];
         }
         // from the backward sweep: the interior nodes; the two boundary nodes are added here
-        if (a.sxx) xx = a.sxx[(size_t)n * DP * DP + (size_t)i * DP + j] + x0[xpos(i)] * x0[xpos(j)] + xL[xpos(i)] * xL[xpos(j)];
+        if (a.sxx) {
+            xx = x0[xpos(i)] * x0[xpos(j)] + xL[xpos(i)] * xL[xpos(j)];
+            for (int w = 0; w < a.W; ++w) xx += a.sxx[((size_t)n * a.W + w) * DP * DP + (size_t)i * DP + j];
+        }
         const double s0 = S[idx], s1 = S[D * D + idx], s2 = S[2 * D * D + idx];
         mo[MOM_GA(D, K) + idx] = xx - xL[xpos(i)] * xL[xpos(j)] + s0 + nint * s1;
         mo[MOM_GC(D, K) + idx] = xx + s0 + nint * s1 + s2;
@@ -205,7 +208,7 @@ ParamArgs make_args(pyvb_lds* h) {
     a.A_mean = h->A_mean; a.A_var = h->A_var; a.C_mean = h->C_mean; a.C_var = h->C_var;
     a.Q_a = h->Q_a; a.Q_b = h->Q_b; a.R_a = h->R_a; a.R_b = h->R_b; a.qld_A = h->qld_A; a.qld_C = h->qld_C;
     a.resQ = h->resQ; a.resR = h->resR; a.elbo = h->elbo; a.pri = h->pri;
-    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L; a.c0 = 0; a.c1 = h->D; a.which0 = 0; a.fuse = 0; a.sxx = nullptr;
+    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L; a.c0 = 0; a.c1 = h->D; a.which0 = 0; a.fuse = 0; a.sxx = nullptr; a.W = 1;
     return a;
 }
 
@@ -219,6 +222,7 @@ int launch_observe(pyvb_lds* h) {
 int launch_moments(pyvb_lds* h, bool sxx_from_sweep) {
     ParamArgs a = make_args(h);
     a.sxx = sxx_from_sweep ? h->sxx : nullptr;
+    a.W = h->W;
     TimedLaunch tl(h, PYVB_K_PARAMS);
     hipLaunchKernelGGL(k_moments, dim3(h->N), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());

@@ -24,6 +24,7 @@ struct SweepArgs {
     double* U;          // [N][T][DP]: c_t = F mu_{t-1} + G y_t of the interior nodes, in accumulator order (see MODE)
     double* Sxx;        // [N][DP][DP]: sum over the interior nodes of mu_t mu_t^T, written by the MODE 2 sweep
     int N, T, D, K, dir;
+    int W;              // wavefronts per replicate: each takes a contiguous part of the interior time range (grid.y)
     int keep_x;         // 0: the sweep that follows reads only c_t and the rows next to the far boundary, so the interior rows of Xnew are not written
     Layout L;
 };
@@ -72,13 +73,14 @@ __device__ __forceinline__ double boundary_update(bool first, const double* g, c
 // runs ONE product per step instead of three; MODE 0 computes everything and keeps nothing.
 // c rows are stored in accumulator order, [tile m][lane group q][register r], so a lane moves 32
 // contiguous bytes per tile.
-template <int DT, int KT, bool FULL, int MODE>
+// SPLIT: several wavefronts per replicate (a.W > 1, few replicates); without it the part offsets fold to constants.
+template <int DT, int KT, bool FULL, int MODE, bool SPLIT>
 __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     constexpr int DS = 4 * DT, KS = 4 * KT, DP = 16 * DT;
     __shared__ double gl[MODE == 2 ? DP * 17 : DT * KS * 64];     // G as MFMA A operands; MODE 2: the state tile, transposed (below)
     __shared__ double xs[64];               // boundary state exchange
     __shared__ double vs[64];               // boundary_update scratch
-    const int n = blockIdx.x, lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+    const int n = blockIdx.x, w = SPLIT ? blockIdx.y : 0, lane = threadIdx.x, c = lane & 15, q = lane >> 4;
     const int T = a.T, D = a.D, K = a.K;
     const bool fwd = (a.dir == 0);
     const int sgn = fwd ? 1 : -1;
@@ -106,40 +108,50 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
         }
     }
 
-    // ---- first boundary node (t = 0 forward, T-1 backward): only the old neighbour
+    // ---- the part of the interior this wavefront owns.  With few replicates the interior time range
+    // (nodes 1 .. T-2, counted from the side the sweep starts at) is dealt out to a.W wavefronts per
+    // replicate in contiguous parts of Lw nodes; every part is again cut into 16 segments.  All
+    // segments but those that reach the chain's first node within J steps warm up from zero.
+    const int Tint = T - 2;
+    const int Lw = SPLIT ? ((((Tint + a.W - 1) / a.W) + 15) & ~15) : Tint;
+    const int ow = SPLIT ? w * Lw : 0;                       // interior nodes before this part
+    const int Tw = (Tint - ow < Lw) ? Tint - ow : Lw;        // interior nodes of this part (<= 0: none)
+    const int J = a.warm[n * 2 + a.dir];
+
+    // ---- first boundary node (t = 0 forward, T-1 backward): only the old neighbour.  Every wavefront
+    // whose warm-up can reach it computes it; the first one stores it.
     const int t_first = fwd ? 0 : T - 1, t_last = fwd ? T - 1 : 0;
     const double* Am = a.A_mean + (size_t)n * D * D;
     const double* Cm = a.C_mean + (size_t)n * K * D;
-    {
+    if (!SPLIT || ow <= J) {
         const double* xo = Xo + (size_t)(t_first + sgn) * DP;
         const double s = boundary_update(fwd, g, L, Am, Cm, D, K, lane, [&](int j) { return xo[xpos(j)]; },
                                          Yn + (size_t)t_first * K, vs);
-        if (lane < DP) Xn[(size_t)t_first * DP + xpos(lane)] = (lane < D) ? s : 0.0;
+        if (w == 0 && lane < DP) Xn[(size_t)t_first * DP + xpos(lane)] = (lane < D) ? s : 0.0;
         xs[lane] = (lane < D) ? s : 0.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    // ---- interior: t = 1 .. T-2 in 16 segments
-    const int Tint = T - 2;
-    if (Tint > 0) {
-        const int Lseg = (Tint + 15) >> 4;
-        const int J = a.warm[n * 2 + a.dir];
+    // ---- interior: this part's nodes in 16 segments
+    if (Tw > 0) {
+        const int Lseg = (Tw + 15) >> 4;
         const int cL = c * Lseg;
-        const int jc = -(J < cL ? J : cL);                       // first loop index of this column
-        const int jstart = -((J < 15 * Lseg) ? J : 15 * Lseg);   // of the wave
+        const int before = ow + cL;                              // interior nodes between the chain's start and this column
+        const int jc = -(J < before ? J : before);               // first loop index of this column
+        const int jstart = -((J < ow + 15 * Lseg) ? J : ow + 15 * Lseg);   // of the wave (its last column starts earliest)
         // starting state: the true boundary value when the warm-up reaches it, else zero
         d4 x[DT];
 #pragma unroll
         for (int m = 0; m < DT; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[m][r] = (jc == -cL) ? xs[16 * m + 4 * r + q] : 0.0;
+            for (int r = 0; r < 4; ++r) x[m][r] = (jc == -before) ? xs[16 * m + 4 * r + q] : 0.0;
 
         // time index of this column at loop index j:  t = tbase + sgn * j
-        const int tbase = fwd ? (1 + cL) : (T - 2 - cL);
+        const int tbase = fwd ? (1 + before) : (T - 2 - before);
         const int tsafe = fwd ? 1 : T - 2;      // an interior row that always exists: what inactive columns read
-        auto active = [&](int j) { int tt = cL + j; return j >= jc && j < Lseg && tt < Tint; };
+        auto active = [&](int j) { int tt = cL + j; return j >= jc && j < Lseg && tt < Tw; };
         // input registers: y_t and the old neighbour mean, as B operands in permuted k order.
         // Loads are unconditional and unmasked: an inactive column reads a valid row and computes
         // a value that the select after the step discards (MFMA columns do not mix), and padded
@@ -188,7 +200,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
             for (int m = 0; m < DT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[m][r] = act ? acc[m][r] : x[m][r];
-            out_pending = (act && j >= 0 && (a.keep_x || cL + j == Tint - 1)) ? Xn + (size_t)(tbase + sgn * j) * DP : trash;
+            out_pending = (act && j >= 0 && (a.keep_x || before + j == Tint - 1)) ? Xn + (size_t)(tbase + sgn * j) * DP : trash;
         };
         if constexpr (MODE == 2) {
             // One product per step: the sweep is bound by the c_t stream, so c rows are fetched PF
@@ -256,7 +268,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                 tile_read(xt);
                 tile_accumulate(xt);
             }
-            double* Sn = a.Sxx + (size_t)n * DP * DP;
+            double* Sn = a.Sxx + ((size_t)n * (SPLIT ? a.W : 1) + w) * DP * DP;       // this wavefront's part of the sum (k_moments adds the parts)
 #pragma unroll
             for (int m = 0; m < DT; ++m)
 #pragma unroll
@@ -326,7 +338,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
         }
         store_x(out_pending);
         // the column that holds the last interior node hands its state to the closing boundary step
-        const int clast = (Tint - 1) / Lseg;
+        const int clast = (Tw - 1) / Lseg;
         __builtin_amdgcn_s_barrier();
         if (c == clast) {
 #pragma unroll
@@ -339,8 +351,9 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
-    // ---- closing boundary node (t = T-1 forward, 0 backward): only the new neighbour
-    {
+    // ---- closing boundary node (t = T-1 forward, 0 backward): only the new neighbour; done by the
+    // wavefront that owns the last interior node
+    if (!SPLIT || w == ((Tint > 0) ? (Tint - 1) / Lw : 0)) {
         const double s = boundary_update(!fwd, g, L, Am, Cm, D, K, lane, [&](int j) { return xs[j]; },
                                          Yn + (size_t)t_last * K, vs);
         if (lane < DP) Xn[(size_t)t_last * DP + xpos(lane)] = (lane < D) ? s : 0.0;
@@ -384,7 +397,8 @@ template <int DT, int KT>
 static int launch_sweep_t(pyvb_lds* h, const SweepArgs& a) {
     const bool full = h->D == 16 * DT && h->K == 16 * KT;
     const int mode = a.dir == PYVB_FORWARD ? 1 : (h->u_valid ? 2 : 0);
-#define PYVB_SWEEP_CASE(F, M) hipLaunchKernelGGL((k_sweep<DT, KT, F, M>), dim3(h->N), dim3(64), 0, h->stream, a)
+#define PYVB_SWEEP_CASE(F, M) do { if (h->W > 1) hipLaunchKernelGGL((k_sweep<DT, KT, F, M, true>), dim3(h->N, h->W), dim3(64), 0, h->stream, a); \
+                                   else hipLaunchKernelGGL((k_sweep<DT, KT, F, M, false>), dim3(h->N), dim3(64), 0, h->stream, a); } while (0)
     if (full) { if (mode == 1) PYVB_SWEEP_CASE(true, 1); else if (mode == 2) PYVB_SWEEP_CASE(true, 2); else PYVB_SWEEP_CASE(true, 0); }
     else { if (mode == 1) PYVB_SWEEP_CASE(false, 1); else if (mode == 2) PYVB_SWEEP_CASE(false, 2); else PYVB_SWEEP_CASE(false, 0); }
 #undef PYVB_SWEEP_CASE
@@ -394,6 +408,7 @@ static int launch_sweep_t(pyvb_lds* h, const SweepArgs& a) {
 int launch_sweep(pyvb_lds* h, int direction, bool keep_x) {
     SweepArgs a;
     a.keep_x = (keep_x || direction != PYVB_FORWARD) ? 1 : 0;
+    a.W = h->W;
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
     a.trash = h->trash; a.U = h->U; a.Sxx = h->sxx; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;

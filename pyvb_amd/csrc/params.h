@@ -8,7 +8,8 @@ struct ParamArgs {
     // statistics
     const double* part; int nchunk; const double* Sigma; const double* qld_x; const double* X; const double* Syy;
     double* mom;            // [N][mom_total]: see k_moments
-    const double* sxx;      // k_moments: [N][DP][DP] interior sum of mu mu^T from the backward sweep, or null (then from part)
+    const double* sxx;      // k_moments: [N][W][DP][DP] parts of the interior sum of mu mu^T from the backward sweep, or null (then from part)
+    int W;
     // parameters
     double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *qld_A, *qld_C;
     double *resQ, *resR, *elbo;

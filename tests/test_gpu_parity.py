@@ -317,6 +317,22 @@ def test_baseline_config2_single_long_chain():
     b.close()
 
 
+@pytest.mark.parametrize("T,D,K,N", [(600, 6, 4, 1), (777, 16, 16, 2), (1030, 33, 17, 3), (4099, 8, 8, 5), (2050, 64, 64, 1)])
+def test_time_split_over_wavefronts(T, D, K, N):
+    """Few replicates and a long chain: the sweeps deal the time axis out to several wavefronts per replicate
+    (ragged parts, parts without nodes, warm-up across part borders)."""
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=900 + T)
+    _stagewise(Y, st0, pri, iters=2)
+    b = _batch(Y, st0, pri)
+    st = O.expand_state(st0, pri, T)
+    for it in range(2):
+        parts = O.iterate(st, pri, Y)
+        b.iterate(1)
+    _close(b.get_state(("X",))["X"], st["X"], "X after iterate (time split)")
+    _close(b.elbo().sum(1), parts.sum(1), "elbo after iterate (time split)")
+    b.close()
+
+
 def test_rccl_communicator_single_rank():
     """The RCCL leg of pyvb_lds_elbo_total (dlopen of librccl, unique id, communicator, all-reduce on
     the handle's stream) with a one-rank communicator: the sum over ranks is the local sum."""
