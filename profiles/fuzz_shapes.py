@@ -13,7 +13,7 @@ worst = 0.0
 for case in range(ncase):
     D = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 50, 57, 63, 64]))
     K = int(rng.choice([1, 2, 5, 16, 17, 32, 33, 48, 49, 60, 64]))
-    T = int(rng.choice([2, 3, 4, 17, 18, 19, 33, 50, 97, 160, 257]))
+    T = int(rng.choice([2, 3, 4, 17, 18, 19, 33, 50, 97, 160, 257, 514, 600, 1111, 3000]))
     N = int(rng.choice([1, 2, 3]))
     noise = "gamma" if rng.random() < 0.25 else "diagonal_gamma"
     Y, st0, pri = synth.make_problem(T, D, K, N, seed=1000 + case)
