@@ -117,14 +117,18 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     h->nchunk = nchunk; h->chunk_len = clen;
     TRY(dev_alloc(&h->stats, n * nchunk * L.stats_total));
     TRY(dev_alloc(&h->mom, n * ((size_t)3 * D * D + (size_t)K * D + D)));
-    // few replicates: the sweeps split the time axis over W wavefronts per replicate (k_sweep.hip), up to about one
-    // wavefront per SIMD on the chip and not below 256 interior nodes per wavefront
+    // The sweeps may split the time axis over W wavefronts per replicate (k_sweep.hip).  A wavefront takes
+    // ceil(part/16) + J steps (J ~ 32 warm-up steps), the chip runs 1024 of them at a time: W minimises
+    // rounds x steps, with parts of at least 64 nodes.  At N >= 1024 that is W = 1.
     h->W = 1;
-    if (N < 512 && T - 2 >= 512) {
-        int wmax = 1024 / N, wlen = (T - 2) / 256;
-        h->W = wmax < wlen ? wmax : wlen;
-        if (h->W > 64) h->W = 64;
-        if (h->W < 1) h->W = 1;
+    {
+        const long Tint = T - 2;
+        double best = 1e300;
+        for (int W = 1; W <= 128 && (W == 1 || Tint / W >= 64); ++W) {
+            const long part = (((Tint + W - 1) / W) + 15) & ~15L;
+            const double cost = (double)(((long)N * W + 1023) / 1024) * (double)((part + 15) / 16 + 32);
+            if (cost < best * 0.97) { best = cost; h->W = W; }      // prefer fewer wavefronts unless clearly better
+        }
     }
     TRY(dev_alloc(&h->sxx, n * (size_t)h->W * L.DP * L.DP));
     TRY(dev_alloc(&h->resQ, n * D)); TRY(dev_alloc(&h->resR, n * K));

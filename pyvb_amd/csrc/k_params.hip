@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(256) k_moments(ParamArgs a) {
         // from the backward sweep: the interior nodes; the two boundary nodes are added here
         if (a.sxx) {
             xx = x0[xpos(i)] * x0[xpos(j)] + xL[xpos(i)] * xL[xpos(j)];
+#pragma unroll 8
             for (int w = 0; w < a.W; ++w) xx += a.sxx[((size_t)n * a.W + w) * DP * DP + (size_t)i * DP + j];
         }
         const double s0 = S[idx], s1 = S[D * D + idx], s2 = S[2 * D * D + idx];
