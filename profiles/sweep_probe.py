@@ -11,4 +11,4 @@ b.sweep("forward"); b.sweep("backward"); b.sync(); b.timing(True)
 for _ in range(3):
     b.sweep("forward"); b.sync(); f=b.kernel_times()["sweep"][0]
     b.sweep("backward"); b.sync(); t=b.kernel_times()["sweep"][0]
-    print(os.environ.get("PYVB_SWEEP_DBG","0"), "fwd %.3f ms  bwd %.3f ms (cumulative %.3f)" % (f - getattr(b,'_last',0.0), t - f, t)); b._last = t
+    print("fwd %.3f ms  bwd %.3f ms (cumulative %.3f)" % (f - getattr(b,'_last',0.0), t - f, t)); b._last = t
