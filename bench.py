@@ -46,24 +46,21 @@ def make_inputs(T, D, K, N, seed):
     return Y, st0, pri
 
 
-def cpu_baseline_and_parity(T, D, K, device):
-    """Oracle (numpy port of the reference's loop, oracle/lds_closed_form.py) timed on this host on
-    a bounded sample of the same workload, and the ELBO of the HIP path checked against it."""
+def cpu_baseline_and_parity(sample, pri, iters, got_elbo, got_X):
+    """Oracle (numpy port of the reference's loop, oracle/lds_closed_form.py) run on the first replicates OF THE
+    TIMED BATCH for the same number of iterations (warm-up + timed), timed on this host's cores: that is both the
+    CPU baseline (a bounded sample of the same workload) and the parity check of the numbers just timed."""
     from oracle import lds_closed_form as O
-    from pyvb_amd import synth
-    from pyvb_amd.lds import LDSBatch
-    n_s, iters = 4, 8        # about 12 s of numpy on the GPU box's host cores
-    Y, st0, pri = synth.make_problem(T, D, K, n_s, seed=99)
+    Y, st0 = sample
+    n_s, T, K = Y.shape
+    D = st0["A_mean"].shape[1]
     st = O.expand_state(st0, pri, T)
     t0 = time.perf_counter()
     for _ in range(iters):
         ref = O.iterate(st, pri, Y)
     cpu_s = time.perf_counter() - t0
-    b = LDSBatch.from_problem(Y, st0, pri, device=device)
-    b.iterate(iters)
-    got = b.elbo()
-    b.close()
-    rel = float(np.max(np.abs(got.sum(1) - ref.sum(1)) / np.abs(ref.sum(1))))
+    rel = float(np.max(np.abs(got_elbo[:n_s].sum(1) - ref.sum(1)) / np.abs(ref.sum(1))))
+    rel_x = float(np.abs(got_X[:n_s] - st["X"]).max() / np.abs(st["X"]).max())
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
@@ -74,9 +71,17 @@ def cpu_baseline_and_parity(T, D, K, device):
         "unit": "VB iterations/s per 1024 replicates",
         "cores": int(cores),
         "kind": "port",
-        "sample": "%d replicates x %d iterations at T=%d D=%d K=%d (%.1f s), scaled by replicates/1024" % (n_s, iters, T, D, K, cpu_s),
+        "sample": "replicates 0..%d of the timed batch x %d iterations at T=%d D=%d K=%d (%.1f s), scaled by replicates/1024"
+                  % (n_s - 1, iters, T, D, K, cpu_s),
     }
-    return base, rel
+    # the reference itself cannot run on the GPU box (Python 2 source, never shipped); its rate is measured in the build
+    # container by profiles/reference_cpu.py at the same D, K and a short chain, and extrapolated (cost is linear in T
+    # and in the number of replicates): reported next to the port, from the committed file
+    for tag in ("r02",):
+        path = os.path.join(REPO, "profiles", tag, "reference_cpu.json")
+        if os.path.exists(path):
+            base["reference_extrapolated"] = json.load(open(path))
+    return base, rel, rel_x
 
 
 def main():
@@ -89,6 +94,9 @@ def main():
     ap.add_argument("--D", type=int, default=64)
     ap.add_argument("--K", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-replicates", type=int, default=4, help="replicates of the timed batch re-run in the oracle")
+    ap.add_argument("--allow-gloo-fallback", action="store_true",
+                    help="if the RCCL communicator cannot be created, reduce the lower bound over gloo (marked degraded) instead of failing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,11 +116,15 @@ def main():
     _capi.check(_capi.lib.pyvb_device_count(_capi.ctypes.byref(ndev)))
     device = local_rank % max(ndev.value, 1)          # a launcher may already have narrowed the visible devices
     b = LDSBatch.from_problem(Y, st0, pri, device=device)
+    n_par = max(1, min(args.parity_replicates, N))
+    sample = (Y[:n_par].copy(), {k: v[:n_par].copy() for k, v in st0.items()})
     del Y
     collective = "none (1 GPU)"
+    degraded = False
+    use_rccl = False
     if world > 1:
         # the one collective of the data path: all-reduce of the 6 lower-bound parts, over RCCL inside the library
-        uid, ok = None, 0.0
+        uid, ok, why = None, 0.0, ""
         # one node: RCCL's bootstrap (sockets, not the data path) over loopback, like the rendezvous above --
         # the container's hostname / outward interface may not be usable
         if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
@@ -121,19 +133,28 @@ def main():
             try:
                 uid = LDSBatch.comm_unique_id()
             except Exception as e:
-                sys.stderr.write("rank 0: no RCCL unique id (%s)\n" % (e,))
+                why = "rank 0: no RCCL unique id (%s)" % (e,)
         uid = comm.broadcast_bytes(uid)
         if uid is not None:
             try:
                 b.comm_init(uid, rank, world)
                 ok = 1.0
-            except Exception as e:      # keep the run alive: the 48-byte reduction then goes over gloo, and the line says so
-                sys.stderr.write("rank %d: RCCL communicator failed (%s); reducing the lower bound over gloo\n" % (rank, e))
+            except Exception as e:
+                why = "rank %d: RCCL communicator failed (%s)" % (rank, e)
         ok = -comm.max_float(-ok)       # min over ranks
-        collective = "rccl allreduce(6 x f64) per step" if ok == 1.0 else "gloo allreduce(6 x f64) per step (RCCL init failed)"
         use_rccl = ok == 1.0
-    else:
-        use_rccl = False
+        if not use_rccl:
+            # a number taken with the lower bound going through host memory is not this design's data path:
+            # fail unless the caller asked for the fallback, and mark the line if so
+            if why:
+                sys.stderr.write(why + "\n")
+            if not args.allow_gloo_fallback:
+                b.close()
+                comm.close()
+                raise SystemExit("RCCL communicator could not be created on every rank (see stderr); "
+                                 "re-run with --allow-gloo-fallback for a degraded (gloo) measurement")
+            degraded = True
+        collective = "rccl allreduce(6 x f64) per step" if use_rccl else "gloo allreduce(6 x f64) per step (RCCL init failed: DEGRADED)"
 
     def step():
         b.iterate(1)
@@ -156,42 +177,83 @@ def main():
     kt = b.kernel_times()
     b.timing(False)
 
-    # roofline of the dominant kernel (the sweep): algorithmic fp64 flops per launch / mean launch time
-    sweep_ms, sweep_n = kt["sweep"]
-    flops_per_launch = float(N) * T * (4 * D * D + 2 * D * K)            # one sweep of N replicates
-    bytes_per_launch = float(N) * 8 * T * (K + 2 * D)
-    mean_ms = sweep_ms / max(sweep_n, 1)
-    achieved = flops_per_launch / (mean_ms * 1e-3) / 1e12 if sweep_n else 0.0
-    # HBM bytes per k_sweep launch from the PMC passes committed with this round's profiles
-    # (profiles/collect_traffic.sh: FETCH_SIZE x2 per the gfx950 correction, + WRITE_SIZE; mean of the two directions)
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "r01", "traffic_pmc.json")
-    if os.path.exists(tpath) and (N, T, D, K) == (1024, 10000, 64, 64):
-        tj = json.load(open(tpath))
-        vals = [v["hbm_bytes_per_launch"] for k, v in tj.items() if "k_sweep" in k]
-        traffic = sum(vals) / len(vals) if vals else None
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "kernel": "k_sweep", "launches": sweep_n, "mean_launch_ms": mean_ms,
-                # the backward launch reuses c_t = F mu_{t-1} + G y_t of the forward one and executes a third of
-                # its algorithmic FLOPs: executed / algorithmic over a forward+backward pair
-                "executed_over_algorithmic_flops": (3.0 + 1.0) / 6.0,
-                # ... and uses its idle matrix pipe for Sxx = sum_t mu_t mu_t^T, 10 of the 42 statistics tiles, which are
-                # NOT counted in `achieved` (algorithmic FLOPs of the fused part per backward launch, for reference):
-                "fused_statistics_flops_per_backward_launch": float(N) * T * 2 * D * D,
-                "hbm_algorithmic_GBs": bytes_per_launch / (mean_ms * 1e-3) / 1e9 if sweep_n else 0.0}
+    # ---- roofline, per kernel instantiation.  Work per launch (N replicates, T nodes; unit u = 2 D^2 flops per node):
+    #   forward sweep   k_sweep<..,1,..>: F mu_{t-1} + B mu_{t+1} + G y_t          executed = algorithmic = T (4 D^2 + 2 D K)
+    #   backward sweep  k_sweep<..,2,..>: B mu_{t+1} + c_t (c_t cached by the forward sweep) + the 10 upper tiles of Sxx
+    #                   executed = T (2 D^2 + Sxx share); algorithmic (a full sweep)   = T (4 D^2 + 2 D K)
+    #   statistics      k_stats<..,false>: Sx1x + Syx                              executed = T (2 D^2 + 2 D K)
+    #                   algorithmic (all statistics, a third of them done in the backward launch) = T (4 D^2 + 2 D K + 2 K)
+    # `achieved`/`frac` are EXECUTED flops over the mean launch time from HIP events on the handle's stream: they can
+    # not exceed the peak.  The contract figure for the whole iteration (SURVEY's algorithmic flops over the wall
+    # time of a step, whatever kernel a piece of work is fused into) is roofline.iteration.
+    DT = (D + 15) // 16
+    sxx_share = (DT * (DT + 1) / 2.0) / (DT * DT)           # symmetric: upper tiles only
+    nt = float(N) * T
+    work = {
+        "sweep_fwd": {"kernel": "k_sweep<%d, %d, %s, 1, false>" % (DT, (K + 15) // 16, "true" if (D % 16 == 0 and K % 16 == 0) else "false"),
+                      "executed_flops": nt * (4 * D * D + 2 * D * K), "algorithmic_flops": nt * (4 * D * D + 2 * D * K),
+                      "algorithmic_bytes": nt * 8 * (K + 2 * D)},
+        "sweep_bwd": {"kernel": "k_sweep<%d, %d, %s, 2, false>" % (DT, (K + 15) // 16, "true" if (D % 16 == 0 and K % 16 == 0) else "false"),
+                      "executed_flops": nt * (2 * D * D + sxx_share * 2 * D * D), "algorithmic_flops": nt * (4 * D * D + 2 * D * K),
+                      "algorithmic_bytes": nt * 8 * (K + 2 * D)},
+        "stats": {"kernel": "k_stats<%d, %d, false>" % (DT, (K + 15) // 16),
+                  "executed_flops": nt * (2 * D * D + 2 * D * K), "algorithmic_flops": nt * (4 * D * D + 2 * D * K + 2 * K),
+                  "algorithmic_bytes": 0.0},
+    }
+    # HBM bytes per launch: PMC passes over this workload, committed with the round's profiles (NOT measured in this run)
+    traffic, traffic_source = {}, None
+    if (N, T, D, K) == (1024, 10000, 64, 64):
+        for tag in ("r02", "r01"):
+            tpath = os.path.join(REPO, "profiles", tag, "traffic_pmc.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                for key, w in work.items():
+                    hit = [v["hbm_bytes_per_launch"] for k, v in tj.items() if w["kernel"].replace(" ", "") in k.replace(" ", "")]
+                    if hit:
+                        traffic[key] = hit[0]
+                traffic_source = "profiles/%s/traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; not measured in this run)" % tag
+                break
+    entries = {}
+    for key, w in work.items():
+        ms, cnt = kt[key]
+        if not cnt:
+            continue
+        mean_ms = ms / cnt
+        ex = w["executed_flops"] / (mean_ms * 1e-3) / 1e12
+        e = {"kernel": w["kernel"], "launches": cnt, "mean_launch_ms": mean_ms,
+             "executed_flops": w["executed_flops"], "algorithmic_flops": w["algorithmic_flops"],
+             "achieved": ex, "frac": ex / FP64_MFMA_PEAK_TFLOPS,
+             "algorithmic_TFLOPs": w["algorithmic_flops"] / (mean_ms * 1e-3) / 1e12,
+             "traffic": traffic.get(key)}
+        if traffic.get(key):
+            e["hbm_GBs_measured_traffic"] = traffic[key] / (mean_ms * 1e-3) / 1e9
+            e["hbm_frac"] = e["hbm_GBs_measured_traffic"] / HBM_PEAK_GBS
+        entries[key] = e
+    dom = entries.get("sweep_fwd", {})
+    roofline = {"bound": "mfma", "achieved": dom.get("achieved", 0.0), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": dom.get("frac", 0.0), "traffic": dom.get("traffic"), "traffic_source": traffic_source,
+                "kernel": dom.get("kernel"), "launches": dom.get("launches"), "mean_launch_ms": dom.get("mean_launch_ms"),
+                "algorithmic_flops_per_launch": work["sweep_fwd"]["algorithmic_flops"],
+                "algorithmic_bytes_per_launch": work["sweep_fwd"]["algorithmic_bytes"],
+                "secondary": {k: v for k, v in entries.items() if k != "sweep_fwd"}}
     # the whole iteration against the same peak: SURVEY.md section 8(d) work model (sweeps + statistics) over the wall time
-    # of a step -- independent of which kernel a piece of the work is fused into
+    # of a step -- independent of which kernel a piece of the work is fused into -- and the flops actually executed
     iter_flops = float(N) * T * (12 * D * D + 6 * D * K + 2 * K)
-    roofline["iteration"] = {"algorithmic_flops": iter_flops, "achieved": iter_flops / (dt / args.steps) / 1e12,
-                             "frac": iter_flops / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                             "algorithmic_bytes": float(N) * 16 * T * (K + 2 * D)}
+    iter_exec = sum(w["executed_flops"] for w in work.values())
+    step_s = dt / args.steps
+    roofline["iteration"] = {"algorithmic_flops": iter_flops, "achieved": iter_flops / step_s / 1e12,
+                             "frac": iter_flops / step_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             "executed_flops_big_kernels": iter_exec, "executed_TFLOPs": iter_exec / step_s / 1e12,
+                             "executed_frac": iter_exec / step_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             "algorithmic_bytes": float(N) * 16 * T * (K + 2 * D),
+                             "traffic": (sum(traffic.values()) if len(traffic) == len(work) else None)}
 
     if rank == 0:
-        cpu, rel = (None, None)
+        cpu, rel, rel_x = (None, None, None)
         if not args.no_cpu_baseline:
-            cpu, rel = cpu_baseline_and_parity(T, D, K, local_rank)
+            got = b.elbo()
+            gx = b.get_state(("X",))["X"][:n_par].copy()
+            cpu, rel, rel_x = cpu_baseline_and_parity(sample, pri, args.warmup + args.steps, got, gx)
         total_rep = N * world
         value = (total_rep / 1024.0) * args.steps / dt
         out = {
@@ -203,7 +265,9 @@ def main():
             "data": "synthetic LDS (simulated x_t = A x_{t-1} + w, y_t = C x_t + v; up to 128 distinct systems tiled, distinct initial posteriors)",
             "config": {"workload": "LDS T=%d D=%d K=%d, %d replicates per GPU (BASELINE configs[%d])" % (T, D, K, N, 2 if world == 1 else 3),
                        "replicates_total": total_rep, "parallelism": "replicates sharded over %d GPU(s)" % world, "collective": collective,
-                       "elbo_rel_err_vs_numpy": rel, "elbo_total": float(np.sum(elbo)),
+                       "elbo_rel_err_vs_numpy": rel, "state_rel_err_vs_numpy": rel_x,
+                       "parity_checked_on": "replicates 0..%d of the timed batch after %d iterations" % (n_par - 1, args.warmup + args.steps),
+                       "degraded": degraded, "elbo_total": float(np.sum(elbo)),
                        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kt.items() if v[1]}},
             "roofline": roofline,
             "cpu_baseline": cpu,

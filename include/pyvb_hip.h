@@ -52,7 +52,8 @@ enum { PYVB_NOISE_DIAGONAL_GAMMA = 0,   /* nodes_todo.py:159-204 DiagonalGamma *
 enum { PYVB_FORWARD = 0, PYVB_BACKWARD = 1 };
 
 /* which kernels pyvb_lds_timing_get() reports on */
-enum { PYVB_K_PREP = 0, PYVB_K_SWEEP = 1, PYVB_K_STATS = 2, PYVB_K_PARAMS = 3, PYVB_K_STEP = 4, PYVB_K_COUNT = 5 };
+enum { PYVB_K_PREP = 0, PYVB_K_SWEEP_FWD = 1, PYVB_K_STATS = 2, PYVB_K_PARAMS = 3, PYVB_K_STEP = 4,
+       PYVB_K_SWEEP_BWD = 5, PYVB_K_ELBO = 6, PYVB_K_COUNT = 7 };
 
 const char* pyvb_last_error(void);
 int pyvb_version(void);
@@ -123,6 +124,11 @@ int pyvb_lds_timing_reset(pyvb_lds* h);
 int pyvb_lds_timing_get(pyvb_lds* h, int kernel, double* total_ms, int* launches);
 /* device-side diagnostics: warm-up lengths chosen for the segmented sweeps [N][2] */
 int pyvb_lds_get_warmup(pyvb_lds* h, int* warm);
+/* Wavefronts per replicate in the sweeps (the time axis is dealt out to W of them when there are few replicates;
+ * pyvb_lds_create picks W, = 1 from about 1024 replicates on).  The setter lets a test run the W = 1 code path
+ * (the one the headline workload uses) on a handful of replicates; results do not depend on W beyond rounding. */
+int pyvb_lds_get_time_split(pyvb_lds* h, int* W);
+int pyvb_lds_set_time_split(pyvb_lds* h, int W);
 
 /* Multi-GPU: replicates are sharded over ranks; the only exchange is the ELBO all-reduce. */
 int pyvb_comm_unique_id(char id[128]);

@@ -9,12 +9,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyvb_hip.so")
+# PYVB_HIP_LIB: another build of the same library (kernel experiments, profiles/); there is still no other backend
+LIB_PATH = os.environ.get("PYVB_HIP_LIB") or os.path.join(_HERE, "libpyvb_hip.so")
 
 OK, E_ARG, E_HIP, E_LINALG, E_STALE, E_RCCL, E_UNSUPPORTED = range(7)
 NOISE_DIAGONAL_GAMMA, NOISE_GAMMA = 0, 1
 FORWARD, BACKWARD = 0, 1
-K_PREP, K_SWEEP, K_STATS, K_PARAMS, K_STEP = range(5)
+K_PREP, K_SWEEP_FWD, K_STATS, K_PARAMS, K_STEP, K_SWEEP_BWD, K_ELBO = range(7)
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -50,6 +51,8 @@ SIGNATURES = {
     "pyvb_lds_timing_reset": (ctypes.c_int, [_h]),
     "pyvb_lds_timing_get": (ctypes.c_int, [_h, ctypes.c_int, _dp, _ip]),
     "pyvb_lds_get_warmup": (ctypes.c_int, [_h, _ip]),
+    "pyvb_lds_get_time_split": (ctypes.c_int, [_h, _ip]),
+    "pyvb_lds_set_time_split": (ctypes.c_int, [_h, ctypes.c_int]),
     "pyvb_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "pyvb_lds_comm_init": (ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "pyvb_lds_comm_destroy": (ctypes.c_int, [_h]),

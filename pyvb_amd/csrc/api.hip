@@ -182,6 +182,7 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     return PYVB_OK;
 }
 
+static void states_changed(pyvb_lds* h);
 #define ENTER(h) do { ARGCHK(h, "handle is NULL"); HIPCHK(hipSetDevice((h)->device)); } while (0)
 
 static int h2d(pyvb_lds* h, double* dst, const double* src, size_t n) {
@@ -348,6 +349,30 @@ int pyvb_lds_get_column_qld(pyvb_lds* h, double* qld_A, double* qld_C) {
     if ((rc = d2h(h, qld_A, h->qld_A, (size_t)h->N * h->D))) return rc;
     if ((rc = d2h(h, qld_C, h->qld_C, (size_t)h->N * h->D))) return rc;
     return pyvb_lds_sync(h);
+}
+
+int pyvb_lds_get_time_split(pyvb_lds* h, int* W) {
+    ENTER(h);
+    ARGCHK(W, "W is NULL");
+    *W = h->W;
+    return PYVB_OK;
+}
+
+int pyvb_lds_set_time_split(pyvb_lds* h, int W) {
+    ENTER(h);
+    ARGCHK(W >= 1 && W <= 128, "W must be in 1..128");
+    ARGCHK(W == 1 || (h->T - 2) / W >= 16, "parts of fewer than 16 nodes");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (W != h->W) {
+        double* p = nullptr;
+        int rc = dev_alloc(&p, (size_t)h->N * W * h->L.DP * h->L.DP);
+        if (rc) return rc;
+        (void)hipFree(h->sxx);
+        h->sxx = p; h->W = W;
+        h->sxx_valid = false; h->u_valid = false;
+        states_changed(h);
+    }
+    return PYVB_OK;
 }
 
 int pyvb_lds_get_warmup(pyvb_lds* h, int* warm) {

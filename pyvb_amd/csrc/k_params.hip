@@ -242,7 +242,7 @@ int launch_noise(pyvb_lds* h, int which) {
 
 int launch_elbo(pyvb_lds* h) {
     ParamArgs a = make_args(h);
-    TimedLaunch tl(h, PYVB_K_PARAMS);
+    TimedLaunch tl(h, PYVB_K_ELBO);
     hipLaunchKernelGGL(k_elbo, dim3(h->N), dim3(64), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;

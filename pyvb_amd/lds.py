@@ -105,6 +105,15 @@ class LDSBatch(object):
         C.check(C.lib.pyvb_lds_get_warmup(self._h, w.ctypes.data_as(C._ip)))
         return w
 
+    def get_time_split(self):
+        w = C.ctypes.c_int()
+        C.check(C.lib.pyvb_lds_get_time_split(self._h, C.ctypes.byref(w)))
+        return w.value
+
+    def set_time_split(self, W):
+        """Wavefronts per replicate in the sweeps (chosen by the library; tests force W = 1, the headline code path)."""
+        C.check(C.lib.pyvb_lds_set_time_split(self._h, int(W)))
+
     # -- updates ----------------------------------------------------------------------------
     def sweep(self, direction="forward"):
         C.check(C.lib.pyvb_lds_sweep(self._h, C.FORWARD if direction == "forward" else C.BACKWARD))
@@ -154,7 +163,8 @@ class LDSBatch(object):
         C.check(C.lib.pyvb_lds_timing_reset(self._h))
 
     def kernel_times(self):
-        names = {"prep": C.K_PREP, "sweep": C.K_SWEEP, "stats": C.K_STATS, "params": C.K_PARAMS, "step": C.K_STEP}
+        names = {"prep": C.K_PREP, "sweep_fwd": C.K_SWEEP_FWD, "sweep_bwd": C.K_SWEEP_BWD, "stats": C.K_STATS,
+                 "params": C.K_PARAMS, "elbo": C.K_ELBO, "step": C.K_STEP}
         out = {}
         for nm, k in names.items():
             ms, cnt = C.ctypes.c_double(), C.ctypes.c_int()

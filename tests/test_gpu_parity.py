@@ -301,6 +301,73 @@ def test_headline_shape_against_oracle():
     big.close()
 
 
+def test_headline_instantiation_one_wavefront_per_replicate_warmup():
+    """The instantiation bench.py times -- k_sweep<4,4,true,{1,2},SPLIT=false>: one wavefront per replicate, 16
+    segments of Lseg nodes that warm up J < Lseg steps from zero -- forced on a handful of replicates
+    (pyvb_lds_set_time_split) and compared with the oracle over two full iterations."""
+    T, D, K, N = 2402, 64, 64, 3
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=777)
+    b = _batch(Y, st0, pri)
+    b.set_time_split(1)
+    assert b.get_time_split() == 1
+    st = O.expand_state(st0, pri, T)
+    for it in range(2):
+        parts = O.iterate(st, pri, Y)
+        b.iterate(1)
+        w = b.get_warmup()
+        assert np.all(w > 0) and np.all(w < (T - 2) // 16), "warm-up path not exercised: J = %r, Lseg = %d" % (w, (T - 2) // 16)
+        _close(b.get_state(("X",))["X"], st["X"], "X (W = 1, iteration %d)" % it)
+        got = b.elbo()
+        assert np.all(np.abs(got - parts) <= RTOL * np.abs(parts).sum(axis=1, keepdims=True)), "elbo parts (W = 1)"
+    _compare_params(b, st, "W = 1 ")
+    Sig, qld = b.get_posterior_classes()
+    _close(Sig, st["Sigma"], "Sigma (W = 1)")
+    # stage by stage as well (MODE 0 backward sweep, separate statistics with Sxx from k_stats)
+    b.close()
+    b = _batch(Y, st0, pri)
+    b.set_time_split(1)
+    st = O.expand_state(st0, pri, T)
+    post = O.state_posteriors(st, pri)
+    O.sweep(st, pri, Y, "backward", post); b.sweep("backward")
+    _close(b.get_state(("X",))["X"], st["X"], "backward sweep alone (W = 1)")
+    O.sweep(st, pri, Y, "forward", post); b.sweep("forward")
+    _close(b.get_state(("X",))["X"], st["X"], "forward sweep with stored states (W = 1)")
+    b.close()
+
+
+def test_headline_batch_1024_replicates():
+    """BASELINE configs[2] as bench.py runs it: N = 1024 replicates (the library itself chooses one wavefront per
+    replicate), T = 10^4, D = K = 64.  Two distinct problems tiled 512 times: replicates 0 and 1 against the oracle,
+    every copy bitwise equal to the first."""
+    T, D, K, N = 10000, 64, 64, 1024
+    Y2, st2, pri = synth.make_problem(T, D, K, 2, seed=4243)
+    rep = N // 2
+    Y = np.concatenate([Y2] * rep)
+    st0 = {k: np.concatenate([v] * rep) for k, v in st2.items()}
+    b = _batch(Y, st0, pri)
+    del Y
+    assert b.get_time_split() == 1
+    st = O.expand_state(st2, pri, T)
+    for it in range(2):
+        parts = O.iterate(st, pri, Y2)
+        b.iterate(1)
+    w = b.get_warmup()
+    assert np.all(w > 0) and np.all(w < (T - 2) // 16)
+    e = b.elbo()
+    assert np.all(np.abs(e[:2] - parts) <= RTOL * np.abs(parts).sum(axis=1, keepdims=True)), "elbo parts (N = 1024)"
+    _close(e[:2].sum(1), parts.sum(1), "elbo (N = 1024)")
+    assert np.array_equal(e[0::2], np.repeat(e[0:1], rep, 0)) and np.array_equal(e[1::2], np.repeat(e[1:2], rep, 0))
+    g = b.get_state(("A_mean", "C_mean", "Q_b", "R_b"))
+    _close(g["A_mean"][:2], st["A_mean"], "A_mean (N = 1024)")
+    _close(g["C_mean"][:2], st["C_mean"], "C_mean (N = 1024)")
+    _close(g["Q_b"][:2], st["Q_b"], "Q_b (N = 1024)")
+    _close(g["R_b"][:2], st["R_b"], "R_b (N = 1024)")
+    X = b.get_state(("X",))["X"]
+    _close(X[:2], st["X"], "X (N = 1024)")
+    assert np.array_equal(X[2:4], X[:2]) and np.array_equal(X[-2:], X[:2])
+    b.close()
+
+
 def test_baseline_config2_single_long_chain():
     """BASELINE configs[1]: T = 10^4, D = K = 16, one replicate, three full iterations against the oracle
     (the segmented sweeps run with 624 interior nodes per segment and a data-driven warm-up)."""
