@@ -48,7 +48,8 @@ typedef enum {
 } pyvb_status;
 
 enum { PYVB_NOISE_DIAGONAL_GAMMA = 0,   /* nodes_todo.py:159-204 DiagonalGamma */
-       PYVB_NOISE_GAMMA = 1 };          /* nodes_todo.py:88-157  Gamma (isotropic) */
+       PYVB_NOISE_GAMMA = 1,            /* nodes_todo.py:88-157  Gamma (isotropic) */
+       PYVB_NOISE_WISHART = 2 };        /* nodes_todo.py:205-234 Wishart (dense precisions; see pyvb_lds_set_wishart_priors) */
 enum { PYVB_FORWARD = 0, PYVB_BACKWARD = 1 };
 
 /* which kernels pyvb_lds_timing_get() reports on */
@@ -74,6 +75,19 @@ int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_pre
                         const double* A_prior_mean, const double* A_prior_prec,
                         const double* C_prior_mean, const double* C_prior_prec,
                         const double* Q_a0, const double* Q_b0, const double* R_a0, const double* R_b0);
+
+/* Wishart noise precisions (Linear_Dynamic_System.py:55-56; nodes_todo.py:205-234), for handles created with
+ * PYVB_NOISE_WISHART: Q = Wishart(D, Q_v0, Q_w0[D][D]), R = Wishart(K, R_v0, R_w0[K][K]); call after pyvb_lds_set_priors
+ * (whose Gamma arguments may then be NULL).  State: qv (fixed by the graph, update_v :224-227) and qw ([N][D][D] /
+ * [N][K][K], update :228-231); E[Lambda] = qv * inv(qw) (:233-234).  The columns of A and C then have dense posterior
+ * covariances A_cov[N][D][D][D] (column i: [D][D]) and C_cov[N][D][K][K]; pyvb_lds_set_state's A_colvar / C_colvar give
+ * diagonal initial ones.  Deviations from the unfinished reference class (prior not mutated by update(), symmetric part
+ * of qw in the expectation, a defined lower bound) are listed at the top of pyvb_amd/csrc/k_wishart.hip. */
+int pyvb_lds_set_wishart_priors(pyvb_lds* h, double Q_v0, const double* Q_w0, double R_v0, const double* R_w0);
+int pyvb_lds_set_wishart_state(pyvb_lds* h, const double* Q_w, const double* R_w);
+int pyvb_lds_get_wishart_state(pyvb_lds* h, double* Q_v, double* Q_w, double* R_v, double* R_w);
+int pyvb_lds_set_column_cov(pyvb_lds* h, const double* A_cov, const double* C_cov);
+int pyvb_lds_get_column_cov(pyvb_lds* h, double* A_cov, double* C_cov);
 
 /* Gaussian.observe for every Y_t (gaussian.py:74-100, full observations only). */
 int pyvb_lds_set_observations(pyvb_lds* h, const double* Y);

@@ -48,7 +48,9 @@ def noise_expect(kind, a, b, dim):
     if kind == "gamma":
         return (a / b)[:, None, None] * np.eye(dim)[None]
     if kind == "wishart":
-        return a[:, None, None] * np.linalg.inv(b)
+        # The reference's update leaves qw non-symmetric (its -<x><mu>^T term, nodes_todo.py:231); the build takes the
+        # expectation of the symmetric part, which is the same thing for the first update (the parity target).
+        return a[:, None, None] * np.linalg.inv(0.5 * (b + np.swapaxes(b, -1, -2)))
     raise ValueError(kind)
 
 
@@ -59,7 +61,11 @@ def noise_lndet(kind, a, b, dim):
         return np.sum(np.log(a / b), axis=-1)
     if kind == "gamma":
         return dim * (np.log(a) - np.log(b))
-    raise AttributeError("Wishart has no pass_down_lndet in the reference (SURVEY Q8)")
+    if kind == "wishart":
+        # NOT in the reference (Wishart has no pass_down_lndet): ln det of the expectation, like the Gamma
+        # nodes (quirk Q2).  Parity unpinned.
+        return dim * np.log(a) - np.linalg.slogdet(0.5 * (b + np.swapaxes(b, -1, -2)))[1]
+    raise ValueError(kind)
 
 
 def noise_a(kind, a0, n_children, dim):
@@ -70,8 +76,33 @@ def noise_a(kind, a0, n_children, dim):
     return a0 + 0.5 * n_children
 
 
+def _psi_multi(x, dim):
+    return sum(digamma(x - 0.5 * i) for i in range(dim))
+
+
+def _lgamma_multi(x, dim):
+    return 0.25 * dim * (dim - 1) * np.log(np.pi) + sum(gammaln(x - 0.5 * i) for i in range(dim))
+
+
+def wishart_llb(a0, B0, a, B):
+    """Lower-bound term of a Wishart node in the reference's (a, B) parametrisation, E ln p - E ln q with
+    ln p(L) = (a0 - (D+1)/2) ln|L| - ln Gamma_D(a0) + a0 ln|B0| - tr(B0 L); reduces to Gamma.log_lower_bound
+    (nodes_todo.py:149-157) for D = 1.  NOT in the reference: derived, parity unpinned."""
+    dim = B.shape[-1]
+    Bs = 0.5 * (B + np.swapaxes(B, -1, -2))
+    lndB = np.linalg.slogdet(Bs)[1]
+    EL = a[:, None, None] * np.linalg.inv(Bs)
+    Eln = _psi_multi(a, dim) - lndB
+    half = 0.5 * (dim + 1)
+    ret = (a0 - half) * Eln - _lgamma_multi(a0, dim) + a0 * np.linalg.slogdet(B0)[1] - np.einsum("ij,nji->n", B0, EL)
+    ret = ret - ((a - half) * Eln - _lgamma_multi(a, dim) + a * lndB - a * dim)
+    return ret
+
+
 def noise_llb(kind, a0, b0, a, b):
     """log_lower_bound of a Gamma / DiagonalGamma node (nodes_todo.py:149-157, :199-204)."""
+    if kind == "wishart":
+        return wishart_llb(a0, b0, a, b)
     Elnx = digamma(a) - np.log(b)
     ret = (a0 - 1) * Elnx - gammaln(a0) + a0 * np.log(b0) - b0 * (a / b)
     ret = ret - ((a - 1) * Elnx - gammaln(a) + a * np.log(b) - b * (a / b))
@@ -394,6 +425,9 @@ def expand_state(st0, pri, T):
     if pri["noise"] == "gamma":
         st["Q_b"] = st["Q_b"][:, 0].copy()
         st["R_b"] = st["R_b"][:, 0].copy()
+    elif pri["noise"] == "wishart" and st["Q_b"].ndim == 2:     # compact form: the diagonal of qw
+        st["Q_b"] = np.einsum("nd,de->nde", st["Q_b"], np.eye(st["Q_b"].shape[1]))
+        st["R_b"] = np.einsum("nd,de->nde", st["R_b"], np.eye(st["R_b"].shape[1]))
     init_noise_a(st, pri, T)
     st["qld_A"] = np.full(st["A_mean"].shape[:1] + st["A_mean"].shape[2:], np.nan)
     st["qld_C"] = st["qld_A"].copy()

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYVB_HIP_LIB") or os.path.join(_HERE, "libpyvb_hip.so")
 
 OK, E_ARG, E_HIP, E_LINALG, E_STALE, E_RCCL, E_UNSUPPORTED = range(7)
-NOISE_DIAGONAL_GAMMA, NOISE_GAMMA = 0, 1
+NOISE_DIAGONAL_GAMMA, NOISE_GAMMA, NOISE_WISHART = 0, 1, 2
 FORWARD, BACKWARD = 0, 1
 K_PREP, K_SWEEP_FWD, K_STATS, K_PARAMS, K_STEP, K_SWEEP_BWD, K_ELBO = range(7)
 
@@ -29,6 +29,11 @@ SIGNATURES = {
     "pyvb_lds_create": (ctypes.c_int, [ctypes.POINTER(_h)] + [ctypes.c_int] * 6),
     "pyvb_lds_destroy": (ctypes.c_int, [_h]),
     "pyvb_lds_set_priors": (ctypes.c_int, [_h] + [_dp] * 10),
+    "pyvb_lds_set_wishart_priors": (ctypes.c_int, [_h, ctypes.c_double, _dp, ctypes.c_double, _dp]),
+    "pyvb_lds_set_wishart_state": (ctypes.c_int, [_h, _dp, _dp]),
+    "pyvb_lds_get_wishart_state": (ctypes.c_int, [_h, _dp, _dp, _dp, _dp]),
+    "pyvb_lds_set_column_cov": (ctypes.c_int, [_h, _dp, _dp]),
+    "pyvb_lds_get_column_cov": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_lds_set_observations": (ctypes.c_int, [_h, _dp]),
     "pyvb_lds_set_column_observations": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_lds_set_state": (ctypes.c_int, [_h] + [_dp] * 7),

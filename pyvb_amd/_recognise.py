@@ -28,13 +28,18 @@ class LDSPlan(object):
         self.batch.set_observations(np.hstack([y.__dict__["_h_qmu"] for y in Ys]).T.reshape(1, T, K))
         diag = lambda nodes_: np.stack([np.diag(n.__dict__["_h_qcov"]) for n in nodes_])
         qb = lambda nd, dim: np.broadcast_to(np.asarray(nd.__dict__["_h_qb"], dtype=float), (dim,)).reshape(1, dim)
-        self.batch.set_state(
+        state = dict(
             X=np.hstack([x.__dict__["_h_qmu"] for x in Xs]).T.reshape(1, T, D),
             A_mean=np.hstack([a.__dict__["_h_qmu"] for a in As]).reshape(1, D, D),
             A_colvar=diag(As).reshape(1, D, D),
             C_mean=np.hstack([c.__dict__["_h_qmu"] for c in Cs]).reshape(1, K, D),
-            C_colvar=diag(Cs).reshape(1, D, K),
-            Q_b=qb(Q, D), R_b=qb(R, K))
+            C_colvar=diag(Cs).reshape(1, D, K))
+        if self.kind == "wishart":
+            self.batch.set_state(**state)
+            self.batch.set_wishart_state(np.asarray(Q.__dict__["_h_qw"], dtype=float).reshape(1, D, D),
+                                         np.asarray(R.__dict__["_h_qw"], dtype=float).reshape(1, K, K))
+        else:
+            self.batch.set_state(Q_b=qb(Q, D), R_b=qb(R, K), **state)
         if pri.get("A_obs") is not None:
             self.batch.set_column_observations(pri["A_obs"], pri["C_obs"])
         self.index = {}
@@ -99,6 +104,9 @@ class LDSPlan(object):
             Sig, qld = self.batch.get_posterior_classes()
             qa, qc = self.batch.get_column_qld()
             self.cache = {"st": st, "Sigma": Sig[0], "qld_x": qld[0], "qld_A": qa[0], "qld_C": qc[0]}
+            if self.kind == "wishart":
+                self.cache["w"] = self.batch.get_wishart_state()
+                self.cache["A_cov"], self.cache["C_cov"] = [v[0] for v in self.batch.get_column_cov()]
         return self.cache
 
     def read(self, node, name):
@@ -116,7 +124,11 @@ class LDSPlan(object):
             M, V, q = ("A_mean", "A_colvar", "qld_A") if kind == "a" else ("C_mean", "C_colvar", "qld_C")
             if name == "qmu":
                 return st[M][0][:, [i]].copy()
+            if name == "qcov" and self.kind == "wishart":
+                return c["A_cov" if kind == "a" else "C_cov"][i].copy()
             return np.diag(st[V][0, i]) if name == "qcov" else float(c[q][i])
+        if name == "qw":
+            return c["w"]["Q_w" if kind == "q" else "R_w"][0].copy()
         if name == "qb":
             v = st["Q_b" if kind == "q" else "R_b"][0]
             return float(v[0]) if self.kind == "gamma" else v.copy()
@@ -138,6 +150,9 @@ class LDSPlan(object):
             else:
                 st[V][0, i] = np.diag(np.asarray(value))
             self.batch.set_state(**{M: st[M], V: st[V]})
+        elif kind in ("q", "r") and name == "qw":
+            v = np.asarray(value, dtype=float).reshape((1,) + node.shape)
+            self.batch.set_wishart_state(**{"Q_w" if kind == "q" else "R_w": v})
         elif kind in ("q", "r") and name == "qb":
             key = "Q_b" if kind == "q" else "R_b"
             st[key][0] = np.broadcast_to(np.asarray(value, dtype=float), st[key][0].shape)
@@ -200,10 +215,8 @@ def describe(start):
     noise = [n for n in comp if isinstance(n, (N.Gamma, N.DiagonalGamma, N.Wishart))]
     if len(stacks) != 2 or len(noise) != 2:
         _fail("expected two hstack matrices and two noise-precision nodes, found %d and %d" % (len(stacks), len(noise)))
-    if any(isinstance(n, N.Wishart) for n in noise):
-        _fail("Wishart noise")
     if type(noise[0]) is not type(noise[1]):
-        _fail("Q and R must both be DiagonalGamma or both Gamma")
+        _fail("Q and R must both be DiagonalGamma, both Gamma or both Wishart")
     if any(isinstance(n, N.Addition) for n in comp):
         _fail("Addition nodes")
     # the chain start: a Gaussian with Constant parents that is multiplied by an hstack
@@ -261,7 +274,7 @@ def describe(start):
                 obs[:, i] = col.obs_value.reshape(-1)
         return obs
 
-    kind = "diagonal_gamma" if isinstance(Q, N.DiagonalGamma) else "gamma"
+    kind = "diagonal_gamma" if isinstance(Q, N.DiagonalGamma) else ("wishart" if isinstance(Q, N.Wishart) else "gamma")
     pri = {
         "noise": kind,
         "x0_mean": X0.mean_parent.value.reshape(-1).astype(float), "x0_prec": np.asarray(X0.precision_parent.value, dtype=float),
@@ -275,6 +288,10 @@ def describe(start):
             _fail("matrix columns need Constant mean parents")
     if kind == "diagonal_gamma":
         pri.update(Q_a0=Q.a0s, Q_b0=Q.b0s, R_a0=R.a0s, R_b0=R.b0s)
+    elif kind == "wishart":
+        if any(c.observed or c.partially_observed for c in As + Cs):
+            _fail("known entries of the matrices together with Wishart noise")
+        pri.update(Q_a0=float(Q.v0), Q_b0=np.array(Q.w0, dtype=float), R_a0=float(R.v0), R_b0=np.array(R.w0, dtype=float))
     else:
         pri.update(Q_a0=float(Q.a0), Q_b0=float(Q.b0), R_a0=float(R.a0), R_b0=float(R.b0))
     for col in As + Cs:

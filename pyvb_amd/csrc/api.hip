@@ -68,7 +68,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     ARGCHK(T >= 2, "T must be >= 2 (a chain needs X_0 and X_{T-1})");
     ARGCHK(D >= 1 && D <= 64, "latent dimension D must be in 1..64");
     ARGCHK(K >= 1 && K <= 64, "observed dimension K must be in 1..64");
-    ARGCHK(noise_kind == PYVB_NOISE_DIAGONAL_GAMMA || noise_kind == PYVB_NOISE_GAMMA, "unknown noise kind");
+    ARGCHK(noise_kind == PYVB_NOISE_DIAGONAL_GAMMA || noise_kind == PYVB_NOISE_GAMMA || noise_kind == PYVB_NOISE_WISHART, "unknown noise kind");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     ARGCHK(device >= 0 && device < ndev, "no such device");
@@ -77,6 +77,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     memset(h, 0, sizeof(*h));
     h->device = device; h->N = N; h->T = T; h->D = D; h->K = K; h->noise = noise_kind;
     h->L = make_layout(D, K);
+    h->dense = noise_kind == PYVB_NOISE_WISHART;
     const Layout& L = h->L;
     int rc = PYVB_OK;
 #define TRY(x) do { rc = (x); if (rc != PYVB_OK) { pyvb_lds_destroy(h); return rc; } } while (0)
@@ -136,7 +137,8 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int)));
     TRYHIP(hipMemset(h->status, 0, sizeof(int)));
     // priors block: x0_mean D, x0_prec D*D, A_pm D*D, A_pp D*D, C_pm K*D, C_pp D*K, Q_a0 D, Q_b0 D, R_a0 K, R_b0 K
-    size_t pn = (size_t)D + 3 * (size_t)D * D + 2 * (size_t)K * D + 2 * (size_t)D + 2 * (size_t)K + (size_t)D * D + (size_t)K * D + 2 * (size_t)D;
+    size_t pn = (size_t)D + 3 * (size_t)D * D + 2 * (size_t)K * D + 2 * (size_t)D + 2 * (size_t)K + (size_t)D * D + (size_t)K * D + 2 * (size_t)D
+                + (size_t)D * D + (size_t)K * K;
     TRY(dev_alloc(&h->pri_block, pn));
     double* p = h->pri_block;
     h->pri.x0_mean = p; p += D; h->pri.x0_prec = p; p += D * D;
@@ -145,6 +147,17 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     h->pri.Q_a0 = p; p += D; h->pri.Q_b0 = p; p += D; h->pri.R_a0 = p; p += K; h->pri.R_b0 = p; p += K;
     h->pri.A_obs = p; p += D * D; h->pri.C_obs = p; p += K * D;
     h->pri.A_pld = p; p += D; h->pri.C_pld = p; p += D;
+    h->pri.Q_w0 = p; p += D * D; h->pri.R_w0 = p; p += K * K;
+    if (h->dense) {
+        TRY(dev_alloc(&h->Q_w, n * D * D)); TRY(dev_alloc(&h->R_w, n * K * K));
+        TRY(dev_alloc(&h->Qbar, n * D * D)); TRY(dev_alloc(&h->Rbar, n * K * K));
+        TRY(dev_alloc(&h->lnd, n * 4));
+        TRY(dev_alloc(&h->QA, n * D * D)); TRY(dev_alloc(&h->RC, n * K * D));
+        TRY(dev_alloc(&h->trA, n * D)); TRY(dev_alloc(&h->trC, n * D));
+        TRY(dev_alloc(&h->A_cov, n * D * D * D)); TRY(dev_alloc(&h->C_cov, n * D * K * K));
+        TRY(dev_alloc(&h->SyyF, n * K * K));
+        TRY(dev_alloc(&h->RQ, n * D * D)); TRY(dev_alloc(&h->RR, n * K * K));
+    }
     TRYHIP(hipMemset(h->pri.A_obs, 0xFF, ((size_t)D * D + (size_t)K * D) * sizeof(double)));     // all-ones bytes = NaN = nothing observed
     h->fresh = (unsigned char*)calloc(T, 1);
     h->world = 1;
@@ -168,7 +181,8 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     pyvb_lds_comm_destroy(h);
     double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
-                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->sxx, h->U};
+                      h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->sxx, h->U,
+                      h->Q_w, h->R_w, h->Qbar, h->Rbar, h->lnd, h->QA, h->RC, h->trA, h->trC, h->A_cov, h->C_cov, h->SyyF, h->RQ, h->RR};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
     if (h->status) (void)hipFree(h->status);
@@ -227,7 +241,8 @@ int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_pre
                         const double* A_pm, const double* A_pp, const double* C_pm, const double* C_pp,
                         const double* Q_a0, const double* Q_b0, const double* R_a0, const double* R_b0) {
     ENTER(h);
-    ARGCHK(x0_mean && x0_prec && A_pm && A_pp && C_pm && C_pp && Q_a0 && Q_b0 && R_a0 && R_b0, "all prior arrays are required");
+    ARGCHK(x0_mean && x0_prec && A_pm && A_pp && C_pm && C_pp, "the priors of X_0 and of the columns are required");
+    ARGCHK(h->dense || (Q_a0 && Q_b0 && R_a0 && R_b0), "the Gamma priors of Q and R are required");
     const int D = h->D, K = h->K, T = h->T, N = h->N;
     for (int i = 0; i < D * D; ++i) ARGCHK(A_pp[i] > 0.0, "A_prior_prec must be positive");
     for (int i = 0; i < D * K; ++i) ARGCHK(C_pp[i] > 0.0, "C_prior_prec must be positive");
@@ -247,6 +262,12 @@ int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_pre
         }
         HIPCHK(hipMemcpyAsync(h->pri.A_pld, ld.data(), 2 * (size_t)D * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (h->dense) {         // the Wishart priors come through pyvb_lds_set_wishart_priors
+        HIPCHK(hipStreamSynchronize(h->stream));
+        params_changed(h);
+        h->resQ_valid = h->resR_valid = false;
+        return PYVB_OK;
     }
     if ((rc = h2d(h, h->pri.Q_a0, Q_a0, D))) return rc;
     if ((rc = h2d(h, h->pri.Q_b0, Q_b0, D))) return rc;
@@ -269,8 +290,83 @@ int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_pre
     return PYVB_OK;
 }
 
+int pyvb_lds_set_wishart_priors(pyvb_lds* h, double Q_v0, const double* Q_w0, double R_v0, const double* R_w0) {
+    ENTER(h);
+    ARGCHK(h->dense, "the handle was not created with PYVB_NOISE_WISHART");
+    ARGCHK(Q_w0 && R_w0, "Q_w0 and R_w0 are required");
+    const int D = h->D, K = h->K, T = h->T, N = h->N;
+    if (host_lndet(Q_w0, D, &h->pri.Q_w0_lndet) != PYVB_OK || host_lndet(R_w0, K, &h->pri.R_w0_lndet) != PYVB_OK) {
+        pyvb_set_error("a Wishart prior w0 is not symmetric positive definite");
+        return PYVB_E_LINALG;
+    }
+    h->pri.Q_a0_host = Q_v0; h->pri.R_a0_host = R_v0;
+    int rc;
+    if ((rc = h2d(h, h->pri.Q_w0, Q_w0, (size_t)D * D))) return rc;
+    if ((rc = h2d(h, h->pri.R_w0, R_w0, (size_t)K * K))) return rc;
+    // qv is fixed by the graph: update_v, nodes_todo.py:224-227 (+0.5 per child); Q has T-1 children, R has T
+    std::vector<double> qa((size_t)N * D, Q_v0 + 0.5 * (T - 1)), ra((size_t)N * K, R_v0 + 0.5 * T);
+    if ((rc = h2d(h, h->Q_a, qa.data(), qa.size()))) return rc;
+    if ((rc = h2d(h, h->R_a, ra.data(), ra.size()))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->expect_valid = false;
+    params_changed(h);
+    h->resQ_valid = h->resR_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_lds_set_wishart_state(pyvb_lds* h, const double* Q_w, const double* R_w) {
+    ENTER(h);
+    ARGCHK(h->dense, "the handle was not created with PYVB_NOISE_WISHART");
+    int rc;
+    if ((rc = h2d(h, h->Q_w, Q_w, (size_t)h->N * h->D * h->D))) return rc;
+    if ((rc = h2d(h, h->R_w, R_w, (size_t)h->N * h->K * h->K))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->expect_valid = false;
+    params_changed(h);
+    return PYVB_OK;
+}
+
+int pyvb_lds_get_wishart_state(pyvb_lds* h, double* Q_v, double* Q_w, double* R_v, double* R_w) {
+    ENTER(h);
+    ARGCHK(h->dense, "the handle was not created with PYVB_NOISE_WISHART");
+    const size_t N = h->N, D = h->D, K = h->K;
+    int rc;
+    if (Q_v) HIPCHK(hipMemcpy2DAsync(Q_v, sizeof(double), h->Q_a, D * sizeof(double), sizeof(double), N, hipMemcpyDeviceToHost, h->stream));
+    if (R_v) HIPCHK(hipMemcpy2DAsync(R_v, sizeof(double), h->R_a, K * sizeof(double), sizeof(double), N, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = d2h(h, Q_w, h->Q_w, N * D * D))) return rc;
+    if ((rc = d2h(h, R_w, h->R_w, N * K * K))) return rc;
+    return pyvb_lds_sync(h);
+}
+
+int pyvb_lds_set_column_cov(pyvb_lds* h, const double* A_cov, const double* C_cov) {
+    ENTER(h);
+    ARGCHK(h->dense, "dense column covariances exist with PYVB_NOISE_WISHART only");
+    const size_t N = h->N, D = h->D, K = h->K;
+    int rc;
+    if ((rc = h2d(h, h->A_cov, A_cov, N * D * D * D))) return rc;
+    if ((rc = h2d(h, h->C_cov, C_cov, N * D * K * K))) return rc;
+    // keep the diagonals (what the lower bound reads) in step
+    if (A_cov) HIPCHK(hipMemcpy2DAsync(h->A_var, sizeof(double), h->A_cov, (D + 1) * sizeof(double), sizeof(double), N * D * D, hipMemcpyDeviceToDevice, h->stream));
+    if (C_cov) HIPCHK(hipMemcpy2DAsync(h->C_var, sizeof(double), h->C_cov, (K + 1) * sizeof(double), sizeof(double), N * D * K, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    params_changed(h);
+    h->resQ_valid = h->resR_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_lds_get_column_cov(pyvb_lds* h, double* A_cov, double* C_cov) {
+    ENTER(h);
+    ARGCHK(h->dense, "dense column covariances exist with PYVB_NOISE_WISHART only");
+    const size_t N = h->N, D = h->D, K = h->K;
+    int rc;
+    if ((rc = d2h(h, A_cov, h->A_cov, N * D * D * D))) return rc;
+    if ((rc = d2h(h, C_cov, h->C_cov, N * D * K * K))) return rc;
+    return pyvb_lds_sync(h);
+}
+
 int pyvb_lds_set_column_observations(pyvb_lds* h, const double* A_obs, const double* C_obs) {
     ENTER(h);
+    if (h->dense) { pyvb_set_error("known entries of A / C together with Wishart noise are not supported"); return PYVB_E_UNSUPPORTED; }
     int rc;
     if ((rc = h2d(h, h->pri.A_obs, A_obs, (size_t)h->D * h->D))) return rc;
     if ((rc = h2d(h, h->pri.C_obs, C_obs, (size_t)h->K * h->D))) return rc;
@@ -288,6 +384,7 @@ int pyvb_lds_set_observations(pyvb_lds* h, const double* Y) {
     if ((rc = h2d(h, h->Y, Y, (size_t)h->N * h->T * h->K))) return rc;
     h->u_valid = false;
     if ((rc = launch_syy(h))) return rc;
+    if (h->dense && (rc = launch_syy_full(h))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     states_changed(h);
     return PYVB_OK;
@@ -308,6 +405,7 @@ int pyvb_lds_set_state(pyvb_lds* h, const double* X, const double* A_mean, const
     if ((rc = h2d(h, h->C_var, C_colvar, N * D * K))) return rc;
     if ((rc = h2d(h, h->Q_b, Q_b, N * D))) return rc;
     if ((rc = h2d(h, h->R_b, R_b, N * K))) return rc;
+    if (h->dense && (A_colvar || C_colvar) && (rc = launch_colvar_to_cov(h))) return rc;     // diagonal initial covariances
     HIPCHK(hipStreamSynchronize(h->stream));
     if (X) { states_changed(h); h->u_valid = false; h->sxx_valid = false; }
     if (A_mean || A_colvar || C_mean || C_colvar || Q_b || R_b) { params_changed(h); h->resQ_valid = h->resR_valid = false; }
@@ -386,10 +484,22 @@ int pyvb_lds_get_warmup(pyvb_lds* h, int* warm) {
 // gains (k_prep) depend on the parameter posteriors.  The posterior covariance classes that the
 // statistics use are those of the X_t's LAST update; they switch to the freshly prepared ones
 // once every X_t has been updated under the current parameters.
+static int ensure_expect(pyvb_lds* h) {        // E[Q], E[R] of the current Wishart posteriors
+    if (h->expect_valid) return PYVB_OK;
+    int rc = launch_wexpect(h);
+    if (rc) return rc;
+    h->expect_valid = true;
+    return PYVB_OK;
+}
+
 static int ensure_gains(pyvb_lds* h) {
     if (h->gains_valid) return PYVB_OK;
-    int rc = launch_prep(h);
-    if (rc) return rc;
+    int rc;
+    if (h->dense) {
+        if ((rc = ensure_expect(h))) return rc;
+        if ((rc = launch_dense_pre(h))) return rc;
+    }
+    if ((rc = launch_prep(h))) return rc;
     h->gains_valid = true;
     memset(h->fresh, 0, h->T);
     h->fresh_count = 0;
@@ -430,7 +540,7 @@ static int ensure_resid(pyvb_lds* h, int which) {
     if (valid) return PYVB_OK;
     int rc = ensure_stats(h);
     if (rc) return rc;
-    if ((rc = launch_resid(h, which))) return rc;
+    if ((rc = h->dense ? launch_wresid(h, which, 0) : launch_resid(h, which))) return rc;
     valid = true;
     return PYVB_OK;
 }
@@ -472,7 +582,10 @@ int pyvb_lds_update_columns(pyvb_lds* h, int which, int col_begin, int col_end) 
     ARGCHK(col_begin >= 0 && col_begin < col_end && col_end <= h->D, "bad column range");
     int rc = ensure_stats(h);
     if (rc) return rc;
-    if ((rc = launch_cols(h, which, col_begin, col_end))) return rc;
+    if (h->dense) {
+        if ((rc = ensure_expect(h))) return rc;
+        if ((rc = launch_cols_dense(h, which, col_begin, col_end))) return rc;
+    } else if ((rc = launch_cols(h, which, col_begin, col_end))) return rc;
     params_changed(h);
     if (which == 0) h->resQ_valid = false; else h->resR_valid = false;
     return PYVB_OK;
@@ -481,29 +594,33 @@ int pyvb_lds_update_columns(pyvb_lds* h, int which, int col_begin, int col_end) 
 int pyvb_lds_update_A(pyvb_lds* h) { ARGCHK(h, "handle is NULL"); return pyvb_lds_update_columns(h, 0, 0, h->D); }
 int pyvb_lds_update_C(pyvb_lds* h) { ARGCHK(h, "handle is NULL"); return pyvb_lds_update_columns(h, 1, 0, h->D); }
 
-int pyvb_lds_update_Q(pyvb_lds* h) {
-    ENTER(h);
-    int rc = ensure_resid(h, 0);
-    if (rc) return rc;
-    if ((rc = launch_noise(h, 0))) return rc;
+static int update_noise(pyvb_lds* h, int which) {
+    int rc;
+    if (h->dense) {     // Wishart.update: the residual matrix and qw = w0 + it in one launch
+        if ((rc = ensure_stats(h))) return rc;
+        if ((rc = launch_wresid(h, which, 1))) return rc;
+        (which == 0 ? h->resQ_valid : h->resR_valid) = true;
+        h->expect_valid = false;
+    } else {
+        if ((rc = ensure_resid(h, which))) return rc;
+        if ((rc = launch_noise(h, which))) return rc;
+    }
     params_changed(h);
     return PYVB_OK;
 }
 
-int pyvb_lds_update_R(pyvb_lds* h) {
-    ENTER(h);
-    int rc = ensure_resid(h, 1);
-    if (rc) return rc;
-    if ((rc = launch_noise(h, 1))) return rc;
-    params_changed(h);
-    return PYVB_OK;
-}
+int pyvb_lds_update_Q(pyvb_lds* h) { ENTER(h); return update_noise(h, 0); }
+int pyvb_lds_update_R(pyvb_lds* h) { ENTER(h); return update_noise(h, 1); }
 
 int pyvb_lds_elbo(pyvb_lds* h) {
     ENTER(h);
     int rc;
     if ((rc = ensure_resid(h, 0))) return rc;
     if ((rc = ensure_resid(h, 1))) return rc;
+    if (h->dense) {
+        if ((rc = ensure_expect(h))) return rc;
+        return launch_elbo_dense(h);
+    }
     return launch_elbo(h);
 }
 
@@ -525,6 +642,14 @@ int pyvb_lds_iterate(pyvb_lds* h, int niters) {
         if ((rc = sweep(h, PYVB_BACKWARD, true))) return rc;
         // A and C are independent given the statistics, and so are Q and R given A and C: the pairs
         // share launches here (same arithmetic as update_A, update_C, update_Q, update_R in turn)
+        if (h->dense) {
+            if ((rc = pyvb_lds_update_columns(h, 0, 0, h->D))) return rc;
+            if ((rc = pyvb_lds_update_columns(h, 1, 0, h->D))) return rc;
+            if ((rc = update_noise(h, 0))) return rc;
+            if ((rc = update_noise(h, 1))) return rc;
+            if ((rc = pyvb_lds_elbo(h))) return rc;
+            continue;
+        }
         if ((rc = ensure_stats(h))) return rc;
         if ((rc = launch_cols(h, 2, 0, h->D, 3))) return rc;       // columns, residuals and noise update in one launch
         params_changed(h);

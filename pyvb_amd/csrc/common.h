@@ -65,8 +65,10 @@ static inline Layout make_layout(int D, int K) {
 struct Priors {          // device pointers, shared by all replicates
     double *x0_mean, *x0_prec, *A_pm, *A_pp, *C_pm, *C_pp, *Q_a0, *Q_b0, *R_a0, *R_b0;
     double *A_obs, *C_obs;   // observed entries of the matrices, [row][col], NaN = not observed
+    double *Q_w0, *R_w0;     // Wishart priors w0: [D][D], [K][K] (v0 in Q_a0[0], R_a0[0]); nodes_todo.py:207-211
     double *A_pld, *C_pld;   // [D] ln det of each column's diagonal prior precision
     double x0_lndet;     // ln det of x0_prec (Constant.lndet, node.py:301-302)
+    double Q_a0_host, R_a0_host, Q_w0_lndet, R_w0_lndet;    // Wishart: v0 and ln det w0 of the two priors
 };
 
 struct EventPair;
@@ -109,6 +111,17 @@ struct pyvb_lds {
     bool mixed_cov;                         // the X_t hold covariances of different parameter generations
     bool timing; KernelTimer timers[PYVB_K_COUNT];
     void* comm; int rank, world;
+    // ---- Wishart noise precisions (nodes_todo.py:205-234): dense expectations, dense column covariances
+    bool dense;                     // noise == PYVB_NOISE_WISHART
+    double *Q_w, *R_w;              // [N][D][D], [N][K][K] posterior qw as the reference stores it (qv is in Q_a / R_a)
+    double *Qbar, *Rbar;            // [N][D][D], [N][K][K] E[Lambda] = qv inv(sym qw)
+    double *lnd;                    // [N][4]: ln det E[Q], ln det E[R], ln det sym(Q_w), ln det sym(R_w)
+    double *QA, *RC;                // [N][D][D] E[Q]<A>, [N][K][D] E[R]<C>
+    double *trA, *trC;              // [N][D] tr(S_i E[Q]), tr(S'_i E[R])
+    double *A_cov, *C_cov;          // [N][D][D][D], [N][D][K][K] column covariances
+    double *SyyF;                   // [N][K][K] sum_t y y^T
+    double *RQ, *RR;                // [N][D][D], [N][K][K]: sum over children of 1/2<xx^T> + 1/2<mu mu^T> - <x><mu>^T
+    bool expect_valid;              // Qbar, Rbar, lnd belong to the current Q_w, R_w
 };
 
 // ---- launchers implemented in the kernel translation units ----
@@ -125,6 +138,14 @@ int launch_resid(pyvb_lds* h, int which);     // 0 = Q, 1 = R
 int launch_noise(pyvb_lds* h, int which);
 int launch_elbo(pyvb_lds* h);
 int launch_elbo_sum(pyvb_lds* h);
+// k_wishart.hip
+int launch_wexpect(pyvb_lds* h);                    // Qbar, Rbar, lnd from Q_w, R_w
+int launch_dense_pre(pyvb_lds* h);                  // QA, RC, trA, trC
+int launch_cols_dense(pyvb_lds* h, int which, int c0, int c1);
+int launch_wresid(pyvb_lds* h, int which, int update);
+int launch_syy_full(pyvb_lds* h);
+int launch_elbo_dense(pyvb_lds* h);
+int launch_colvar_to_cov(pyvb_lds* h);              // A_var/C_var (diagonals) -> A_cov/C_cov
 
 void pyvb_set_error(const char* fmt, ...);
 int pyvb_hip_fail(hipError_t e, const char* what, const char* file, int line);

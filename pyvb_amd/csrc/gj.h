@@ -1,0 +1,79 @@
+// Gauss-Jordan inversion of symmetric positive definite matrices in registers, shared by k_prep.hip and k_wishart.hip.
+#pragma once
+#include "common.h"
+
+// Inverses of NP symmetric positive definite D x D matrices at once, by Gauss-Jordan elimination
+// without pivoting, entirely in registers.  Thread (a = tid/16, b = tid%16) owns the 4 x 4 tile of
+// elements (4a + ra, 4b + cb) of every matrix (padded to 64 x 64 with the identity), v[c][4 ra + cb].
+// Step p of each:  P_ij -= P_ip P_pj / piv  off row and column p, row p *= 1/piv, column p *= -1/piv,
+// pivot -> 1/piv.  A thread needs 4 entries of column p and 4 of row p per step (two 32-byte LDS reads
+// each); the loop over p is unrolled by four so that which of its rows / columns is the pivot one is
+// a compile-time index.  Row p+1, column p+1 and the reciprocal of the next pivot (computed once, by the
+// thread that owns it) are stashed into double-buffered LDS vectors as they are produced, so a step
+// costs one barrier, and the NP independent eliminations interleave to cover its latency.
+// rc: scratch [NP][2][GJ_BUF], pivs [NP][64].  On return v holds the inverses and pivs the pivots,
+// whose logs sum to 2 * sum log diag(chol(P)).
+#define GJ_BUF 136      // row (64), column (64), 1/pivot, padding
+template <int NP>
+__device__ static void gj_inverse(double (&v)[NP][16], int D, int tid, double* rc, double* pivs) {
+    const int a = tid >> 4, b = tid & 15;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        double* row = rc + (c * 2) * GJ_BUF;
+        if (a == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) row[4 * b + cb] = v[c][cb];           // row 0
+        }
+        if (b == 0) {
+#pragma unroll
+            for (int ra = 0; ra < 4; ++ra) row[64 + 4 * a + ra] = v[c][4 * ra];  // column 0
+        }
+        if (tid == 0) row[128] = 1.0 / v[c][0];
+    }
+    int cur = 0;
+    for (int P = 0; 4 * P < D; ++P) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int p = 4 * P + pp;
+            if (p >= D) break;                                  // block-uniform
+            const int P1 = (pp == 3) ? P + 1 : P, q1 = (pp + 1) & 3;    // where row / column p + 1 live
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                const double* row = rc + (c * 2 + cur) * GJ_BUF;
+                const double* col = row + 64;
+                double* nrow = rc + (c * 2 + (cur ^ 1)) * GJ_BUF;
+                double* ncol = nrow + 64;
+                const double d = row[128];
+                if (tid == 0) pivs[c * 64 + p] = row[p];
+                double rj[4], ci[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rj[k] = row[4 * b + k] * d; ci[k] = col[4 * a + k]; }
+#pragma unroll
+                for (int ra = 0; ra < 4; ++ra)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) v[c][4 * ra + cb] -= ci[ra] * rj[cb];
+                if (b == P) {                                   // column p
+#pragma unroll
+                    for (int ra = 0; ra < 4; ++ra) v[c][4 * ra + pp] = -ci[ra] * d;
+                }
+                if (a == P) {                                   // row p
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) v[c][4 * pp + cb] = (b == P && cb == pp) ? d : rj[cb];
+                }
+                if (a == P1) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) nrow[4 * b + cb] = v[c][4 * q1 + cb];
+                }
+                if (b == P1) {
+#pragma unroll
+                    for (int ra = 0; ra < 4; ++ra) ncol[4 * a + ra] = v[c][4 * ra + q1];
+                }
+                if (a == P1 && b == P1) nrow[128] = 1.0 / v[c][4 * q1 + q1];
+            }
+            cur ^= 1;
+        }
+    }
+    __syncthreads();
+}
+

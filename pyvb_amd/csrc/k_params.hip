@@ -65,14 +65,6 @@ __global__ void __launch_bounds__(64) k_noise(ParamArgs a) {
     }
 }
 
-__device__ static double digamma_pos(double x) {
-    double r = 0.0;
-    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
-    const double f = 1.0 / (x * x);
-    const double ser = f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))));
-    return r + log(x) - 0.5 / x - ser;
-}
-
 // log_lower_bound of one Gamma-family entry  nodes_todo.py:149-157 / :199-204
 __device__ static double gamma_llb(double a0, double b0, double qa, double qb) {
     const double Elnx = digamma_pos(qa) - log(qb);

@@ -13,10 +13,13 @@
 // place by Gauss-Jordan elimination without pivoting (they are symmetric positive definite); its
 // pivots are the squares of the Cholesky diagonal, which gives the reference's q_ln_det.
 #include "common.h"
+#include "gj.h"
 
 struct PrepArgs {
     const double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *x0_mean, *x0_prec;
     double *Sigma, *qld, *gains, *scratch;
+    // Wishart noise (DENSE): E[Q] [D][D], E[Q] <A> [D][D], E[R] <C> [K][D], tr(S_i E[Q]) [D], tr(S'_i E[R]) [D] per replicate
+    const double *Qbar, *QA, *RC, *trA, *trC;
     int *warm, *status;
     int N, T, D, K;
     Layout L;
@@ -46,81 +49,6 @@ __device__ __forceinline__ void mm(int wave, int lane, FA a_at, FB b_at, FS stor
 #pragma unroll
             for (int e = 0; e < 4; ++e) store(16 * m + 4 * e + q, 16 * n + r, acc[n][e]);
     }
-}
-
-// Inverses of NP symmetric positive definite D x D matrices at once, by Gauss-Jordan elimination
-// without pivoting, entirely in registers.  Thread (a = tid/16, b = tid%16) owns the 4 x 4 tile of
-// elements (4a + ra, 4b + cb) of every matrix (padded to 64 x 64 with the identity), v[c][4 ra + cb].
-// Step p of each:  P_ij -= P_ip P_pj / piv  off row and column p, row p *= 1/piv, column p *= -1/piv,
-// pivot -> 1/piv.  A thread needs 4 entries of column p and 4 of row p per step (two 32-byte LDS reads
-// each); the loop over p is unrolled by four so that which of its rows / columns is the pivot one is
-// a compile-time index.  Row p+1, column p+1 and the reciprocal of the next pivot (computed once, by the
-// thread that owns it) are stashed into double-buffered LDS vectors as they are produced, so a step
-// costs one barrier, and the NP independent eliminations interleave to cover its latency.
-// rc: scratch [NP][2][GJ_BUF], pivs [NP][64].  On return v holds the inverses and pivs the pivots,
-// whose logs sum to 2 * sum log diag(chol(P)).
-#define GJ_BUF 136      // row (64), column (64), 1/pivot, padding
-template <int NP>
-__device__ static void gj_inverse(double (&v)[NP][16], int D, int tid, double* rc, double* pivs) {
-    const int a = tid >> 4, b = tid & 15;
-#pragma unroll
-    for (int c = 0; c < NP; ++c) {
-        double* row = rc + (c * 2) * GJ_BUF;
-        if (a == 0) {
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) row[4 * b + cb] = v[c][cb];           // row 0
-        }
-        if (b == 0) {
-#pragma unroll
-            for (int ra = 0; ra < 4; ++ra) row[64 + 4 * a + ra] = v[c][4 * ra];  // column 0
-        }
-        if (tid == 0) row[128] = 1.0 / v[c][0];
-    }
-    int cur = 0;
-    for (int P = 0; 4 * P < D; ++P) {
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            const int p = 4 * P + pp;
-            if (p >= D) break;                                  // block-uniform
-            const int P1 = (pp == 3) ? P + 1 : P, q1 = (pp + 1) & 3;    // where row / column p + 1 live
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < NP; ++c) {
-                const double* row = rc + (c * 2 + cur) * GJ_BUF;
-                const double* col = row + 64;
-                double* nrow = rc + (c * 2 + (cur ^ 1)) * GJ_BUF;
-                double* ncol = nrow + 64;
-                const double d = row[128];
-                if (tid == 0) pivs[c * 64 + p] = row[p];
-                double rj[4], ci[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { rj[k] = row[4 * b + k] * d; ci[k] = col[4 * a + k]; }
-#pragma unroll
-                for (int ra = 0; ra < 4; ++ra)
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) v[c][4 * ra + cb] -= ci[ra] * rj[cb];
-                if (b == P) {                                   // column p
-#pragma unroll
-                    for (int ra = 0; ra < 4; ++ra) v[c][4 * ra + pp] = -ci[ra] * d;
-                }
-                if (a == P) {                                   // row p
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) v[c][4 * pp + cb] = (b == P && cb == pp) ? d : rj[cb];
-                }
-                if (a == P1) {
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) nrow[4 * b + cb] = v[c][4 * q1 + cb];
-                }
-                if (b == P1) {
-#pragma unroll
-                    for (int ra = 0; ra < 4; ++ra) ncol[4 * a + ra] = v[c][4 * ra + q1];
-                }
-                if (a == P1 && b == P1) nrow[128] = 1.0 / v[c][4 * q1 + q1];
-            }
-            cur ^= 1;
-        }
-    }
-    __syncthreads();
 }
 
 // max_i sum_j |A_ij|: four threads per row (16 columns each), rows and then wavefronts combined by
@@ -186,7 +114,9 @@ __device__ static int warmup_length(double* W1, double* W2, int LD, int D, int t
     return best;
 }
 
-template <int DT, int KT>
+// DENSE: the noise precisions are Wishart nodes (nodes_todo.py:205-234), their expectations dense matrices; the
+// products with them (k_wishart.hip: k_dense_pre) replace the row scalings of the diagonal case.
+template <int DT, int KT, bool DENSE>
 __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     constexpr int DP = 16 * DT, DS = 4 * DT, KS = 4 * KT, LD = DP + 2;
     // <A> and <C> are MFMA operands straight from global memory (L2-resident, 32 KB each): keeping them in
@@ -205,9 +135,14 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     double* g = a.gains + (size_t)n * L.gains_total;
 
     if (tid < 64) {
-        qbar[tid] = (tid < D) ? a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid] : 0.0;
-        rbar[tid] = (tid < K) ? a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid] : 0.0;
+        qbar[tid] = (!DENSE && tid < D) ? a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid] : 0.0;
+        rbar[tid] = (!DENSE && tid < K) ? a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid] : 0.0;
     }
+    const double* Qd = DENSE ? a.Qbar + (size_t)n * D * D : nullptr;
+    const double* QAd = DENSE ? a.QA + (size_t)n * D * D : nullptr;
+    const double* RCd = DENSE ? a.RC + (size_t)n * K * D : nullptr;
+    auto QA_at = [&](int k, int j) { const double v = QAd[(k < D ? k : D - 1) * D + (j < D ? j : D - 1)]; return (k < D && j < D) ? v : 0.0; };
+    auto RC_at = [&](int k, int j) { const double v = RCd[(k < K ? k : K - 1) * D + (j < D ? j : D - 1)]; return (k < K && j < D) ? v : 0.0; };
     for (int idx = tid; idx < DP * LD; idx += PREP_THREADS) {
         W[idx] = 0.0;
         P[idx] = 0.0;
@@ -218,20 +153,24 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     // traces of the column covariances against the noise expectations (diagonal of node.py:223-227)
     if (tid < D) {
         double tc = 0.0, ta = 0.0;
-        for (int k = 0; k < K; ++k) tc += Cv[tid * K + k] * rbar[k];
-        for (int k = 0; k < D; ++k) ta += Av[tid * D + k] * qbar[k];
+        if constexpr (DENSE) {
+            tc = a.trC[(size_t)n * D + tid]; ta = a.trA[(size_t)n * D + tid];
+        } else {
+            for (int k = 0; k < K; ++k) tc += Cv[tid * K + k] * rbar[k];
+            for (int k = 0; k < D; ++k) ta += Av[tid * D + k] * qbar[k];
+        }
         rowp[tid] = tc; colp[tid] = ta;
     }
     __syncthreads();
     // <C^T R C> -> W;  <C^T R C> + <A^T Q A> -> P     (node.py:213-227)
     mm<DT, DT, KS>(wave, lane,
-                   [&](int i, int k) { return C_at(k, i) * rbar[k]; },
-                   [&](int k, int j) { return C_at(k, j); },
+                   [&](int i, int k) { return DENSE ? C_at(k, i) : C_at(k, i) * rbar[k]; },
+                   [&](int k, int j) { if constexpr (DENSE) return RC_at(k, j); else return C_at(k, j); },
                    [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += rowp[i]; W[i * LD + j] = v; } });
     __syncthreads();
     mm<DT, DT, DS>(wave, lane,
-                   [&](int i, int k) { return A_at(k, i) * qbar[k]; },
-                   [&](int k, int j) { return A_at(k, j); },
+                   [&](int i, int k) { return DENSE ? A_at(k, i) : A_at(k, i) * qbar[k]; },
+                   [&](int k, int j) { if constexpr (DENSE) return QA_at(k, j); else return A_at(k, j); },
                    [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += colp[i]; P[i * LD + j] = W[i * LD + j] + v; } });
     __syncthreads();
 
@@ -246,7 +185,8 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
             const int i = 4 * ta + ra, j = 4 * tb + cb, u = 4 * ra + cb;
             const bool in = i < D && j < D;
             const double mc = in ? W[i * LD + j] : 0.0, mac = in ? P[i * LD + j] : 0.0;
-            const double qd = (in && i == j) ? qbar[i] : 0.0;
+            double qd;
+            if constexpr (DENSE) qd = in ? Qd[i * D + j] : 0.0; else qd = (in && i == j) ? qbar[i] : 0.0;
             const double pad = (!in && i == j) ? 1.0 : 0.0;         // identity in the padding keeps pivots finite
             sig[0][u] = (in ? a.x0_prec[i * D + j] : 0.0) + mac + pad;
             sig[1][u] = qd + mac + pad;
@@ -314,21 +254,21 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
         // Sigma <Q><A>: multiplies the mean of X_{t-1}
         mm<DT, DT, DS>(wave, lane,
                        [&](int i, int k) { return P[i * LD + k]; },
-                       [&](int k, int j) { return qbar[k] * A_at(k, j); },
+                       [&](int k, int j) { if constexpr (DENSE) return QA_at(k, j); else return qbar[k] * A_at(k, j); },
                        [&](int i, int j, double v) {
                            if (i < D && j < D) { g[L.oFn + pos_nat(i, j, DS)] = v; W[i * LD + j] = v; }
                        });
         // Sigma <A>^T<Q>: multiplies the mean of X_{t+1}
         mm<DT, DT, DS>(wave, lane,
                        [&](int i, int k) { return P[i * LD + k]; },
-                       [&](int k, int j) { return A_at(j, k) * qbar[j]; },
+                       [&](int k, int j) { if constexpr (DENSE) return QA_at(j, k); else return A_at(j, k) * qbar[j]; },
                        [&](int i, int j, double v) {
                            if (i < D && j < D) g[L.oBn + pos_nat(i, j, DS)] = v;
                        });
         // Sigma <C>^T<R>: multiplies y_t
         mm<DT, KT, DS>(wave, lane,
                        [&](int i, int k) { return P[i * LD + k]; },
-                       [&](int k, int l) { return C_at(l, k) * rbar[l]; },
+                       [&](int k, int l) { if constexpr (DENSE) return RC_at(l, k); else return C_at(l, k) * rbar[l]; },
                        [&](int i, int l, double v) {
                            if (i < D && l < K) g[L.oGp + pos_perm(i, l, KS)] = v;
                        });
@@ -351,7 +291,8 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
 
 template <int DT, int KT>
 static void launch_prep_t(pyvb_lds* h, const PrepArgs& a) {
-    hipLaunchKernelGGL((k_prep<DT, KT>), dim3(h->N), dim3(PREP_THREADS), 0, h->stream, a);
+    if (h->dense) hipLaunchKernelGGL((k_prep<DT, KT, true>), dim3(h->N), dim3(PREP_THREADS), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_prep<DT, KT, false>), dim3(h->N), dim3(PREP_THREADS), 0, h->stream, a);
 }
 
 int launch_prep(pyvb_lds* h) {
@@ -361,6 +302,7 @@ int launch_prep(pyvb_lds* h) {
     a.x0_mean = h->pri.x0_mean; a.x0_prec = h->pri.x0_prec;
     a.Sigma = h->Sigma_new; a.qld = h->qld_x_new; a.gains = h->gains; a.scratch = h->scratch;
     a.warm = h->warm; a.status = h->status;
+    a.Qbar = h->Qbar; a.QA = h->QA; a.RC = h->RC; a.trA = h->trA; a.trC = h->trC;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.L = h->L;
     {
         TimedLaunch tl(h, PYVB_K_PREP);

@@ -20,6 +20,7 @@
 struct SweepArgs {
     const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
     const double *A_mean, *C_mean;      // the boundary nodes read <A>, <C> themselves
+    const double *QA, *RC;              // Wishart noise: <Q><A> [D][D] and <R><C> [K][D] per replicate (k_wishart.hip), else null
     double* trash;      // [N][256]: where lanes of inactive columns aim their (unconditional) stores
     double* U;          // [N][T][DP]: c_t = F mu_{t-1} + G y_t of the interior nodes, in accumulator order (see MODE)
     double* Sxx;        // [N][DP][DP]: sum over the interior nodes of mu_t mu_t^T, written by the MODE 2 sweep
@@ -40,13 +41,26 @@ struct SweepArgs {
 //   t = T-1 : v = <Q><A> mu_{T-2}       + <C>^T<R> y_{T-1}     mu_{T-1} = Sigma_2 v
 // i.e. qmu = qcov (sum of the m2 messages), as the reference has it.  nb(j) is entry j of the one
 // neighbour's mean, vs 64 doubles of LDS.
+// With Wishart noise the expected precisions are dense: QA = <Q><A>, RC = <R><C> take the place of the scaled rows
+// (<A>^T<Q> = QA^T, <C>^T<R> = RC^T; the expectations are symmetric).
 template <class NB>
 __device__ __forceinline__ double boundary_update(bool first, const double* g, const Layout& L, const double* Am, const double* Cm,
-                                                  int D, int K, int lane, NB nb, const double* y, double* vs) {
+                                                  int D, int K, int lane, NB nb, const double* y, double* vs,
+                                                  const double* QA = nullptr, const double* RC = nullptr) {
     const double* qb = g + L.oqr;
     const double* rb = qb + 64;
     double v = 0.0;
-    if (lane < D) {
+    if (QA) {
+        if (lane < D) {
+            if (first) {
+                v = g[L.ow0 + lane];
+                for (int i = 0; i < D; ++i) v += QA[(size_t)i * D + lane] * nb(i);
+            } else {
+                for (int j = 0; j < D; ++j) v += QA[(size_t)lane * D + j] * nb(j);
+            }
+            for (int k = 0; k < K; ++k) v += RC[(size_t)k * D + lane] * y[k];
+        }
+    } else if (lane < D) {
         if (first) {
             v = g[L.ow0 + lane];
             for (int i = 0; i < D; ++i) v += Am[(size_t)i * D + lane] * (qb[i] * nb(i));
@@ -126,10 +140,12 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     const int t_first = fwd ? 0 : T - 1, t_last = fwd ? T - 1 : 0;
     const double* Am = a.A_mean + (size_t)n * D * D;
     const double* Cm = a.C_mean + (size_t)n * K * D;
+    const double* QAm = a.QA ? a.QA + (size_t)n * D * D : nullptr;
+    const double* RCm = a.RC ? a.RC + (size_t)n * K * D : nullptr;
     if (!SPLIT || ow <= J) {
         const double* xo = Xo + (size_t)(t_first + sgn) * DP;
         const double s = boundary_update(fwd, g, L, Am, Cm, D, K, lane, [&](int j) { return xo[xpos(j)]; },
-                                         Yn + (size_t)t_first * K, vs);
+                                         Yn + (size_t)t_first * K, vs, QAm, RCm);
         if (w == 0 && lane < DP) Xn[(size_t)t_first * DP + xpos(lane)] = (lane < D) ? s : 0.0;
         xs[lane] = (lane < D) ? s : 0.0;
     }
@@ -492,14 +508,14 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
     // wavefront that owns the last interior node
     if (!SPLIT || w == ((Tint > 0) ? (Tint - 1) / Lw : 0)) {
         const double s = boundary_update(!fwd, g, L, Am, Cm, D, K, lane, [&](int j) { return xs[j]; },
-                                         Yn + (size_t)t_last * K, vs);
+                                         Yn + (size_t)t_last * K, vs, QAm, RCm);
         if (lane < DP) Xn[(size_t)t_last * DP + xpos(lane)] = (lane < D) ? s : 0.0;
     }
 }
 
 // Xs[t].update() alone, in place in the current buffer (neighbours as they are now).
 struct StepArgs {
-    double* X; const double* Y; const double* gains; const double *A_mean, *C_mean;
+    double* X; const double* Y; const double* gains; const double *A_mean, *C_mean, *QA, *RC;
     int N, T, D, K, t;
     Layout L;
 };
@@ -517,7 +533,8 @@ __global__ void __launch_bounds__(64) k_step(StepArgs a) {
         __shared__ double vs[64];
         const double* nbr = X + (size_t)(cls == 0 ? 1 : T - 2) * DP;
         const double s = boundary_update(cls == 0, g, L, a.A_mean + (size_t)n * D * D, a.C_mean + (size_t)n * K * D, D, K, lane,
-                                         [&](int j) { return nbr[xpos(j)]; }, y, vs);
+                                         [&](int j) { return nbr[xpos(j)]; }, y, vs,
+                                         a.QA ? a.QA + (size_t)n * D * D : nullptr, a.RC ? a.RC + (size_t)n * K * D : nullptr);
         if (lane < DP) X[(size_t)t * DP + xpos(lane)] = (lane < D) ? s : 0.0;
         return;
     }
@@ -548,6 +565,7 @@ int launch_sweep(pyvb_lds* h, int direction, bool keep_x) {
     a.W = h->W;
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
     a.trash = h->trash; a.U = h->U; a.Sxx = h->sxx; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
+    a.QA = h->dense ? h->QA : nullptr; a.RC = h->dense ? h->RC : nullptr;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
     {
         TimedLaunch tl(h, direction == PYVB_FORWARD ? PYVB_K_SWEEP_FWD : PYVB_K_SWEEP_BWD);
@@ -592,6 +610,7 @@ int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal)
 int launch_step(pyvb_lds* h, int t) {
     StepArgs a;
     a.X = h->X[h->cur]; a.Y = h->Y; a.gains = h->gains; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
+    a.QA = h->dense ? h->QA : nullptr; a.RC = h->dense ? h->RC : nullptr;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.t = t; a.L = h->L;
     TimedLaunch tl(h, PYVB_K_STEP);
     hipLaunchKernelGGL(k_step, dim3(h->N), dim3(64), 0, h->stream, a);

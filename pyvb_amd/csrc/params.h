@@ -46,4 +46,14 @@ __device__ __forceinline__ double bcast(double v, int j) {
     return __hiloint2double(hi, lo);
 }
 
+// digamma for positive and for negative non-integer arguments (recurrence up to x >= 10, then the asymptotic series)
+__device__ static inline double digamma_pos(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    const double ser = f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))));
+    return r + log(x) - 0.5 / x - ser;
+}
+
+
 ParamArgs make_args(pyvb_lds* h);

@@ -11,7 +11,7 @@ from . import _capi as C
 
 __all__ = ["LDSBatch"]
 
-_NOISE = {"diagonal_gamma": C.NOISE_DIAGONAL_GAMMA, "gamma": C.NOISE_GAMMA}
+_NOISE = {"diagonal_gamma": C.NOISE_DIAGONAL_GAMMA, "gamma": C.NOISE_GAMMA, "wishart": C.NOISE_WISHART}
 
 
 def _f64(a, shape, name):
@@ -26,7 +26,7 @@ class LDSBatch(object):
 
     def __init__(self, N, T, D, K, noise="diagonal_gamma", device=0):
         if noise not in _NOISE:
-            raise NotImplementedError("noise precision %r has no HIP path (DiagonalGamma and Gamma do)" % (noise,))
+            raise NotImplementedError("noise precision %r has no HIP path (DiagonalGamma, Gamma and Wishart do)" % (noise,))
         self.N, self.T, self.D, self.K, self.noise, self.device = int(N), int(T), int(D), int(K), noise, int(device)
         h = C.ctypes.c_void_p()
         C.check(C.lib.pyvb_lds_create(C.ctypes.byref(h), self.device, self.N, self.T, self.D, self.K, _NOISE[noise]))
@@ -54,8 +54,13 @@ class LDSBatch(object):
             _f64(pri["x0_mean"], (D,), "x0_mean"), _f64(pri["x0_prec"], (D, D), "x0_prec"),
             _f64(pri["A_prior_mean"], (D, D), "A_prior_mean"), _f64(pri["A_prior_prec"], (D, D), "A_prior_prec"),
             _f64(pri["C_prior_mean"], (K, D), "C_prior_mean"), _f64(pri["C_prior_prec"], (D, K), "C_prior_prec"),
-            bc(pri["Q_a0"], D), bc(pri["Q_b0"], D), bc(pri["R_a0"], K), bc(pri["R_b0"], K),
         ]
+        if self.noise == "wishart":     # Wishart(dim, v0, w0): Q_a0 / R_a0 hold v0, Q_b0 / R_b0 the matrices w0
+            C.check(C.lib.pyvb_lds_set_priors(self._h, *([C.dptr(a) for a in arrs] + [None] * 4)))
+            qw0, rw0 = _f64(pri["Q_b0"], (D, D), "Q_w0"), _f64(pri["R_b0"], (K, K), "R_w0")
+            C.check(C.lib.pyvb_lds_set_wishart_priors(self._h, float(pri["Q_a0"]), C.dptr(qw0), float(pri["R_a0"]), C.dptr(rw0)))
+            return
+        arrs += [bc(pri["Q_a0"], D), bc(pri["Q_b0"], D), bc(pri["R_a0"], K), bc(pri["R_b0"], K)]
         C.check(C.lib.pyvb_lds_set_priors(self._h, *[C.dptr(a) for a in arrs]))
 
     def set_observations(self, Y):
@@ -70,6 +75,29 @@ class LDSBatch(object):
                   ("C_mean", C_mean, (N, K, D)), ("C_colvar", C_colvar, (N, D, K)), ("Q_b", Q_b, (N, D)), ("R_b", R_b, (N, K))]
         arrs = [None if a is None else _f64(a, s, nm) for nm, a, s in shapes]
         C.check(C.lib.pyvb_lds_set_state(self._h, *[C.dptr(a) for a in arrs]))
+
+    def set_wishart_state(self, Q_w=None, R_w=None):
+        """Posterior qw of the Wishart nodes, [N,D,D] and [N,K,K] (nodes_todo.py:216-217 draws a random rank-one one)."""
+        q = None if Q_w is None else _f64(Q_w, (self.N, self.D, self.D), "Q_w")
+        r = None if R_w is None else _f64(R_w, (self.N, self.K, self.K), "R_w")
+        C.check(C.lib.pyvb_lds_set_wishart_state(self._h, C.dptr(q), C.dptr(r)))
+
+    def get_wishart_state(self):
+        N, D, K = self.N, self.D, self.K
+        out = {"Q_v": np.empty(N), "Q_w": np.empty((N, D, D)), "R_v": np.empty(N), "R_w": np.empty((N, K, K))}
+        C.check(C.lib.pyvb_lds_get_wishart_state(self._h, C.dptr(out["Q_v"]), C.dptr(out["Q_w"]), C.dptr(out["R_v"]), C.dptr(out["R_w"])))
+        return out
+
+    def set_column_cov(self, A_cov=None, C_cov=None):
+        a = None if A_cov is None else _f64(A_cov, (self.N, self.D, self.D, self.D), "A_cov")
+        c = None if C_cov is None else _f64(C_cov, (self.N, self.D, self.K, self.K), "C_cov")
+        C.check(C.lib.pyvb_lds_set_column_cov(self._h, C.dptr(a), C.dptr(c)))
+
+    def get_column_cov(self):
+        """Dense posterior covariances of the columns of A ([N,D,D,D]) and C ([N,D,K,K]); Wishart noise only."""
+        A, Cc = np.empty((self.N, self.D, self.D, self.D)), np.empty((self.N, self.D, self.K, self.K))
+        C.check(C.lib.pyvb_lds_get_column_cov(self._h, C.dptr(A), C.dptr(Cc)))
+        return A, Cc
 
     def set_column_observations(self, A_obs=None, C_obs=None):
         """Known entries of A ([D,D]) and C ([K,D]) as (row, col) arrays with NaN where unknown
@@ -190,7 +218,12 @@ class LDSBatch(object):
         b = cls(N, T, D, K, pri.get("noise", "diagonal_gamma"), device)
         b.set_priors(pri)
         b.set_observations(Y)
-        b.set_state(**{k: st0[k] for k in ("X", "A_mean", "A_colvar", "C_mean", "C_colvar", "Q_b", "R_b")})
+        if b.noise == "wishart":        # the compact initial state carries the diagonal of qw in Q_b / R_b
+            b.set_state(**{k: st0[k] for k in ("X", "A_mean", "A_colvar", "C_mean", "C_colvar")})
+            dense = lambda v: np.einsum("nd,de->nde", v, np.eye(v.shape[1])) if v.ndim == 2 else v
+            b.set_wishart_state(dense(st0["Q_b"]), dense(st0["R_b"]))
+        else:
+            b.set_state(**{k: st0[k] for k in ("X", "A_mean", "A_colvar", "C_mean", "C_colvar", "Q_b", "R_b")})
         if pri.get("A_obs") is not None or pri.get("C_obs") is not None:
             b.set_column_observations(pri.get("A_obs"), pri.get("C_obs"))
         return b

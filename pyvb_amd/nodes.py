@@ -343,7 +343,13 @@ class DiagonalGamma(_NoiseNode):                # nodes_todo.py:159-204
 
 
 class Wishart(_NoiseNode):                      # nodes_todo.py:205-234
-    """Constructible, so that graphs can name it; no HIP path yet."""
+    """Wishart(dim, v0, w0): E[Lambda] = qv * inv(qw), qv = v0 + 1/2 per child, qw = w0 + sum over the children of
+    1/2<x x^T> + 1/2<mu mu^T> - <x><mu>^T.  The reference class is unfinished; the device path
+    (pyvb_amd/csrc/k_wishart.hip) keeps its update formula and departs from it where it is broken: the prior is not
+    mutated by update(), the expectation uses the symmetric part of qw, and pass_down_lndet / log_lower_bound exist.
+    As in the reference, the random initial qw is rank one: reading E[Lambda] before the first update() (or before
+    assigning a positive definite qw) raises numpy.linalg.LinAlgError."""
+    qw = _DeviceAttr("qw")
 
     def __init__(self, dim, v0, w0):
         self._init_common(dim)
@@ -363,8 +369,12 @@ class Wishart(_NoiseNode):                      # nodes_todo.py:205-234
         for child in self.children:
             self.qv += 0.5
 
-    def update(self):
-        raise NotImplementedError("Wishart noise has no HIP path (SURVEY.md §8f item 4)")
+    def _sym(self):
+        w = np.asarray(self.qw, dtype=float)
+        return 0.5 * (w + w.T)
 
     def pass_down_Ex(self):
-        return self.qv * np.linalg.inv(self.qw)
+        return self.qv * np.linalg.inv(self._sym())
+
+    def pass_down_lndet(self):                  # not in the reference (Q8): ln det of the expectation, as Gamma does (Q2)
+        return self.shape[0] * np.log(self.qv) - np.linalg.slogdet(self._sym())[1]

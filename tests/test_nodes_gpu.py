@@ -25,8 +25,6 @@ def _rel(a, b):
 def test_example_loop_through_the_node_api(golden):
     from pyvb_amd import nodes
     meta, Y, st0, pri, z = golden
-    if meta["noise"] == "wishart":
-        pytest.skip("no HIP path for Wishart noise")
     if meta["D"] > 16:
         pytest.skip("node-by-node reads are slow for the large fixture; covered by test_gpu_parity")
     g = _golden_module().build_graph(nodes, Y[0], pri, {k: v for k, v in st0.items()})
@@ -54,10 +52,17 @@ def test_example_loop_through_the_node_api(golden):
             assert _rel(Xs[T - 1].qcov, z[tag + "Sigma"][2]) <= RTOL
             if T > 2:
                 assert _rel(Xs[1].qcov, z[tag + "Sigma"][1]) <= RTOL
+            plan = Xs[0]._plan
+            if meta["noise"] == "wishart":      # first update only; no reference lower bound (Q8)
+                assert _rel(Q.qw, z[tag + "Q_b"]) <= RTOL and _rel(R.qw, z[tag + "R_b"]) <= RTOL
+                assert abs(Q.qv - float(z[tag + "Q_a"])) <= 1e-12 and abs(R.qv - float(z[tag + "R_a"])) <= 1e-12
+                assert _rel(np.stack([a.qcov for a in As]), z[tag + "A_cov"]) <= RTOL
+                assert _rel(Q.pass_down_Ex(), float(z[tag + "Q_a"]) * np.linalg.inv(z[tag + "Q_b"])) <= 1e-7
+                assert np.isfinite(Q.log_lower_bound()) and np.isfinite(plan.elbo_parts()).all()
+                continue
             assert _rel(np.asarray(Q.qb, dtype=float), z[tag + "Q_b"]) <= RTOL
             assert _rel(np.asarray(R.qb, dtype=float), z[tag + "R_b"]) <= RTOL
             assert _rel(np.asarray(Q.qa, dtype=float), z[tag + "Q_a"]) <= RTOL
-            plan = Xs[0]._plan
             parts = plan.elbo_parts()
             ref = z[tag + "elbo_parts"]
             assert abs(parts.sum() - ref.sum()) <= RTOL * abs(ref.sum())
