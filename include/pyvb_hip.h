@@ -185,6 +185,25 @@ int pyvb_pca_iterate(pyvb_pca* h, int niters);
 int pyvb_pca_sync(pyvb_pca* h);
 int pyvb_pca_comm_init(pyvb_pca* h, const char id[128], int rank, int world);
 
+/* ------------------------------------------------------------------------------------------------
+ * Generic graphs, node by node (network.py:40-56 over arbitrary node lists; src/tests.py:9-202): every posterior,
+ * constant, message and temporary of one graph lives in a device arena of doubles; the work of one reference method --
+ *   Gaussian.update gaussian.py:102-134, Gaussian.log_lower_bound :136-151, Gaussian.pass_up_m1_m2 :179-183,
+ *   Addition.pass_up_m1_m2 / pass_down_* node.py:95-129, Multiplication.* node.py:182-276, hstack.* nodes_todo.py:33-62,
+ *   Gamma.* :125-157, DiagonalGamma.* :183-204, Wishart.* :224-234, Constant.* node.py:304-311
+ * -- is a TAPE of small dense operations on arena offsets (records of 8 int32: opcode, dst, a, b, m, n, p, flags; the
+ * opcodes are documented in pyvb_amd/csrc/k_tape.hip and mirrored by pyvb_amd/generic.py), interpreted by one workgroup
+ * per launch.  Tapes are uploaded once and replayed (the graph is static). */
+typedef struct pyvb_graph pyvb_graph;
+int pyvb_graph_create(pyvb_graph** out, int device, size_t arena_doubles);
+int pyvb_graph_destroy(pyvb_graph* g);
+int pyvb_graph_write(pyvb_graph* g, size_t offset, const double* src, size_t n);
+int pyvb_graph_read(pyvb_graph* g, size_t offset, double* dst, size_t n);
+int pyvb_graph_tape_create(pyvb_graph* g, const int* ops, int nops, int* tape_id);
+int pyvb_graph_tape_run(pyvb_graph* g, int tape_id);
+int pyvb_graph_tape_destroy(pyvb_graph* g, int tape_id);
+int pyvb_graph_sync(pyvb_graph* g);
+
 #ifdef __cplusplus
 }
 #endif

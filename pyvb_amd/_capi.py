@@ -61,6 +61,14 @@ SIGNATURES = {
     "pyvb_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "pyvb_lds_comm_init": (ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "pyvb_lds_comm_destroy": (ctypes.c_int, [_h]),
+    "pyvb_graph_create": (ctypes.c_int, [ctypes.POINTER(_h), ctypes.c_int, ctypes.c_size_t]),
+    "pyvb_graph_destroy": (ctypes.c_int, [_h]),
+    "pyvb_graph_write": (ctypes.c_int, [_h, ctypes.c_size_t, _dp, ctypes.c_size_t]),
+    "pyvb_graph_read": (ctypes.c_int, [_h, ctypes.c_size_t, _dp, ctypes.c_size_t]),
+    "pyvb_graph_tape_create": (ctypes.c_int, [_h, _ip, ctypes.c_int, _ip]),
+    "pyvb_graph_tape_run": (ctypes.c_int, [_h, ctypes.c_int]),
+    "pyvb_graph_tape_destroy": (ctypes.c_int, [_h, ctypes.c_int]),
+    "pyvb_graph_sync": (ctypes.c_int, [_h]),
     "pyvb_pca_create": (ctypes.c_int, [ctypes.POINTER(_h), ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_long]),
     "pyvb_pca_destroy": (ctypes.c_int, [_h]),
     "pyvb_pca_set_priors": (ctypes.c_int, [_h, _dp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double]),

@@ -170,9 +170,33 @@ class LDSPlan(object):
             return float(self.elbo_parts()[4])
         if kind == "r":
             return float(self.elbo_parts()[5])
-        raise NotImplementedError(
-            "per-node log_lower_bound() of the %d state/output/column nodes is not split out on the device; "
-            "use Network.learn / Network.llb or plan.elbo_parts() (sums per node class)" % (2 * self.T + 2 * self.D))
+        # a single state / output / column node: the fused kernels only form class sums, so the term is evaluated by the
+        # generic tape path on a mirror of the current state (gaussian.py:136-151)
+        return self.mirror().node_llb(node)
+
+    def mirror(self):
+        """A generic (node-by-node) plan holding a copy of this plan's current posteriors: serves single messages
+        (pass_up_m1_m2) and single lower-bound terms, which the fused kernels never materialise."""
+        self.flush()
+        if getattr(self, "_mirror", None) is None or self._mirror_of is not self.cache or self.cache is None:
+            from .generic import GenericPlan
+            c = self._pull()
+            for nd in self.Xs + self.As + self.Cs:
+                for name in ("qmu", "qcov"):
+                    nd.__dict__["_h_" + name] = self.read(nd, name)
+                try:
+                    nd.__dict__["_h_q_ln_det"] = self.read(nd, "q_ln_det")
+                except Exception:
+                    pass
+            if self.kind == "wishart":
+                self.Q.__dict__["_h_qw"], self.R.__dict__["_h_qw"] = self.read(self.Q, "qw"), self.read(self.R, "qw")
+            else:
+                self.Q.__dict__["_h_qb"], self.R.__dict__["_h_qb"] = self.read(self.Q, "qb"), self.read(self.R, "qb")
+            if getattr(self, "_mirror", None) is not None:
+                self._mirror.ex and self._mirror.ex.close()
+            self._mirror = GenericPlan(self.Xs[0], adopt=False)
+            self._mirror_of = c
+        return self._mirror
 
 
 # -------------------------------------------------------------------------------------------------
@@ -304,10 +328,16 @@ def describe(start):
 
 
 def bind(node):
+    """Give the graph `node` belongs to an execution plan: the fused LDS or VB-PCA plan if it is one of those graphs,
+    else the generic node-by-node plan (pyvb_amd/generic.py).  All three run on the device."""
     comp = _component(node)
-    if any(isinstance(n, N.Addition) for n in comp):
-        return PCAPlan(**describe_pca(node))
-    return LDSPlan(**describe(node))
+    try:
+        if any(isinstance(n, N.Addition) for n in comp):
+            return PCAPlan(**describe_pca(node))
+        return LDSPlan(**describe(node))
+    except NotImplementedError:
+        from .generic import GenericPlan
+        return GenericPlan(node)
 
 
 # -------------------------------------------------------------------------------------------------
@@ -472,4 +502,20 @@ class PCAPlan(object):
             return float(parts[3])
         if kind == "beta":
             return float(parts[4])
-        raise NotImplementedError("per-node log_lower_bound() is summed per node class on the device: use Network.learn / plan.elbo_parts()")
+        return self.mirror().node_llb(node)
+
+    def mirror(self):
+        """See LDSPlan.mirror."""
+        self.flush()
+        if getattr(self, "_mirror", None) is None or self._mirror_of is not self.cache or self.cache is None:
+            from .generic import GenericPlan
+            c = self._pull()
+            for nd in self.Ws + self.Zs + self.Xs + [self.Mu]:
+                for name in ("qmu", "qcov"):
+                    nd.__dict__["_h_" + name] = self.read(nd, name)
+            self.Beta.__dict__["_h_qb"] = self.read(self.Beta, "qb")
+            if getattr(self, "_mirror", None) is not None:
+                self._mirror.ex and self._mirror.ex.close()
+            self._mirror = GenericPlan(self.W, adopt=False)
+            self._mirror_of = c
+        return self._mirror

@@ -1,0 +1,282 @@
+// Generic per-node path: graphs the recognisers (pyvb_amd/_recognise.py) have no fused plan for run node by node.
+// Every quantity of such a graph -- posterior parameters, constants, messages, temporaries -- lives in one device
+// arena of doubles; what a node's update(), pass_up_m1_m2(), pass_down_*() or log_lower_bound() computes in the reference
+// (gaussian.py:102-183, node.py:95-129,182-276, nodes_todo.py:33-62,125-157,183-204,224-234) is emitted by the host
+// (pyvb_amd/generic.py) as a TAPE of small dense operations on arena offsets, and one workgroup interprets the tape:
+// one launch per node update, or per whole Network.learn iteration, instead of one launch per numpy call.
+// The matrices of this path are tiny (dimensions of single nodes); the interpreter favours generality over speed.
+#include "common.h"
+#include <vector>
+
+enum {
+    T_NOP = 0,
+    T_COPY2D = 1,     // dst[i*p0 + j] = a[i*p1 + j]                         i < m, j < n       (p0, p1: leading dimensions)
+    T_FILL = 2,       // dst[i*p0 + j] = (flags & 1) ? (i == j) : 0
+    T_AXPBY = 3,      // dst = alpha a + beta b (m x n, contiguous); alpha = arena[p0], beta = arena[p1]; b < 0: dst = alpha a
+    T_GEMM = 4,       // dst[m x n] (+)= op(a)[m x k] op(b)[k x n]; flags 1: a^T, 2: b^T, 4: accumulate, 8: subtract
+    T_SCALE = 5,      // dst = a * s (flags 0) or a / s (flags 1), s = arena[b]; m x n
+    T_TRACE = 6,      // dst[0] (+)= tr(a[m x m]) (flags 4: accumulate)
+    T_DIAG = 7,       // flags 0: dst[m] = diag(a[m x m]); flags 1: dst[m x m] = diag(a[m])
+    T_CHOLINV = 8,    // dst[m x m] = inverse of the s.p.d. a[m x m]; arena[b] = 0.5 / sum log diag chol (quirk Q1), arena[b+1] = sum log diag chol; p0 = scratch (2 m^2)
+    T_DOT = 9,        // dst[0] (+)= sum_ij a_ij b_ij (m x n); flags 4: accumulate
+    T_UNARY = 10,     // dst = f(a) elementwise, m x n; flags: 0 log, 1 digamma, 2 lgamma, 3 reciprocal, 4 negate, 5 exp
+    T_GATHER = 11,    // dst[i*n + j] = a[r_i * p0 + c_j], r = (int)arena[b + i], c = (int)arena[p1 + j]
+    T_SCATTER = 12,   // dst[r_i * p0 + c_j] (+)= a[i*n + j]  (flags 4: accumulate)
+    T_MUL = 13,       // dst = a .* b elementwise, m x n
+};
+
+struct TapeArgs { double* arena; const int* ops; int nops; int* status; };
+
+#define TAPE_THREADS 256
+
+__device__ static double tape_digamma(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    const double ser = f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))));
+    return r + log(x) - 0.5 / x - ser;
+}
+
+__global__ void __launch_bounds__(TAPE_THREADS) k_tape(TapeArgs t) {
+    __shared__ double red[TAPE_THREADS];
+    double* A = t.arena;
+    const int tid = threadIdx.x;
+    for (int pc = 0; pc < t.nops; ++pc) {
+        const int* o = t.ops + 8 * pc;
+        const int op = o[0], m = o[4], n = o[5], flags = o[7];
+        double* dst = A + o[1];
+        const double* a = A + o[2];
+        const double* b = A + (o[3] < 0 ? 0 : o[3]);
+        switch (op) {
+        case T_COPY2D:
+            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[(idx / n) * o[3] + idx % n] = a[(idx / n) * o[6] + idx % n];
+            break;
+        case T_FILL:
+            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[(idx / n) * o[3] + idx % n] = ((flags & 1) && idx / n == idx % n) ? 1.0 : 0.0;
+            break;
+        case T_AXPBY: {
+            const double al = A[o[6]];
+            if (o[3] < 0) { for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[idx] = al * a[idx]; }
+            else { const double be = A[flags]; for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[idx] = al * a[idx] + be * b[idx]; }
+            break; }
+        case T_GEMM: {
+            const int k = o[6];
+            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) {
+                const int i = idx / n, j = idx % n;
+                double s = 0.0;
+                for (int l = 0; l < k; ++l) s += ((flags & 1) ? a[l * m + i] : a[i * k + l]) * ((flags & 2) ? b[j * k + l] : b[l * n + j]);
+                if (flags & 8) s = -s;
+                dst[idx] = (flags & 4) ? dst[idx] + s : s;
+            }
+            break; }
+        case T_SCALE: {
+            const double s = A[o[3]];
+            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[idx] = (flags & 1) ? a[idx] / s : a[idx] * s;
+            break; }
+        case T_TRACE: case T_DOT: {
+            double s = 0.0;
+            if (op == T_TRACE) { for (int i = tid; i < m; i += TAPE_THREADS) s += a[i * m + i]; }
+            else { for (int idx = tid; idx < m * n; idx += TAPE_THREADS) s += a[idx] * b[idx]; }
+            red[tid] = s;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+                for (int i = 0; i < TAPE_THREADS; ++i) tot += red[i];
+                dst[0] = (flags & 4) ? dst[0] + tot : tot;
+            }
+            break; }
+        case T_DIAG:
+            if (flags & 1) { for (int idx = tid; idx < m * m; idx += TAPE_THREADS) dst[idx] = (idx / m == idx % m) ? a[idx / m] : 0.0; }
+            else { for (int i = tid; i < m; i += TAPE_THREADS) dst[i] = a[i * m + i]; }
+            break;
+        case T_CHOLINV: {
+            // L (lower, row major) in scratch, column by column; then X = L^{-1} by forward substitution, one thread per
+            // column of the identity; then dst = X^T X.  (cho_factor / cho_solve of gaussian.py:118-119.)
+            double* L = A + o[6];
+            double* X = L + m * m;
+            for (int idx = tid; idx < m * m; idx += TAPE_THREADS) L[idx] = a[idx];
+            __syncthreads();
+            bool bad = false;
+            for (int j = 0; j < m; ++j) {
+                if (tid == 0) {
+                    const double piv = L[j * m + j];
+                    if (!(piv > 0.0)) { atomicOr(t.status, 1); L[j * m + j] = nan(""); }
+                    else L[j * m + j] = sqrt(piv);
+                }
+                __syncthreads();
+                const double d = L[j * m + j];
+                for (int i = j + 1 + tid; i < m; i += TAPE_THREADS) L[i * m + j] /= d;
+                __syncthreads();
+                const int rem = m - j - 1;                      // trailing update, lower triangle
+                for (int idx = tid; idx < rem * rem; idx += TAPE_THREADS) {
+                    const int i = j + 1 + idx / rem, c = j + 1 + idx % rem;
+                    if (c <= i) L[i * m + c] -= L[i * m + j] * L[c * m + j];
+                }
+                __syncthreads();
+            }
+            (void)bad;
+            if (tid == 0) {
+                double s = 0.0;
+                for (int j = 0; j < m; ++j) s += log(L[j * m + j]);
+                A[o[3]] = 0.5 / s;          // gaussian.py:120: .5 / np.log(np.prod(np.diag(chol)))
+                A[o[3] + 1] = s;
+            }
+            for (int c = tid; c < m; c += TAPE_THREADS) {       // X[:, c] = L^{-1} e_c
+                for (int i = 0; i < m; ++i) {
+                    double s = (i == c) ? 1.0 : 0.0;
+                    for (int l = c; l < i; ++l) s -= L[i * m + l] * X[l * m + c];
+                    X[i * m + c] = (i < c) ? 0.0 : s / L[i * m + i];
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < m * m; idx += TAPE_THREADS) {
+                const int i = idx / m, j = idx % m;
+                double s = 0.0;
+                for (int l = (i > j ? i : j); l < m; ++l) s += X[l * m + i] * X[l * m + j];
+                dst[idx] = s;
+            }
+            break; }
+        case T_UNARY:
+            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) {
+                const double x = a[idx];
+                double y;
+                switch (flags) {
+                    case 0: y = log(x); break;
+                    case 1: y = tape_digamma(x); break;
+                    case 2: y = lgamma(x); break;
+                    case 3: y = 1.0 / x; break;
+                    case 4: y = -x; break;
+                    default: y = exp(x); break;
+                }
+                dst[idx] = y;
+            }
+            break;
+        case T_GATHER:
+            for (int idx = tid; idx < m * n; idx += TAPE_THREADS)
+                dst[idx] = a[(int)A[o[3] + idx / n] * o[6] + (int)A[flags + idx % n]];
+            break;
+        case T_SCATTER:
+            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) {
+                double* p = dst + (int)A[o[3] + idx / n] * o[6] + (int)A[(flags & ~0x40000000) + idx % n];
+                *p = (flags & 0x40000000) ? *p + a[idx] : a[idx];
+            }
+            break;
+        case T_MUL:
+            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[idx] = a[idx] * b[idx];
+            break;
+        default: break;
+        }
+        __syncthreads();
+    }
+}
+
+struct pyvb_graph {
+    int device;
+    hipStream_t stream;
+    double* arena; size_t arena_n;
+    int* status;
+    std::vector<int*> tapes; std::vector<int> tape_len;
+};
+
+#define ARGCHK(cond, msg) do { if (!(cond)) { pyvb_set_error("%s", msg); return PYVB_E_ARG; } } while (0)
+
+extern "C" {
+
+int pyvb_graph_create(pyvb_graph** out, int device, size_t arena_doubles) {
+    ARGCHK(out && arena_doubles > 0 && arena_doubles < ((size_t)1 << 31), "bad arguments (the arena is addressed with 32-bit offsets)");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    ARGCHK(device >= 0 && device < ndev, "no such device");
+    HIPCHK(hipSetDevice(device));
+    pyvb_graph* g = new pyvb_graph();
+    g->device = device; g->arena_n = arena_doubles; g->arena = nullptr; g->status = nullptr; g->stream = nullptr;
+    hipError_t e = hipStreamCreate(&g->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->arena, arena_doubles * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(g->arena, 0, arena_doubles * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->status, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(g->status, 0, sizeof(int));
+    if (e != hipSuccess) { pyvb_graph_destroy(g); return pyvb_hip_fail(e, "pyvb_graph_create", __FILE__, __LINE__); }
+    *out = g;
+    return PYVB_OK;
+}
+
+int pyvb_graph_destroy(pyvb_graph* g) {
+    if (!g) return PYVB_OK;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (int* t : g->tapes) if (t) (void)hipFree(t);
+    if (g->arena) (void)hipFree(g->arena);
+    if (g->status) (void)hipFree(g->status);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    return PYVB_OK;
+}
+
+int pyvb_graph_write(pyvb_graph* g, size_t offset, const double* src, size_t n) {
+    ARGCHK(g && src && offset + n <= g->arena_n, "write outside the arena");
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipMemcpyAsync(g->arena + offset, src, n * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));        // src is the caller's buffer
+    return PYVB_OK;
+}
+
+int pyvb_graph_sync(pyvb_graph* g) {
+    ARGCHK(g, "handle is NULL");
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    int st = 0;
+    HIPCHK(hipMemcpy(&st, g->status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        pyvb_set_error("a posterior precision was not positive definite (numpy.linalg.LinAlgError in the reference)");
+        HIPCHK(hipMemset(g->status, 0, sizeof(int)));
+        return PYVB_E_LINALG;
+    }
+    return PYVB_OK;
+}
+
+int pyvb_graph_read(pyvb_graph* g, size_t offset, double* dst, size_t n) {
+    ARGCHK(g && dst && offset + n <= g->arena_n, "read outside the arena");
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipMemcpyAsync(dst, g->arena + offset, n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    return pyvb_graph_sync(g);
+}
+
+/* A tape: nops records of 8 int32 (opcode, dst, a, b, m, n, p, flags; see the enum at the top of k_tape.hip).  Offsets are
+ * checked against the arena here, once, so the kernel does not have to. */
+int pyvb_graph_tape_create(pyvb_graph* g, const int* ops, int nops, int* tape_id) {
+    ARGCHK(g && ops && nops > 0 && tape_id, "bad arguments");
+    HIPCHK(hipSetDevice(g->device));
+    for (int i = 0; i < nops; ++i) {
+        const int* o = ops + 8 * i;
+        ARGCHK(o[0] >= T_NOP && o[0] <= T_MUL, "unknown opcode in tape");
+        ARGCHK(o[1] >= 0 && (size_t)o[1] < g->arena_n && o[2] >= 0 && (size_t)o[2] < g->arena_n && (o[3] < 0 || (size_t)o[3] < g->arena_n || o[0] == T_COPY2D || o[0] == T_FILL),
+               "tape operand outside the arena");
+        ARGCHK(o[4] >= 0 && o[5] >= 0, "negative dimension in tape");
+    }
+    int* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)nops * 8 * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(d, ops, (size_t)nops * 8 * sizeof(int), hipMemcpyHostToDevice, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->tapes.push_back(d); g->tape_len.push_back(nops);
+    *tape_id = (int)g->tapes.size() - 1;
+    return PYVB_OK;
+}
+
+int pyvb_graph_tape_run(pyvb_graph* g, int tape_id) {
+    ARGCHK(g && tape_id >= 0 && tape_id < (int)g->tapes.size() && g->tapes[tape_id], "no such tape");
+    HIPCHK(hipSetDevice(g->device));
+    TapeArgs t; t.arena = g->arena; t.ops = g->tapes[tape_id]; t.nops = g->tape_len[tape_id]; t.status = g->status;
+    hipLaunchKernelGGL(k_tape, dim3(1), dim3(TAPE_THREADS), 0, g->stream, t);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+int pyvb_graph_tape_destroy(pyvb_graph* g, int tape_id) {
+    ARGCHK(g && tape_id >= 0 && tape_id < (int)g->tapes.size(), "no such tape");
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (g->tapes[tape_id]) { (void)hipFree(g->tapes[tape_id]); g->tapes[tape_id] = nullptr; }
+    return PYVB_OK;
+}
+
+}  // extern "C"

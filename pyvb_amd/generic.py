@@ -1,0 +1,787 @@
+"""Generic per-node execution: graphs without a fused plan (pyvb_amd/_recognise.py knows the LDS and the VB-PCA
+graph) run node by node on the device, the way the reference runs them on the CPU.
+
+Every posterior, constant, message and temporary of the graph lives in one device arena of doubles
+(include/pyvb_hip.h: pyvb_graph_*).  The methods of the reference's node classes are restated here as EMITTERS: where
+the reference computes with numpy, an emitter appends records to a tape -- small dense operations on arena offsets --
+and returns references to the results.  A tape is uploaded once and replayed: `node.update()` is one launch of the tape
+interpreter (pyvb_amd/csrc/k_tape.hip), `Network.learn` one launch per iteration.  Nothing is computed on the host: this
+module only decides WHICH operations run (the graph walk the reference does at every call, done once per node here).
+
+Reference methods restated (paths relative to /root/reference/src/pyvb/nodes/):
+    Gaussian.update                      gaussian.py:102-134     -> GenericPlan._emit_update_gaussian
+    Gaussian.log_lower_bound             gaussian.py:136-151     -> _emit_llb_gaussian
+    Gaussian.pass_up_m1_m2               gaussian.py:179-183     -> _pass_up (Gaussian branch)
+    Addition.pass_up_m1_m2 / pass_down_* node.py:95-129          -> _pass_up / _ex / _exxt (Addition branches)
+    Multiplication.pass_up_m1_m2         node.py:182-232         -> _pass_up (Multiplication branch)
+    Multiplication.pass_down_Ex / ExxT   node.py:235-276         -> _ex / _exxt
+    hstack.pass_down_* / pass_up_m1_m2   nodes_todo.py:33-62     -> _ex / _exxt / _pass_up (hstack branch)
+    Gamma.update / lndet / llb           nodes_todo.py:130-157   -> _emit_update_noise / _lndet / _emit_llb_noise
+    DiagonalGamma.*                      nodes_todo.py:187-204
+    Wishart.update / pass_down_Ex        nodes_todo.py:228-234   (deviations: pyvb_amd/csrc/k_wishart.hip header)
+    Constant.*                           node.py:304-311
+Deviations from the reference, all where it is broken: a Multiplication whose left operand is a
+Constant matrix or a row vector returns a proper (m1, m2) pair (Q3; node.py:209,212 return a bare matrix, which
+Gaussian.update then mis-indexes) and its pass_down_ExxT uses A <BB^T> A^T (node.py:258 has a typo and no transpose, Q6).
+"""
+import numpy as np
+
+from . import nodes as N
+
+(T_NOP, T_COPY2D, T_FILL, T_AXPBY, T_GEMM, T_SCALE, T_TRACE, T_DIAG, T_CHOLINV, T_DOT, T_UNARY, T_GATHER, T_SCATTER,
+ T_MUL) = range(14)
+U_LOG, U_DIGAMMA, U_LGAMMA, U_RECIP, U_NEG, U_EXP = range(6)
+LN2PI = float(np.log(2.0 * np.pi))
+
+CONST_CAP = 8192          # doubles reserved for the constant pool at the start of the arena
+
+
+class Ref(object):
+    """An m x n row-major block of the arena."""
+    __slots__ = ("off", "m", "n")
+
+    def __init__(self, off, m, n):
+        self.off, self.m, self.n = int(off), int(m), int(n)
+
+    @property
+    def size(self):
+        return self.m * self.n
+
+    def elem(self, i, j=0):
+        return Ref(self.off + i * self.n + j, 1, 1)
+
+
+class Tape(object):
+    """Records of one tape plus a bump allocator for its temporaries."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.ops = []
+        self.top = plan.temp_base
+
+    def tmp(self, m, n=1):
+        r = Ref(self.top, m, n)
+        self.top += max(1, m * n)
+        self.plan.temp_high = max(self.plan.temp_high, self.top)
+        return r
+
+    def emit(self, op, dst, a=0, b=0, m=0, n=0, p=0, flags=0):
+        self.ops.append((op, int(dst), int(a), int(b), int(m), int(n), int(p), int(flags)))
+
+    # -- elementary operations; all return a Ref ------------------------------------------------
+    def const(self, v):
+        return self.plan.const(v)
+
+    def copy(self, a, dst=None):
+        dst = dst or self.tmp(a.m, a.n)
+        self.emit(T_COPY2D, dst.off, a.off, dst.n, a.m, a.n, a.n)
+        return dst
+
+    def eye(self, m):
+        r = self.tmp(m, m)
+        self.emit(T_FILL, r.off, 0, m, m, m, 0, 1)
+        return r
+
+    def zeros(self, m, n=1):
+        r = self.tmp(m, n)
+        self.emit(T_FILL, r.off, 0, n, m, n, 0, 0)
+        return r
+
+    def axpby(self, alpha, a, beta=None, b=None, dst=None):
+        """alpha a + beta b; alpha, beta: python floats or 1 x 1 Refs."""
+        al = alpha if isinstance(alpha, Ref) else self.const(alpha)
+        dst = dst or self.tmp(a.m, a.n)
+        if b is None:
+            self.emit(T_AXPBY, dst.off, a.off, -1, a.m, a.n, al.off, 0)
+        else:
+            assert (a.m, a.n) == (b.m, b.n), "shape mismatch in axpby: %r vs %r" % ((a.m, a.n), (b.m, b.n))
+            be = beta if isinstance(beta, Ref) else self.const(beta)
+            self.emit(T_AXPBY, dst.off, a.off, b.off, a.m, a.n, al.off, be.off)
+        return dst
+
+    def add(self, a, b):
+        return self.axpby(1.0, a, 1.0, b)
+
+    def sub(self, a, b):
+        return self.axpby(1.0, a, -1.0, b)
+
+    def gemm(self, a, b, ta=False, tb=False, dst=None, acc=False, neg=False):
+        m, k = (a.n, a.m) if ta else (a.m, a.n)
+        k2, n = (b.n, b.m) if tb else (b.m, b.n)
+        assert k == k2, "inner dimensions differ: %d vs %d" % (k, k2)
+        dst = dst or self.tmp(m, n)
+        self.emit(T_GEMM, dst.off, a.off, b.off, m, n, k, (1 if ta else 0) | (2 if tb else 0) | (4 if acc else 0) | (8 if neg else 0))
+        return dst
+
+    def transpose(self, a):
+        if a.m == 1 or a.n == 1:
+            return Ref(a.off, a.n, a.m)
+        return self.gemm(a, self.eye(a.m), ta=True)
+
+    def scale(self, a, s, divide=False, dst=None):
+        """a * s (or a / s) with s a 1 x 1 Ref (any arena element) or a python float."""
+        s = s if isinstance(s, Ref) else self.const(s)
+        dst = dst or self.tmp(a.m, a.n)
+        self.emit(T_SCALE, dst.off, a.off, s.off, a.m, a.n, 0, 1 if divide else 0)
+        return dst
+
+    def trace(self, a):
+        assert a.m == a.n
+        r = self.tmp(1, 1)
+        self.emit(T_TRACE, r.off, a.off, 0, a.m, a.m, 0, 0)
+        return r
+
+    def dot(self, a, b):
+        assert a.size == b.size
+        r = self.tmp(1, 1)
+        self.emit(T_DOT, r.off, a.off, b.off, a.m, a.n, 0, 0)
+        return r
+
+    def total(self, a):
+        return self.dot(a, self.plan.ones(a.size))
+
+    def diag_of(self, a):
+        r = self.tmp(a.m, 1)
+        self.emit(T_DIAG, r.off, a.off, 0, a.m, a.m, 0, 0)
+        return r
+
+    def diag_matrix(self, v):
+        r = self.tmp(v.size, v.size)
+        self.emit(T_DIAG, r.off, v.off, 0, v.size, v.size, 0, 1)
+        return r
+
+    def cholinv(self, a, dst=None, out2=None):
+        """(inverse, [q_ln_det (quirk Q1), sum log diag chol]) of a symmetric positive definite block."""
+        assert a.m == a.n
+        dst = dst or self.tmp(a.m, a.m)
+        out2 = out2 or self.tmp(2, 1)
+        scratch = self.tmp(2 * a.m * a.m, 1)
+        self.emit(T_CHOLINV, dst.off, a.off, out2.off, a.m, a.m, scratch.off, 0)
+        return dst, out2
+
+    def unary(self, a, f):
+        r = self.tmp(a.m, a.n)
+        self.emit(T_UNARY, r.off, a.off, 0, a.m, a.n, 0, f)
+        return r
+
+    def mul(self, a, b):
+        assert a.size == b.size
+        r = self.tmp(a.m, a.n)
+        self.emit(T_MUL, r.off, a.off, b.off, a.m, a.n, 0, 0)
+        return r
+
+    def gather(self, a, rows, cols):
+        """a.take(rows, 0).take(cols, 1); rows / cols: Refs to index vectors stored as doubles."""
+        r = self.tmp(rows.size, cols.size)
+        self.emit(T_GATHER, r.off, a.off, rows.off, rows.size, cols.size, a.n, cols.off)
+        return r
+
+    def lin(self, c0, terms):
+        """c0 + sum_i c_i * ref_i for scalars (1 x 1 Refs); c_i python floats."""
+        acc = self.copy(self.const(c0))
+        for c, r in terms:
+            self.axpby(1.0, acc, c, r, dst=acc)
+        return acc
+
+    def array(self):
+        return np.array(self.ops, dtype=np.int32).reshape(-1, 8)
+
+
+class DeviceExecutor(object):
+    """Arena + tape runner behind GenericPlan: binds include/pyvb_hip.h's pyvb_graph_*.  (The CPU tests substitute the
+    numpy restatement of the interpreter, oracle/tape_ref.py, through GenericPlan(executor_factory=...); the product
+    has no such path.)"""
+
+    def __init__(self, arena_doubles, device=0):
+        from . import _capi as C
+        self.C = C
+        h = C.ctypes.c_void_p()
+        C.check(C.lib.pyvb_graph_create(C.ctypes.byref(h), int(device), int(arena_doubles)))
+        self._h = h
+        self.size = int(arena_doubles)
+
+    def write(self, off, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64).reshape(-1)
+        if a.size:
+            self.C.check(self.C.lib.pyvb_graph_write(self._h, int(off), self.C.dptr(a), a.size))
+
+    def read(self, off, n):
+        out = np.empty(int(n))
+        if n:
+            self.C.check(self.C.lib.pyvb_graph_read(self._h, int(off), self.C.dptr(out), int(n)))
+        return out
+
+    def tape(self, ops):
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        tid = self.C.ctypes.c_int()
+        self.C.check(self.C.lib.pyvb_graph_tape_create(self._h, ops.ctypes.data_as(self.C._ip), int(ops.shape[0]), self.C.ctypes.byref(tid)))
+        return tid.value
+
+    def run(self, tid):
+        self.C.check(self.C.lib.pyvb_graph_tape_run(self._h, int(tid)))
+
+    def sync(self):
+        self.C.check(self.C.lib.pyvb_graph_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.C.lib.pyvb_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# What GenericPlan runs its tapes on.  The product has exactly one: the device.  tests/test_generic_cpu.py swaps in the
+# numpy restatement of the interpreter (oracle/tape_ref.py) to check the emitters without a GPU.
+EXECUTOR_FACTORY = DeviceExecutor
+
+
+def _component(start):
+    from ._recognise import _component as comp
+    return comp(start)
+
+
+class GenericPlan(object):
+    generic = True
+
+    def __init__(self, start, executor_factory=None, adopt=True):
+        self.nodes = _component(start)
+        self.stale = False
+        self.temp_high = 0
+        self._consts, self._const_vals, self._const_dirty = {}, [], True
+        self._ones = None
+        # ---- state layout
+        self.slot = {}
+        off = CONST_CAP
+
+        def alloc(n):
+            nonlocal off
+            r = off
+            off += max(1, int(n))
+            return r
+
+        init = []       # (offset, array) to upload
+        for nd in self.nodes:
+            s = {}
+            if isinstance(nd, N.Gaussian):
+                d = nd.__dict__["_h_qmu"].shape[0]
+                s["qmu"] = Ref(alloc(d), d, 1)
+                s["qcov"] = Ref(alloc(d * d), d, d)
+                s["qld"] = Ref(alloc(2), 2, 1)
+                init.append((s["qmu"].off, nd.__dict__["_h_qmu"]))
+                init.append((s["qcov"].off, nd.__dict__["_h_qcov"]))
+                init.append((s["qld"].off, np.array([nd.__dict__.get("_h_q_ln_det") if nd.__dict__.get("_h_q_ln_det") is not None else np.nan, np.nan])))
+                if nd.partially_observed:
+                    oi, mi = np.asarray(nd.obs_index, dtype=float), np.asarray(nd.missing_index, dtype=float)
+                    s["obs_index"] = Ref(alloc(oi.size), oi.size, 1)
+                    s["missing_index"] = Ref(alloc(mi.size), mi.size, 1)
+                    s["all_index"] = Ref(alloc(d), d, 1)
+                    s["zero_index"] = Ref(alloc(1), 1, 1)
+                    s["obs_value"] = Ref(alloc(d), d, 1)
+                    init += [(s["obs_index"].off, oi), (s["missing_index"].off, mi), (s["all_index"].off, np.arange(d, dtype=float)),
+                             (s["zero_index"].off, np.zeros(1)), (s["obs_value"].off, np.nan_to_num(nd.obs_value))]
+            elif isinstance(nd, N.Constant):
+                v = np.asarray(nd.value, dtype=float)
+                s["value"] = Ref(alloc(v.size), v.shape[0], v.shape[1])
+                s["xxT"] = Ref(alloc(v.shape[0] ** 2), v.shape[0], v.shape[0])
+                s["xTx"] = Ref(alloc(v.shape[1] ** 2), v.shape[1], v.shape[1])
+                s["lndet"] = Ref(alloc(1), 1, 1)
+                init += [(s["value"].off, v), (s["xxT"].off, nd.value_xxT), (s["xTx"].off, nd.value_xTx),
+                         (s["lndet"].off, np.array([getattr(nd, "lndet", np.nan)], dtype=float))]
+            elif isinstance(nd, N.Gamma):
+                s["qa"], s["qb"] = Ref(alloc(1), 1, 1), Ref(alloc(1), 1, 1)
+                init += [(s["qa"].off, np.array([nd.qa], dtype=float)), (s["qb"].off, np.array([nd.__dict__["_h_qb"]], dtype=float).reshape(-1)[:1])]
+            elif isinstance(nd, N.DiagonalGamma):
+                dim = nd.shape[0]
+                s["qa"], s["qb"] = Ref(alloc(dim), dim, 1), Ref(alloc(dim), dim, 1)
+                s["a0"], s["b0"] = Ref(alloc(dim), dim, 1), Ref(alloc(dim), dim, 1)
+                init += [(s["qa"].off, np.asarray(nd.qa, dtype=float)), (s["qb"].off, np.broadcast_to(np.asarray(nd.__dict__["_h_qb"], dtype=float), (dim,))),
+                         (s["a0"].off, nd.a0s), (s["b0"].off, nd.b0s)]
+            elif isinstance(nd, N.Wishart):
+                dim = nd.shape[0]
+                s["qv"], s["qw"], s["w0"] = Ref(alloc(1), 1, 1), Ref(alloc(dim * dim), dim, dim), Ref(alloc(dim * dim), dim, dim)
+                init += [(s["qv"].off, np.array([nd.qv], dtype=float)), (s["qw"].off, nd.__dict__["_h_qw"]), (s["w0"].off, np.asarray(nd.w0, dtype=float))]
+            self.slot[id(nd)] = s
+        self.temp_base = off
+        self.temp_high = off
+        self._init = init
+        self._tapes = {}                  # key -> (tape id, result refs)
+        self._pending_tapes = []          # (key, ops) built but not uploaded (the arena size is only known then)
+        self._executor_factory = executor_factory or EXECUTOR_FACTORY
+        self.ex = None
+        self.n_random_nodes = len([n for n in self.nodes if isinstance(n, (N.Gaussian, N.Gamma, N.DiagonalGamma, N.Wishart))])
+        if adopt:
+            for nd in self.nodes:
+                nd._plan = self
+
+    # -- constants ------------------------------------------------------------------------------
+    def const(self, v):
+        v = float(v)
+        key = np.float64(v).tobytes()
+        if key not in self._consts:
+            if len(self._const_vals) >= CONST_CAP:
+                raise MemoryError("constant pool of the generic plan exhausted")
+            self._consts[key] = Ref(len(self._const_vals), 1, 1)
+            self._const_vals.append(v)
+            self._const_dirty = True
+        return self._consts[key]
+
+    def ones(self, n):
+        """A vector of n ones in the constant pool (for sums)."""
+        if self._ones is None or self._ones.size < n:
+            start = len(self._const_vals)
+            if start + n > CONST_CAP:
+                raise MemoryError("constant pool of the generic plan exhausted")
+            self._const_vals.extend([1.0] * n)
+            self._ones = Ref(start, n, 1)
+            self._const_dirty = True
+        return Ref(self._ones.off, n, 1)
+
+    # -- running --------------------------------------------------------------------------------
+    def _ensure_executor(self, need):
+        if self.ex is None or need > self.ex.size:
+            old = self.ex
+            size = max(need, self.temp_high) + 4096
+            new = self._executor_factory(size)
+            if old is None:
+                for off, arr in self._init:
+                    new.write(off, arr)
+            else:                       # grown: carry the state over (constants and tapes are re-uploaded below)
+                new.write(CONST_CAP, old.read(CONST_CAP, self.temp_base - CONST_CAP))
+                old.close()
+                self._tapes = {k: (None, ops, res) for k, (tid, ops, res) in self._tapes.items()}
+            self.ex = new
+            self._const_dirty = True
+
+    def _run(self, key, build):
+        """Run the tape `key`, building it with build(tape) -> result refs on first use."""
+        if key not in self._tapes:
+            t = Tape(self)
+            res = build(t)
+            self._tapes[key] = (None, t.array(), res)
+        tid, ops, res = self._tapes[key]
+        self._ensure_executor(self.temp_high)
+        if self._const_dirty:
+            self.ex.write(0, np.array(self._const_vals, dtype=float))
+            self._const_dirty = False
+        if tid is None:
+            tid = self.ex.tape(ops)
+            self._tapes[key] = (tid, ops, res)
+        self.ex.run(tid)
+        return res
+
+    def _read(self, ref):
+        self._ensure_executor(self.temp_high)
+        return self.ex.read(ref.off, ref.size).reshape(ref.m, ref.n)
+
+    # -- plan interface used by pyvb_amd.nodes / network -----------------------------------------
+    def enqueue(self, node):
+        if isinstance(node, N.Gaussian):
+            self._run(("update", id(node)), lambda t: self._emit_update_gaussian(t, node))
+        else:
+            self._run(("update", id(node)), lambda t: self._emit_update_noise(t, node))
+
+    def flush(self):
+        pass
+
+    def read(self, node, name):
+        s = self.slot[id(node)]
+        if isinstance(node, N.Gaussian):
+            if name == "qmu":
+                return self._read(s["qmu"])
+            if name == "qcov":
+                return self._read(s["qcov"])
+            if name == "q_ln_det":
+                v = float(self._read(s["qld"])[0, 0])
+                if np.isnan(v):
+                    raise AttributeError("q_ln_det is set by the first update()")
+                return v
+        elif name == "qb":
+            v = self._read(s["qb"]).reshape(-1)
+            return float(v[0]) if isinstance(node, N.Gamma) else v.copy()
+        elif name == "qw":
+            return self._read(s["qw"])
+        raise AttributeError(name)
+
+    def write(self, node, name, value):
+        s = self.slot[id(node)]
+        if name in ("qmu", "qcov", "qb", "qw") and name in s:
+            self._ensure_executor(self.temp_high)
+            v = np.asarray(value, dtype=float).reshape(-1)
+            self.ex.write(s[name].off, np.ascontiguousarray(np.broadcast_to(v, (s[name].size,))))
+        # other attributes (q_ln_det, qprec) are host-only bookkeeping
+
+    def pull(self):
+        """Device state back into the nodes' host attributes (before the graph is re-bound)."""
+        if self.ex is None:
+            return
+        for nd in self.nodes:
+            s = self.slot[id(nd)]
+            if isinstance(nd, N.Gaussian):
+                nd.__dict__["_h_qmu"] = self._read(s["qmu"])
+                nd.__dict__["_h_qcov"] = self._read(s["qcov"])
+                q = float(self._read(s["qld"])[0, 0])
+                if not np.isnan(q):
+                    nd.__dict__["_h_q_ln_det"] = q
+            elif isinstance(nd, (N.Gamma, N.DiagonalGamma)):
+                v = self._read(s["qb"]).reshape(-1)
+                nd.__dict__["_h_qb"] = float(v[0]) if isinstance(nd, N.Gamma) else v.copy()
+            elif isinstance(nd, N.Wishart):
+                nd.__dict__["_h_qw"] = self._read(s["qw"])
+
+    def release(self):
+        self.pull()
+        for nd in self.nodes:
+            if nd._plan is self:
+                nd._plan = None
+        if self.ex is not None:
+            self.ex.close()
+            self.ex = None
+
+    def node_llb(self, node):
+        res = self._run(("llb", id(node)), lambda t: self._emit_llb(t, node))
+        return float(self._read(res)[0, 0])
+
+    def llb_sum(self, node_list):
+        """sum of log_lower_bound() over the nodes (network.py:49), one launch."""
+        key = ("llbsum",) + tuple(id(n) for n in node_list)
+
+        def build(t):
+            parts = t.zeros(len(node_list), 1)
+            for i, n in enumerate(node_list):
+                t.copy(self._emit_llb(t, n), dst=parts.elem(i))
+            return parts
+        return self._read(self._run(key, build)).reshape(-1)
+
+    def update_all(self, node_list):
+        """[n.update() for n in node_list] as one launch (Network.learn, network.py:46-48)."""
+        key = ("updall",) + tuple(id(n) for n in node_list)
+
+        def build(t):
+            for n in node_list:
+                if isinstance(n, N.Gaussian):
+                    if not n.observed:
+                        self._emit_update_gaussian(t, n)
+                else:
+                    self._emit_update_noise(t, n)
+            return None
+        self._run(key, build)
+
+    def message(self, node, requester):
+        """node.pass_up_m1_m2(requester) evaluated on the device; returns numpy arrays."""
+        res = self._run(("msg", id(node), id(requester)), lambda t: self._pass_up(t, node, requester))
+        return tuple(self._read(r) for r in res)
+
+    def expectation(self, node, what):
+        fn = {"Ex": self._ex, "ExxT": self._exxt, "ExTx": self._extx, "lndet": self._lndet}[what]
+        return self._read(self._run(("exp", what, id(node)), lambda t: fn(t, node)))
+
+    # =============================================================================================
+    # emitters: the reference's methods
+    # =============================================================================================
+    def _ex(self, t, nd):
+        """pass_down_Ex"""
+        s = self.slot[id(nd)]
+        if isinstance(nd, N.DiagonalGaussian):                   # gaussian.py:198-199
+            return t.diag_matrix(s["qmu"])
+        if isinstance(nd, N.Gaussian):                           # gaussian.py:154-160
+            return s["qmu"]
+        if isinstance(nd, N.Constant):                           # node.py:304-305
+            return s["value"]
+        if isinstance(nd, N.Addition):                           # node.py:112-119
+            return t.add(self._ex(t, nd.A), self._ex(t, nd.B))
+        if isinstance(nd, N.Multiplication):                     # node.py:235-242
+            return t.gemm(self._ex(t, nd.A), self._ex(t, nd.B))
+        if isinstance(nd, N.hstack):                             # nodes_todo.py:33-34
+            rows, q = nd.shape
+            out = t.tmp(rows, q)
+            for i, p in enumerate(nd.parents):
+                e = self._ex(t, p)
+                t.emit(T_COPY2D, out.off + i, e.off, q, rows, 1, 1)
+            return out
+        if isinstance(nd, N.Gamma):                              # nodes_todo.py:140-142
+            r = t.scale(s["qa"], s["qb"], divide=True)
+            return t.scale(t.eye(nd.shape[0]), r)
+        if isinstance(nd, N.DiagonalGamma):                      # nodes_todo.py:192-193
+            return t.diag_matrix(t.mul(s["qa"], t.unary(s["qb"], U_RECIP)))
+        if isinstance(nd, N.Wishart):                            # nodes_todo.py:233-234 (symmetric part, see k_wishart.hip)
+            sym = t.axpby(0.5, s["qw"], 0.5, t.transpose(s["qw"]))
+            inv, _ = t.cholinv(sym)
+            return t.scale(inv, s["qv"])
+        raise NotImplementedError("pass_down_Ex of %s" % type(nd).__name__)
+
+    def _exxt(self, t, nd):
+        """pass_down_ExxT"""
+        s = self.slot[id(nd)]
+        if isinstance(nd, N.DiagonalGaussian):                   # gaussian.py:200-201
+            return t.diag_matrix(t.add(t.mul(s["qmu"], s["qmu"]), t.diag_of(s["qcov"])))
+        if isinstance(nd, N.Gaussian):                           # gaussian.py:162-168
+            return t.add(t.gemm(s["qmu"], s["qmu"], tb=True), s["qcov"])
+        if isinstance(nd, N.Constant):
+            return s["xxT"]
+        if isinstance(nd, N.Addition):                           # node.py:121-129
+            outer = t.gemm(self._ex(t, nd.A), self._ex(t, nd.B), tb=True)
+            r = t.add(self._exxt(t, nd.A), self._exxt(t, nd.B))
+            r = t.add(r, outer)
+            return t.add(r, t.transpose(outer))
+        if isinstance(nd, N.hstack):                             # nodes_todo.py:36-38
+            r = None
+            for p in nd.parents:
+                e = self._exxt(t, p)
+                r = e if r is None else t.add(r, e)
+            return r
+        if isinstance(nd, N.Multiplication):                     # node.py:244-276
+            A, B = nd.A, nd.B
+            if A.shape[1] == 1:                                  # rhs is a scalar (:251-252)
+                return t.scale(self._exxt(t, A), self._exxt(t, B))
+            if A.shape[0] == 1:                                  # lhs is a row vector (:253-254)
+                return t.trace(t.gemm(self._exxt(t, B), self._extx(t, A)))
+            BBT = self._exxt(t, B)
+            if isinstance(A, N.Constant):                        # (:257-258, with the transpose it lacks)
+                Am = self._ex(t, A)
+                return t.gemm(Am, t.gemm(BBT, Am, tb=True))
+            if hasattr(A, "parents"):                            # hstack (:260-271): sum_ij <a_i a_j^T> BBT[i,j]
+                Am = self._ex(t, A)
+                r = t.gemm(Am, t.gemm(BBT, Am, tb=True))
+                for i, p in enumerate(A.parents):
+                    t.axpby(1.0, r, BBT.elem(i, i), self.slot[id(p)]["qcov"], dst=r)
+                return r
+            sa = self.slot[id(A)]                                # DiagonalGaussian (:273-276)
+            aaT = t.add(t.gemm(sa["qmu"], sa["qmu"], tb=True), sa["qcov"])
+            return t.mul(BBT, aaT)
+        raise NotImplementedError("pass_down_ExxT of %s" % type(nd).__name__)
+
+    def _extx(self, t, nd):
+        """pass_down_ExTx"""
+        if isinstance(nd, N.DiagonalGaussian):
+            return self._exxt(t, nd)
+        if isinstance(nd, N.Gaussian):                           # gaussian.py:170-177
+            return t.trace(self._exxt(t, nd))
+        if isinstance(nd, N.Constant):
+            return self.slot[id(nd)]["xTx"]
+        raise NotImplementedError("pass_down_ExTx of %s" % type(nd).__name__)
+
+    def _lndet(self, t, nd):
+        """pass_down_lndet (quirk Q2: log det of the expected precision)"""
+        s = self.slot[id(nd)]
+        if isinstance(nd, N.Constant):                           # node.py:301-302, :310-311
+            return s["lndet"]
+        if isinstance(nd, N.Gamma):                              # nodes_todo.py:144-147
+            d = t.sub(t.unary(s["qa"], U_LOG), t.unary(s["qb"], U_LOG))
+            return t.scale(d, float(nd.shape[0]))
+        if isinstance(nd, N.DiagonalGamma):                      # nodes_todo.py:195-197
+            return t.total(t.sub(t.unary(s["qa"], U_LOG), t.unary(s["qb"], U_LOG)))
+        if isinstance(nd, N.Wishart):                            # not in the reference (Q8): dim ln qv - ln det sym(qw)
+            sym = t.axpby(0.5, s["qw"], 0.5, t.transpose(s["qw"]))
+            _, o2 = t.cholinv(sym)
+            return t.axpby(float(nd.shape[0]), t.unary(s["qv"], U_LOG), -2.0, o2.elem(1))
+        raise NotImplementedError("pass_down_lndet of %s" % type(nd).__name__)
+
+    def _sum_child_messages(self, t, nd):
+        msgs = [self._pass_up(t, c, nd) for c in nd.children]
+        if not msgs:
+            raise NotImplementedError("a %s without children was asked for a message" % type(nd).__name__)
+        m1, m2 = msgs[0][0], msgs[0][1]
+        for m in msgs[1:]:
+            m1, m2 = t.add(m1, m[0]), t.add(m2, m[1])
+        return m1, m2, msgs
+
+    def _pass_up(self, t, nd, requester):
+        """pass_up_m1_m2(requester): (m1, m2) -- or the 4-tuple of node.py:202 for an hstack requester"""
+        if isinstance(nd, N.Gaussian):                           # gaussian.py:179-183
+            pp = self._ex(t, nd.precision_parent)
+            return pp, t.gemm(pp, self.slot[id(nd)]["qmu"])
+        if isinstance(nd, N.Addition):                           # node.py:95-110
+            m1, m2, _ = self._sum_child_messages(t, nd)
+            other = nd.B if requester is nd.A else nd.A
+            oe = self._ex(t, other)
+            if m1.size == 1 and oe.size > 1:
+                return m1, t.axpby(1.0, m2, t.scale(m1, -1.0), oe)
+            return m1, t.gemm(m1, oe, dst=t.copy(m2), acc=True, neg=True)
+        if isinstance(nd, N.Multiplication):                     # node.py:182-232
+            m1s, m2s, _ = self._sum_child_messages(t, nd)
+            A, B = nd.A, nd.B
+            if requester is A:
+                if A.shape[1] == 1:                              # lhs is a column, rhs a scalar (:195-197)
+                    return t.scale(m1s, self._exxt(t, B)), t.scale(m2s, self._ex(t, B))
+                if A.shape[0] == 1:                              # lhs a row vector (:198-200; `sumC` there is sum_child_m1s)
+                    return t.scale(self._exxt(t, B), m1s), t.scale(t.transpose(self._ex(t, B)), m2s)
+                return m1s, m2s, self._ex(t, B), self._exxt(t, B)        # hstack lhs (:201-202)
+            Am = self._ex(t, A)
+            m2 = t.gemm(Am, m2s, ta=True)                        # (:204)
+            if A.shape[1] == 1:                                  # (:205-207)
+                return t.trace(t.gemm(self._exxt(t, A), m1s if m1s.size > 1 else t.scale(t.eye(A.shape[0]), m1s))), m2
+            if A.shape[0] == 1:                                  # (:208-209, returned as a pair here: Q3)
+                return t.scale(self._extx(t, A), m1s), m2
+            if m1s.size == 1:
+                m1s = t.scale(t.eye(A.shape[0]), m1s)
+            if isinstance(A, N.Constant):                        # (:211-212, as a pair: Q3)
+                return t.gemm(Am, t.gemm(m1s, Am), ta=True), m2
+            if hasattr(A, "parents"):                            # hstack (:213-227): <A^T L A> = Am^T L^T Am + diag_i tr(S_i L)
+                m1 = t.gemm(Am, t.gemm(m1s, Am, ta=True), ta=True)
+                for i, p in enumerate(A.parents):
+                    tr = t.trace(t.gemm(self.slot[id(p)]["qcov"], m1s))
+                    t.axpby(1.0, m1.elem(i, i), 1.0, tr, dst=m1.elem(i, i))
+                return m1, m2
+            sa = self.slot[id(A)]                                # DiagonalGaussian (:228-230)
+            aaT = t.add(t.gemm(sa["qmu"], sa["qmu"], tb=True), sa["qcov"])
+            return t.mul(aaT, m1s), m2
+        if isinstance(nd, N.hstack):                             # nodes_todo.py:43-62
+            if nd.shape[1] == 1:
+                m1, m2, _ = self._sum_child_messages(t, nd)
+                return m1, m2
+            msgs = [self._pass_up(t, c, nd) for c in nd.children]
+            i = nd.parents.index(requester)
+            rows = nd.shape[0]
+            m1 = t.zeros(rows, rows)
+            m2 = t.zeros(rows, 1)
+            for m in msgs:
+                if len(m) != 4:
+                    raise NotImplementedError("an hstack matrix must be the left operand of its Multiplication children")
+                cm1, cm2, bex, bbt = m
+                if cm1.size == 1:
+                    cm1 = t.scale(t.eye(rows), cm1)
+                t.axpby(1.0, m1, bbt.elem(i, i), cm1, dst=m1)                  # (:56)
+                t.axpby(1.0, m2, bex.elem(i), cm2, dst=m2)                      # (:60)
+                for j, pj in enumerate(nd.parents):                             # (:61)
+                    if j != i:
+                        w = t.gemm(cm1, self._ex(t, pj))
+                        t.axpby(1.0, m2, t.scale(bbt.elem(i, j), -1.0), w, dst=m2)
+            return m1, m2
+        raise NotImplementedError("pass_up_m1_m2 of %s" % type(nd).__name__)
+
+    # -- updates ----------------------------------------------------------------------------------
+    def _emit_update_gaussian(self, t, nd):
+        """Gaussian.update, gaussian.py:102-134"""
+        s = self.slot[id(nd)]
+        d = s["qmu"].m
+        pmu = self._ex(t, nd.mean_parent)
+        pprec = self._ex(t, nd.precision_parent)
+        qprec = t.copy(pprec)
+        wex = t.gemm(pprec, pmu)
+        for c in nd.children:
+            m = self._pass_up(t, c, nd)
+            m1, m2 = m[0], m[1]
+            if m1.size == 1 and d > 1:
+                m1 = t.scale(t.eye(d), m1)
+            t.axpby(1.0, qprec, 1.0, m1, dst=qprec)                              # (:117)
+            t.axpby(1.0, wex, 1.0, m2, dst=wex)                                  # (:122)
+        t.cholinv(qprec, dst=s["qcov"], out2=s["qld"])                           # (:118-120)
+        t.gemm(s["qcov"], wex, dst=s["qmu"])                                     # (:123)
+        if nd.partially_observed:                                                # (:125-134)
+            oi, ai, z = s["obs_index"], s["all_index"], s["zero_index"]
+            cov_obs = t.gather(s["qcov"], oi, oi)
+            cov_obs_inv, _ = t.cholinv(cov_obs)
+            cov_obs_all = t.gather(s["qcov"], ai, oi)
+            delta = t.sub(t.gather(s["obs_value"], oi, z), t.gather(s["qmu"], oi, z))
+            gain = t.gemm(cov_obs_all, cov_obs_inv)
+            t.gemm(gain, delta, dst=s["qmu"], acc=True)
+            t.gemm(gain, cov_obs_all, tb=True, dst=s["qcov"], acc=True, neg=True)
+
+    def _children_residual(self, t, nd):
+        """per child: <x x^T>, <mu mu^T>, <x><mu>^T (nodes_todo.py:138, :190, :231)"""
+        for c in nd.children:
+            yield self._exxt(t, c), self._exxt(t, c.mean_parent), t.gemm(self._ex(t, c), self._ex(t, c.mean_parent), tb=True)
+
+    def _emit_update_noise(self, t, nd):
+        s = self.slot[id(nd)]
+        if isinstance(nd, N.Gamma):                              # nodes_todo.py:130-138
+            acc = t.copy(t.const(float(nd.b0)))
+            for xx, mm, xm in self._children_residual(t, nd):
+                t.axpby(1.0, acc, 0.5, t.trace(xx), dst=acc)
+                t.axpby(1.0, acc, 0.5, t.trace(mm), dst=acc)
+                t.axpby(1.0, acc, -1.0, t.trace(xm), dst=acc)
+            t.copy(acc, dst=s["qb"])
+        elif isinstance(nd, N.DiagonalGamma):                    # nodes_todo.py:187-190
+            acc = t.copy(s["b0"])
+            for xx, mm, xm in self._children_residual(t, nd):
+                t.axpby(1.0, acc, 0.5, t.diag_of(xx), dst=acc)
+                t.axpby(1.0, acc, 0.5, t.diag_of(mm), dst=acc)
+                t.axpby(1.0, acc, -1.0, t.diag_of(xm), dst=acc)
+            t.copy(acc, dst=s["qb"])
+        elif isinstance(nd, N.Wishart):                          # nodes_todo.py:228-231 (w0 is not mutated: SURVEY Q7)
+            acc = t.copy(s["w0"])
+            for xx, mm, xm in self._children_residual(t, nd):
+                t.axpby(1.0, acc, 0.5, xx, dst=acc)
+                t.axpby(1.0, acc, 0.5, mm, dst=acc)
+                t.axpby(1.0, acc, -1.0, xm, dst=acc)
+            t.copy(acc, dst=s["qw"])
+        else:
+            raise NotImplementedError("update of %s" % type(nd).__name__)
+
+    # -- lower bound ------------------------------------------------------------------------------
+    def _emit_llb(self, t, nd):
+        if isinstance(nd, N.Gaussian):
+            return self._emit_llb_gaussian(t, nd)
+        if isinstance(nd, (N.Gamma, N.DiagonalGamma, N.Wishart)):
+            return self._emit_llb_noise(t, nd)
+        return t.copy(t.const(0.0))                              # Node.log_lower_bound, node.py:42-43
+
+    def _emit_llb_gaussian(self, t, nd):
+        """Gaussian.log_lower_bound, gaussian.py:136-151"""
+        s = self.slot[id(nd)]
+        d = s["qmu"].m
+        pp = self._ex(t, nd.precision_parent)
+        inner = t.add(self._exxt(t, nd), self._exxt(t, nd.mean_parent))
+        t.gemm(s["qmu"], self._ex(t, nd.mean_parent), tb=True, dst=inner, acc=True, neg=True)
+        t.gemm(s["qmu"], self._ex(t, nd.mean_parent), tb=True, dst=inner, acc=True, neg=True)      # -2 qmu <mu>^T
+        tr = t.trace(t.gemm(pp, inner))
+        ret = t.lin(-0.5 * d * LN2PI, [(0.5, self._lndet(t, nd.precision_parent)), (-0.5, tr)])
+        if not (nd.observed or nd.partially_observed):           # (:145-147)
+            ret = t.lin(0.5 * d * LN2PI + 0.5 * d, [(1.0, ret), (0.5, s["qld"].elem(0))])
+        elif nd.partially_observed:                              # (:148-150)
+            mi = s["missing_index"]
+            nm = mi.size
+            _, o2 = t.cholinv(t.gather(s["qcov"], mi, mi))       # ln det = 2 sum log diag chol
+            ret = t.lin(-0.5 * nm * LN2PI + 0.5 * nm, [(1.0, ret), (1.0, o2.elem(1))])
+        return ret
+
+    def _emit_llb_noise(self, t, nd):
+        s = self.slot[id(nd)]
+        if isinstance(nd, N.Wishart):
+            # not in the reference (Q8): E ln p - E ln q in the (a, B) form, see pyvb_amd/csrc/k_wishart.hip
+            dim = nd.shape[0]
+            sym = t.axpby(0.5, s["qw"], 0.5, t.transpose(s["qw"]))
+            inv, o2 = t.cholinv(sym)
+            lndw = t.scale(o2.elem(1), 2.0)
+            _, o0 = t.cholinv(s["w0"])
+            lndw0 = t.scale(o0.elem(1), 2.0)
+            EL = t.scale(inv, s["qv"])
+
+            def multi(f, base, shift_consts):
+                acc = t.copy(t.const(0.0))
+                for i in range(dim):
+                    t.axpby(1.0, acc, 1.0, t.unary(t.lin(-0.5 * i, [(1.0, base)]), f), dst=acc)
+                return acc
+            a0 = t.const(float(nd.v0))
+            Eln = t.sub(multi(U_DIGAMMA, s["qv"], None), lndw)
+            lg0 = t.lin(0.25 * dim * (dim - 1) * float(np.log(np.pi)), [(1.0, multi(U_LGAMMA, a0, None))])
+            lgq = t.lin(0.25 * dim * (dim - 1) * float(np.log(np.pi)), [(1.0, multi(U_LGAMMA, s["qv"], None))])
+            half = 0.5 * (dim + 1)
+            p = t.lin(0.0, [(float(nd.v0) - half, Eln), (-1.0, lg0), (float(nd.v0), lndw0), (-1.0, t.trace(t.gemm(s["w0"], EL)))])
+            qa_m = t.lin(-half, [(1.0, s["qv"])])
+            q = t.lin(0.0, [(1.0, t.mul(qa_m, Eln)), (-1.0, lgq), (1.0, t.mul(s["qv"], lndw)), (-float(dim), s["qv"])])
+            return t.sub(p, q)
+        # Gamma nodes_todo.py:149-157, DiagonalGamma :199-204
+        if isinstance(nd, N.Gamma):
+            a0, b0 = t.const(float(nd.a0)), t.const(float(nd.b0))
+        else:
+            a0, b0 = s["a0"], s["b0"]
+        qa, qb = s["qa"], s["qb"]
+        n = qa.size
+        one = self.ones(n)
+        Elnx = t.sub(t.unary(qa, U_DIGAMMA), t.unary(qb, U_LOG))
+        ratio = t.mul(qa, t.unary(qb, U_RECIP))
+        p = t.mul(t.sub(a0, one), Elnx)
+        p = t.sub(p, t.unary(a0, U_LGAMMA))
+        p = t.add(p, t.mul(a0, t.unary(b0, U_LOG)))
+        p = t.sub(p, t.mul(b0, ratio))
+        q = t.mul(t.sub(qa, one), Elnx)
+        q = t.sub(q, t.unary(qa, U_LGAMMA))
+        q = t.add(q, t.mul(qa, t.unary(qb, U_LOG)))
+        q = t.sub(q, t.mul(qb, ratio))
+        return t.total(t.sub(p, q))

@@ -35,6 +35,8 @@ class Network(object):
         if not self.iterable_nodes:
             return
         plan = N._plan_of(self.iterable_nodes[0])
+        if getattr(plan, "generic", False):
+            return self._learn_generic(niters, tol, verbose)
         missing = [n for n in self.iterable_nodes if n._plan is not plan]
         if missing:
             raise NotImplementedError("the network spans nodes outside one recognised LDS graph; no HIP plan")
@@ -50,6 +52,31 @@ class Network(object):
             if verbose:
                 print(niters - i, self.llb)
             if self.llb - old_llb < tol:                        # also fires when the bound decreases
+                if verbose:
+                    print("Convergence!")
+                break
+            old_llb = self.llb
+
+    def _learn_generic(self, niters, tol, verbose):
+        """network.py:40-56 for a graph that runs node by node: per iteration one launch for all update() calls in
+        list order and one for the sum of the log_lower_bound() terms; nodes of several unconnected graphs are grouped
+        by plan."""
+        plans = []
+        for n in self.iterable_nodes:
+            p = N._plan_of(n)
+            if not getattr(p, "generic", False):
+                raise NotImplementedError("a Network that mixes a fused (LDS / PCA) graph with other graphs")
+            if p not in plans:
+                plans.append(p)
+        groups = [(p, [n for n in self.iterable_nodes if n._plan is p]) for p in plans]
+        old_llb = -np.inf
+        for i in range(niters):
+            for p, group in groups:
+                p.update_all(group)
+            self.llb = float(sum(p.llb_sum(group).sum() for p, group in groups))        # network.py:49
+            if verbose:
+                print(niters - i, self.llb)
+            if self.llb - old_llb < tol:                        # SURVEY.md Q9
                 if verbose:
                     print("Convergence!")
                 break

@@ -43,12 +43,18 @@ class Node(object):
 
     def addChild(self, child):
         self.children.append(child)
+        _graph_changed(self)
 
     def update(self):
         pass
 
     def log_lower_bound(self):
         return 0.
+
+    def pass_up_m1_m2(self, requester):
+        """The two messages a parent needs from this node (gaussian.py:179-183, node.py:95-110, :182-232,
+        nodes_todo.py:43-62), evaluated on the device; returns numpy arrays like the reference."""
+        return _messages_of(self, requester)
 
     def __add__(self, other):
         return Addition(self, other)
@@ -62,6 +68,15 @@ class Node(object):
 
 def _wrap(x):
     return Constant(x) if isinstance(x, np.ndarray) else x
+
+
+def _graph_changed(node):
+    """A node gained a child or an observation: a generic plan that was built for the old graph is stale (its tapes
+    spell the old message structure) and is rebuilt at the next use.  The fused LDS / PCA plans are bound to complete
+    graphs and do not follow later changes."""
+    plan = getattr(node, "_plan", None)
+    if plan is not None and getattr(plan, "generic", False):
+        plan.stale = True
 
 
 class Addition(Node):
@@ -170,10 +185,24 @@ class Transpose(Node):
 # random-variable nodes
 # -------------------------------------------------------------------------------------------------
 def _plan_of(node):
+    plan = node._plan
+    if plan is not None and getattr(plan, "stale", False):
+        plan.release()                  # device state back into the nodes, then bind the graph as it is now
     if node._plan is None:
         from . import _recognise
         _recognise.bind(node)
     return node._plan
+
+
+def _generic_view(node):
+    """The generic (tape) plan that can evaluate single messages / single lower-bound terms for `node`: its own plan
+    if the graph runs node by node, else a mirror of the fused plan's current state."""
+    plan = _plan_of(node)
+    return plan if getattr(plan, "generic", False) else plan.mirror()
+
+
+def _messages_of(node, requester):
+    return _generic_view(node).message(node, requester)
 
 
 class _DeviceAttr(object):
@@ -186,13 +215,13 @@ class _DeviceAttr(object):
         if obj is None:
             return self
         if obj._plan is not None:
-            return obj._plan.read(obj, self.name)
+            return _plan_of(obj).read(obj, self.name)
         return obj.__dict__.get("_h_" + self.name)
 
     def __set__(self, obj, value):
         obj.__dict__["_h_" + self.name] = value
         if getattr(obj, "_plan", None) is not None:
-            obj._plan.write(obj, self.name, value)
+            _plan_of(obj).write(obj, self.name, value)
 
 
 class Gaussian(Node):
@@ -231,6 +260,7 @@ class Gaussian(Node):
 
     def observe(self, val):                     # gaussian.py:74-100
         assert val.shape == self.shape, "Bad shape for observation data"
+        _graph_changed(self)
         if np.isnan(val).all():
             return
         elif np.isnan(val).any():
@@ -250,6 +280,9 @@ class Gaussian(Node):
 
     def log_lower_bound(self):
         return _plan_of(self).node_llb(self)
+
+    def pass_up_m1_m2(self, requester):         # gaussian.py:179-183
+        return _messages_of(self, requester)
 
     def pass_down_Ex(self):
         return self.qmu
@@ -302,6 +335,7 @@ class Gamma(_NoiseNode):                        # nodes_todo.py:88-157
     def addChild(self, child):
         self.children.append(child)
         self.update_a()
+        _graph_changed(self)
 
     def update_a(self):
         self.qa = self.a0
@@ -329,6 +363,7 @@ class DiagonalGamma(_NoiseNode):                # nodes_todo.py:159-204
         assert child.shape == (self.shape[0], 1)
         self.children.append(child)
         self.update_a()
+        _graph_changed(self)
 
     def update_a(self):
         self.qa = self.a0s.copy()
@@ -363,6 +398,7 @@ class Wishart(_NoiseNode):                      # nodes_todo.py:205-234
         assert child.shape == (self.shape[0], 1)
         self.children.append(child)
         self.update_v()
+        _graph_changed(self)
 
     def update_v(self):
         self.qv = self.v0

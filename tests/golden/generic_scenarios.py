@@ -1,0 +1,240 @@
+"""Small graphs for the generic (node-by-node) path, written against a `nodes` MODULE so that the same builder
+constructs the graph out of the reference's classes (tests/golden/make_golden.py -> generic_*.npz) and out of
+pyvb_amd.nodes (the tests).  The scenarios follow the demo functions of the reference's src/tests.py (cited per builder);
+data and initial posteriors come from a seeded generator instead of the global numpy stream.
+
+A builder returns (update_order, named) where update_order is the list of nodes whose update() is called, in order,
+once per iteration, and named maps labels to every random-variable node whose posterior is recorded.
+"""
+import numpy as np
+
+
+def _init_gaussian(n, rng):
+    """Explicit initial posterior instead of gaussian.py:70-72's draw from the global stream."""
+    d = n.shape[0] if n.shape[1] == 1 else n.qmu.shape[0]
+    n.qmu = rng.standard_normal((d, 1))
+    n.qcov = np.eye(d) / rng.uniform(0.5, 1.5)
+    n.qprec = np.linalg.inv(n.qcov)
+
+
+def _init_all(named, rng):
+    for k in sorted(named):
+        n = named[k]
+        if hasattr(n, "qmu"):
+            if not n.observed:
+                _init_gaussian(n, rng)
+        elif hasattr(n, "qw"):
+            dim = n.shape[0]
+            W = rng.standard_normal((dim, dim))
+            n.qw = W @ W.T + dim * np.eye(dim)
+        else:
+            n.qb = rng.uniform(0.5, 1.5) if np.ndim(n.qa) == 0 else rng.uniform(0.5, 1.5, size=np.shape(n.qa))
+
+
+def simple_mean_inference(nodes, rng):          # src/tests.py:9-19
+    y = rng.standard_normal(20) * np.sqrt(1.0 / 10) + 7.2
+    mu = nodes.Gaussian(1, np.array([[0.0]]), np.array([[1e-3]]))
+    ys = [nodes.Gaussian(1, mu, np.array([[10.0]])) for _ in range(20)]
+    for yy, n in zip(y, ys):
+        n.observe(yy.reshape(1, 1))
+    named = {"mu": mu}
+    named.update({"y%02d" % i: n for i, n in enumerate(ys)})
+    _init_all(named, rng)
+    return [mu], named
+
+
+def scalar_addition(nodes, rng):                # src/tests.py:21-33
+    A = [nodes.Gaussian(1, np.array([[0.0]]), np.array([[0.01]])) for _ in range(3)]
+    C = nodes.Gaussian(1, A[0] + A[1] + A[2], np.array([[10.0]]))
+    C.observe(np.array([[12.0]]))
+    named = {"A1": A[0], "A2": A[1], "A3": A[2], "C": C}
+    _init_all(named, rng)
+    return A, named
+
+
+def scalar_multiplication(nodes, rng):          # src/tests.py:35-45
+    A1 = nodes.Gaussian(1, np.array([[0.0]]), np.array([[0.001]]))
+    A2 = nodes.Gaussian(1, np.array([[0.0]]), np.array([[0.001]]))
+    C = nodes.Gaussian(1, A1 * A2, np.array([[10.0]]))
+    C.observe(np.array([[16.0]]))
+    named = {"A1": A1, "A2": A2, "C": C}
+    _init_all(named, rng)
+    return [A1, A2], named
+
+
+def vector_addition(nodes, rng):                # src/tests.py:58-72
+    A = [nodes.Gaussian(3, np.zeros((3, 1)), np.eye(3) * 0.01) for _ in range(3)]
+    C = nodes.Gaussian(3, A[0] + A[1] + A[2], np.eye(3) * 10)
+    C.observe(np.array([[12.0], [6.0], [3.0]]))
+    named = {"A1": A[0], "A2": A[1], "A3": A[2], "C": C}
+    _init_all(named, rng)
+    return A, named
+
+
+def multiplication_of_observed(nodes, rng):     # src/tests.py:74-82
+    A1 = nodes.Gaussian(1, np.zeros((1, 1)), np.eye(1) * 1.0)
+    A2 = nodes.Gaussian(1, np.zeros((1, 1)), np.eye(1) * 1.0)
+    A1.observe(np.array([[2.0]]))
+    A2.observe(np.array([[3.0]]))
+    C = nodes.Gaussian(1, A1 * A2, np.eye(1) * 0.01)
+    named = {"A1": A1, "A2": A2, "C": C}
+    _init_all(named, rng)
+    return [C], named
+
+
+def simple_regression(nodes, rng):              # src/tests.py:100-128
+    Nn = 40
+    x = np.linspace(-1, 1, Nn).reshape(Nn, 1)
+    y = 0.7 * x + 0.3 + rng.standard_normal((Nn, 1)) * np.sqrt(1.0 / 10.0)
+    B = nodes.Gaussian(1, np.array([[0.0]]), np.array([[1e-2]]))
+    A = nodes.Gaussian(1, np.array([[0.0]]), np.array([[1e-2]]))
+    noise = nodes.Gamma(1, 1e-3, 1e-3)
+    Xs = [nodes.Constant(xx.reshape(1, 1)) for xx in x]
+    Ys = [nodes.Gaussian(1, Xn * A + B, noise) for Xn in Xs]
+    for n, yy in zip(Ys, y):
+        n.observe(yy.reshape(1, 1))
+    named = {"A": A, "B": B, "noise": noise}
+    named.update({"y%02d" % i: n for i, n in enumerate(Ys)})
+    _init_all(named, rng)
+    return [A, B, noise], named
+
+
+def simple_PCA(nodes, rng):                     # src/tests.py:176-202
+    Nn, d = 25, 4
+    Z_true, W_true, mu_true = rng.standard_normal((Nn, 1)), rng.standard_normal((d, 1)), rng.standard_normal((d, 1))
+    X = Z_true @ W_true.T + mu_true.T + rng.standard_normal((Nn, d)) * np.sqrt(1.0 / 100.0)
+    noise = nodes.Gamma(d, 1e-3, 1e-3)
+    W = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 0.001)
+    Mu = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 0.001)
+    Zs = [nodes.Gaussian(1, np.zeros((1, 1)), np.eye(1)) for _ in range(Nn)]
+    mults = [nodes.Multiplication(W, z) for z in Zs]
+    Xs = [nodes.Gaussian(d, m + Mu, noise) for m in mults]
+    [n.observe(v.reshape(d, 1)) for n, v in zip(Xs, X)]
+    named = {"W": W, "Mu": Mu, "noise": noise}
+    named.update({"z%02d" % i: n for i, n in enumerate(Zs)})
+    named.update({"x%02d" % i: n for i, n in enumerate(Xs)})
+    _init_all(named, rng)
+    return [W] + Zs + [Mu, noise], named
+
+
+def mean_and_variance_inference(nodes, rng):    # src/tests.py:204-218 (without its name clash)
+    Nn = 30
+    Xdata = rng.standard_normal((Nn, 1)) * np.sqrt(1.0 / 5.0) + 1.23
+    prec = nodes.Gamma(1, 1e-3, 1e-3)
+    mu = nodes.Gaussian(1, np.zeros((1, 1)), np.array([[1e-3]]))
+    xs = [nodes.Gaussian(1, mu, prec) for _ in range(Nn)]
+    for n, x in zip(xs, Xdata):
+        n.observe(x.reshape(1, 1))
+    named = {"mu": mu, "prec": prec}
+    named.update({"x%02d" % i: n for i, n in enumerate(xs)})
+    _init_all(named, rng)
+    return [mu, prec], named
+
+
+def partial_observations(nodes, rng):
+    """Vector observations with missing entries and a DiagonalGamma precision: the partial-observation tail of
+    Gaussian.update (gaussian.py:125-134) and of log_lower_bound (:148-150), as examples/PCA_missing_data.py uses them."""
+    Nn, d = 12, 3
+    mu_true = np.array([1.0, -2.0, 0.5])
+    data = mu_true + rng.standard_normal((Nn, d)) * np.array([0.3, 0.6, 1.0])
+    mask = rng.random((Nn, d)) < 0.3
+    mask[0] = [True, False, False]
+    mask[1] = [True, True, True]            # nothing observed: observe() returns at once (gaussian.py:90-91)
+    mask[2] = [False, False, False]
+    data = np.where(mask, np.nan, data)
+    Mu = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3)
+    Beta = nodes.DiagonalGamma(d, np.full(d, 1e-3), np.full(d, 1e-3))
+    Xs = [nodes.Gaussian(d, Mu, Beta) for _ in range(Nn)]
+    [n.observe(row.reshape(d, 1).copy()) for n, row in zip(Xs, data)]
+    named = {"Mu": Mu, "Beta": Beta}
+    named.update({"x%02d" % i: n for i, n in enumerate(Xs)})
+    _init_all(named, rng)
+    return Xs + [Mu, Beta], named
+
+
+def lds_missing_outputs(nodes, rng):
+    """The LDS graph of examples/Linear_Dynamic_System.py:46-66 with one partially observed and one unobserved output:
+    not the fused plan's graph, so every hstack / Multiplication branch runs through the generic path."""
+    T, D, K = 6, 2, 3
+    As = [nodes.Gaussian(D, np.zeros((D, 1)), np.eye(D) * 1e-3) for _ in range(D)]
+    A = nodes.hstack(As)
+    Cs = [nodes.Gaussian(K, np.zeros((K, 1)), np.eye(K) * 1e-3) for _ in range(D)]
+    C = nodes.hstack(Cs)
+    Q = nodes.DiagonalGamma(D, np.full(D, 1e-3), np.full(D, 1e-3))
+    R = nodes.DiagonalGamma(K, np.full(K, 1e-3), np.full(K, 1e-3))
+    Y = rng.standard_normal((T, K))
+    Y[2, 1] = np.nan
+    Y[4, :] = np.nan
+    Xs = [nodes.Gaussian(D, np.zeros((D, 1)), np.eye(D))]
+    Ys = [nodes.Gaussian(K, C * Xs[0], R)]
+    for t in range(1, T):
+        Xs.append(nodes.Gaussian(D, A * Xs[-1], Q))
+        Ys.append(nodes.Gaussian(K, C * Xs[-1], R))
+    for y, row in zip(Ys, Y):
+        y.observe(row.reshape(K, 1).copy())
+    named = {"Q": Q, "R": R}
+    for nm, lst in (("X", Xs), ("Y", Ys), ("a", As), ("c", Cs)):
+        named.update({"%s%02d" % (nm, i): n for i, n in enumerate(lst)})
+    _init_all(named, rng)
+    order = Xs + Xs[::-1] + [Ys[2], Ys[4]] + As + Cs + [Q, R]
+    return order, named
+
+
+def wishart_precision(nodes, rng):
+    """A Wishart precision over vector observations with an unknown mean (nodes_todo.py:205-234).  Only the state after
+    the FIRST pass is a valid reference target (the reference mutates its prior)."""
+    Nn, d = 15, 3
+    L = rng.standard_normal((d, d))
+    data = np.array([2.0, -1.0, 0.0]) + rng.standard_normal((Nn, d)) @ L.T * 0.4
+    Mu = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-2)
+    Lam = nodes.Wishart(d, 2.5, np.eye(d) * 0.1)
+    Xs = [nodes.Gaussian(d, Mu, Lam) for _ in range(Nn)]
+    [n.observe(row.reshape(d, 1).copy()) for n, row in zip(Xs, data)]
+    named = {"Mu": Mu, "Lam": Lam}
+    named.update({"x%02d" % i: n for i, n in enumerate(Xs)})
+    _init_all(named, rng)
+    return [Mu, Lam], named
+
+
+# name -> (builder, seed, iterations after which the state is recorded, messages to record as (node label, requester label))
+SCENARIOS = {
+    "simple_mean_inference": (simple_mean_inference, 101, (1, 2), [("y03", "mu")]),
+    "scalar_addition": (scalar_addition, 102, (1, 7), []),
+    "scalar_multiplication": (scalar_multiplication, 103, (1, 9), []),
+    "vector_addition": (vector_addition, 104, (1, 6), []),
+    "multiplication_of_observed": (multiplication_of_observed, 105, (1, 2), []),
+    "simple_regression": (simple_regression, 106, (1, 5), []),
+    "simple_PCA": (simple_PCA, 107, (1, 4), [("x05", "noise")]),
+    "mean_and_variance_inference": (mean_and_variance_inference, 108, (1, 6), []),
+    "partial_observations": (partial_observations, 109, (1, 3), []),
+    "lds_missing_outputs": (lds_missing_outputs, 110, (1, 3), []),
+    "wishart_precision": (wishart_precision, 111, (1,), []),
+}
+
+
+def snapshot(named):
+    """Posterior of every named node as flat arrays: label -> dict."""
+    out = {}
+    for k in sorted(named):
+        n = named[k]
+        if hasattr(n, "qmu"):
+            out[k + ".qmu"] = np.array(n.qmu, dtype=float)
+            out[k + ".qcov"] = np.array(n.qcov, dtype=float)
+        elif hasattr(n, "qw"):
+            out[k + ".qw"] = np.array(n.qw, dtype=float)
+            out[k + ".qv"] = np.float64(n.qv)
+        else:
+            out[k + ".qa"] = np.array(n.qa, dtype=float)
+            out[k + ".qb"] = np.array(n.qb, dtype=float)
+    return out
+
+
+def lower_bounds(named):
+    """log_lower_bound() of every named node (NaN where the reference raises: Wishart parents)."""
+    out = {}
+    for k in sorted(named):
+        try:
+            out[k + ".llb"] = np.float64(np.asarray(named[k].log_lower_bound(), dtype=float).reshape(-1)[0])
+        except (AttributeError, NotImplementedError):
+            out[k + ".llb"] = np.float64(np.nan)
+    return out

@@ -268,6 +268,32 @@ def run_pca_case(ref, name, N, d, q, iters, seed):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def run_generic_case(ref, name):
+    """Small graphs of src/tests.py through the reference's classes (tests/golden/generic_scenarios.py): posteriors of
+    every random node after the listed iterations, every node's log_lower_bound(), a few pass_up_m1_m2 messages."""
+    import generic_scenarios as GS
+    build, seed, checkpoints, messages = GS.SCENARIOS[name]
+    rng = np.random.default_rng(seed)
+    order, named = build(ref.nodes, rng)
+    out = {"iters": np.array(sorted(checkpoints))}
+    for it in range(1, max(checkpoints) + 1):
+        for n in order:
+            n.update()
+        if it in checkpoints:
+            tag = "it%d." % it
+            for k, v in GS.snapshot(named).items():
+                out[tag + k] = v
+            for k, v in GS.lower_bounds(named).items():
+                out[tag + k] = v
+            for a, b in messages:
+                m = named[a].pass_up_m1_m2(named[b])
+                out[tag + "msg.%s.%s.m1" % (a, b)] = np.array(m[0], dtype=float)
+                out[tag + "msg.%s.%s.m2" % (a, b)] = np.array(m[1], dtype=float)
+    path = os.path.join(HERE, "generic_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 PCA_CASES = [("example_n200_d5_q2", 200, 5, 2, (1, 2, 5), 30100),
              ("n60_d12_q3", 60, 12, 3, (1, 3), 30101),
              ("n40_d70_q17", 40, 70, 17, (1, 2), 30102)]
@@ -324,6 +350,11 @@ if __name__ == "__main__":
     for c in PCA_CASES:
         if not sel or sel == ["small"] or "pca" in sel or c[0] in sel:
             run_pca_case(ref, *c)
+    sys.path.insert(0, HERE)
+    import generic_scenarios
+    for name in generic_scenarios.SCENARIOS:
+        if not sel or sel == ["small"] or "generic" in sel or name in sel:
+            run_generic_case(ref, name)
     for c in CASES:
         if sel and sel != ["small"] and c[0] not in sel:
             continue

@@ -1,0 +1,126 @@
+"""Generic (node-by-node) path on the GPU: the tapes of pyvb_amd/generic.py through the HIP interpreter
+(pyvb_amd/csrc/k_tape.hip, C ABI pyvb_graph_*), against the reference's fixtures and against the numpy restatement of
+the interpreter (oracle/tape_ref.py).  Also the single messages / single lower-bound terms of the fused LDS and PCA plans,
+which are served by a generic mirror of their state."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import generic_scenarios as GS  # noqa: E402
+from test_generic_cpu import check_scenario, _close  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(GS.SCENARIOS))
+def test_generic_scenarios_on_device(name):
+    named = check_scenario(name)
+    from pyvb_amd.generic import GenericPlan, DeviceExecutor
+    plan = next(iter(named.values()))._plan
+    assert isinstance(plan, GenericPlan) and isinstance(plan.ex, DeviceExecutor)
+
+
+def test_every_opcode_against_the_numpy_interpreter():
+    """A tape that uses every opcode with odd shapes, run by the device and by oracle/tape_ref.py on the same arena."""
+    from oracle import tape_ref as R
+    from pyvb_amd import generic as G
+
+    class P(object):        # the slice of GenericPlan that Tape needs
+        temp_base, temp_high = 4096, 4096
+        vals = []
+
+        def const(self, v):
+            self.vals.append(float(v))
+            return G.Ref(len(self.vals) - 1, 1, 1)
+
+        def ones(self, n):
+            o = len(self.vals)
+            self.vals.extend([1.0] * n)
+            return G.Ref(o, n, 1)
+    plan = P()
+    rng = np.random.default_rng(0)
+    base = 2048
+    M = rng.standard_normal((7, 5)); S = rng.standard_normal((9, 9)); S = S @ S.T + 9 * np.eye(9)
+    v = rng.random(9) + 0.5
+    a = G.Ref(base, 7, 5); s = G.Ref(base + 64, 9, 9); vec = G.Ref(base + 256, 9, 1)
+    idx_r = G.Ref(base + 300, 3, 1); idx_c = G.Ref(base + 310, 2, 1)
+    t = G.Tape(plan)
+    g1 = t.gemm(a, a, tb=True)                      # 7 x 7
+    g2 = t.gemm(a, a, ta=True)                      # 5 x 5
+    t.gemm(a, a, ta=True, dst=g2, acc=True, neg=True)
+    inv, o2 = t.cholinv(s)
+    tr = t.trace(inv)
+    dg = t.diag_of(s)
+    dm = t.diag_matrix(vec)
+    ax = t.axpby(0.5, s, -2.0, dm)
+    sc = t.scale(ax, tr, divide=True)
+    un = [t.unary(vec, f) for f in (G.U_LOG, G.U_DIGAMMA, G.U_LGAMMA, G.U_RECIP, G.U_NEG, G.U_EXP)]
+    ml = t.mul(vec, dg)
+    tot = t.total(ml)
+    ga = t.gather(s, idx_r, idx_c)
+    tp = t.transpose(a)
+    li = t.lin(1.5, [(2.0, tr), (-1.0, tot)])
+    ey = t.eye(4); ze = t.zeros(3, 2); cp = t.copy(g1)
+    outs = [g1, g2, inv, o2, tr, dg, dm, ax, sc, ml, tot, ga, tp, li, ey, ze, cp] + un
+    size = plan.temp_high + 64
+    arena = np.zeros(size)
+    arena[:len(plan.vals)] = plan.vals
+    arena[a.off:a.off + 35] = M.reshape(-1); arena[s.off:s.off + 81] = S.reshape(-1); arena[vec.off:vec.off + 9] = v
+    arena[idx_r.off:idx_r.off + 3] = [8, 0, 4]; arena[idx_c.off:idx_c.off + 2] = [2, 7]
+    ref = arena.copy()
+    R.run(ref, t.array())
+    ex = G.DeviceExecutor(size)
+    ex.write(0, arena)
+    ex.run(ex.tape(t.array()))
+    got = ex.read(0, size)
+    ex.close()
+    for i, r in enumerate(outs):
+        _close(got[r.off:r.off + r.size], ref[r.off:r.off + r.size], "output %d of the opcode tape" % i, 1e-11)
+    _close(got[inv.off:inv.off + 81].reshape(9, 9), np.linalg.inv(S), "inverse", 1e-11)
+
+
+def test_not_positive_definite_raises_linalgerror():
+    from pyvb_amd import nodes
+    mu = nodes.Gaussian(2, np.zeros((2, 1)), -np.eye(2))
+    y = nodes.Gaussian(2, mu, np.eye(2) * 0.5)
+    y.observe(np.ones((2, 1)))
+    mu.update()
+    with pytest.raises(np.linalg.LinAlgError):
+        mu.qmu
+
+
+def test_single_messages_and_terms_of_the_fused_lds_plan(golden):
+    """pass_up_m1_m2 and per-node log_lower_bound() on the nodes of a graph that runs through the fused LDS kernels: a
+    generic mirror of the plan's state evaluates them (gaussian.py:136-151, :179-183; node.py:182-232;
+    nodes_todo.py:43-62).  The per-node terms must add up to the class sums the reference's fixture holds."""
+    from pyvb_amd import nodes
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden as MG
+    meta, Y, st0, pri, z = golden
+    if meta["noise"] == "wishart" or meta["D"] > 8 or meta["T"] > 60:
+        pytest.skip("node-by-node evaluation is for small graphs")
+    g = MG.build_graph(nodes, Y[0], pri, {k: v for k, v in st0.items()})
+    Xs, Ys, As, Cs, Q, R = g["Xs"], g["Ys"], g["As"], g["Cs"], g["Q"], g["R"]
+    it = meta["iters"][0]
+    for _ in range(it):
+        [x.update() for x in Xs]
+        Xs.reverse(); [x.update() for x in Xs]; Xs.reverse()
+        [a.update() for a in As]; [c.update() for c in Cs]
+        Q.update(); R.update()
+    ref = z["it%d_elbo_parts" % it]
+    scale = np.abs(ref).sum()
+    got = [sum(n.log_lower_bound() for n in grp) for grp in (Xs, Ys, As, Cs)]
+    for v, r in zip(got, ref[:4]):
+        assert abs(v - r) <= 1e-8 * scale, (got, ref)
+    m1, m2 = Ys[1].pass_up_m1_m2(Ys[1].mean_parent)             # gaussian.py:179-183
+    Rbar = R.pass_down_Ex()
+    _close(m1, Rbar, "m1 of an observed output", 1e-9)
+    _close(m2, Rbar @ Ys[1].qmu, "m2 of an observed output", 1e-9)
+    T = len(Xs)
+    if T > 2:
+        m1, m2 = Xs[1].children[0].pass_up_m1_m2(Xs[1])         # Mult(., X_1), hstack branch node.py:213-227
+        assert m1.shape == (meta["D"], meta["D"]) and np.all(np.isfinite(m1)) and np.all(np.isfinite(m2))

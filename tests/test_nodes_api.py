@@ -107,22 +107,25 @@ def test_recogniser_extracts_the_lds(capsys):
     assert len(net.iterable_nodes) == 2 * 6 + 2 * 3 + 2
 
 
-def test_recogniser_refuses_other_graphs():
+def test_graphs_without_a_fused_plan_go_node_by_node():
+    """Graphs other than the LDS and the VB-PCA graph bind to the generic node-by-node plan (pyvb_amd/generic.py); the
+    fused recognisers say why they decline.  (Binding needs no GPU: the arena is created at the first launch.)"""
+    from pyvb_amd.generic import GenericPlan
     # simple mean inference (src/tests.py:9-19): a valid pyvb graph, but not the LDS path
     mu = nodes.Gaussian(1, np.zeros((1, 1)), np.eye(1) * 1e-3)
     prec = nodes.Gamma(1, 1e-3, 1e-3)
     xs = [nodes.Gaussian(1, mu, prec) for _ in range(5)]
     [x.observe(np.random.randn(1, 1)) for x in xs]
     with pytest.raises(NotImplementedError):
-        mu.update()
+        _recognise.describe(mu)
+    assert isinstance(_recognise.bind(mu), GenericPlan) and prec._plan is mu._plan and xs[3]._plan is mu._plan
     # an LDS whose outputs have missing values
     g, Y, st0, pri = _graph()
     g["Ys"][2].observed = False
     g["Ys"][2].observe(np.array([[1.0], [np.nan], [0.5], [np.nan]]))
     with pytest.raises(NotImplementedError):
-        g["Xs"][0].update()
-    with pytest.raises(NotImplementedError):
-        nodes.Wishart(2, 1e-3, np.eye(2)).update()
+        _recognise.describe(g["Xs"][0])
+    assert isinstance(_recognise.bind(g["Xs"][0]), GenericPlan)
     with pytest.raises(NotImplementedError):
         nodes.Transpose(mu)
 
