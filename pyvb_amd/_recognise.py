@@ -57,7 +57,7 @@ class LDSPlan(object):
         self.cache = None
         self.x_updated = False
         self.n_random_nodes = 2 * self.T + 2 * self.D + 2
-        for n in Xs + Ys + As + Cs + [A, C, Q, R]:
+        for n in _component(Xs[0]):         # the operation nodes and Constants too: their messages go through mirror()
             n._plan = self
 
     # -- queue -----------------------------------------------------------------------------------
@@ -429,7 +429,7 @@ class PCAPlan(object):
         self.index[id(Beta)] = ("beta", 0)
         self.pending, self.cache = [], None
         self.n_random_nodes = 2 * self.N + self.q + 2
-        for n in Ws + Zs + Xs + [W, Mu, Beta]:
+        for n in _component(W):
             n._plan = self
 
     def enqueue(self, node):
