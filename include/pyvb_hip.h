@@ -105,6 +105,10 @@ int pyvb_lds_get_state(pyvb_lds* h, double* X, double* A_mean, double* A_colvar,
                        double* Q_a, double* Q_b, double* R_a, double* R_b);
 /* qcov / q_ln_det of the X_t as of their last update (gaussian.py:119-120); qld of the columns. */
 int pyvb_lds_get_posterior_classes(pyvb_lds* h, double* Sigma, double* qld_x);
+/* Initial covariances of the X_t, one per class (the reference draws an individual random one per node, gaussian.py:70-72;
+ * they are overwritten by the first sweep).  Without this call, statistics / parameter updates / the lower bound return
+ * PYVB_E_STALE until a complete sweep has run.  qld_x may be NULL. */
+int pyvb_lds_set_posterior_classes(pyvb_lds* h, const double* Sigma, const double* qld_x);
 int pyvb_lds_get_column_qld(pyvb_lds* h, double* qld_A, double* qld_C);
 
 /* [x.update() for x in Xs] in forward or reversed order (Linear_Dynamic_System.py:70-73):

@@ -39,6 +39,7 @@ SIGNATURES = {
     "pyvb_lds_set_state": (ctypes.c_int, [_h] + [_dp] * 7),
     "pyvb_lds_get_state": (ctypes.c_int, [_h] + [_dp] * 9),
     "pyvb_lds_get_posterior_classes": (ctypes.c_int, [_h, _dp, _dp]),
+    "pyvb_lds_set_posterior_classes": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_lds_get_column_qld": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_lds_sweep": (ctypes.c_int, [_h, ctypes.c_int]),
     "pyvb_lds_update_x": (ctypes.c_int, [_h, ctypes.c_int]),

@@ -65,7 +65,10 @@ class LDSPlan(object):
         self.pending.append(self.index[id(node)])
 
     def flush(self):
-        """Run the queued update() requests, turning whole-sweep runs into single launches."""
+        """Run the queued update() requests.  The fused kernels serve whole sweeps -- `[x.update() for x in Xs]`, its
+        reverse -- and, once the states have been swept, runs of column updates and the noise updates.  Any other
+        sequence (a single X_t.update(), parameters before the first sweep: the X_t then still have their individual
+        initial covariances, gaussian.py:70-72) is executed node by node instead: the graph moves to the generic plan."""
         ops, self.pending = self.pending, []
         if not ops:
             return
@@ -81,20 +84,59 @@ class LDSPlan(object):
                 elif len(run) == T and run == list(range(T - 1, -1, -1)):
                     b.sweep("backward"); i += T
                 else:
-                    b.update_x(idx); i += 1
+                    return self._demote(ops[i:])
                 self.x_updated = True
-            elif kind in ("a", "c"):
-                j = i
-                while j + 1 < len(ops) and ops[j + 1] == (kind, ops[j][1] + 1):
-                    j += 1
-                b.update_columns("A" if kind == "a" else "C", idx, ops[j][1] + 1)
-                i = j + 1
-            elif kind == "q":
-                b.update_Q(); i += 1
-            elif kind == "r":
-                b.update_R(); i += 1
+            elif kind in ("a", "c", "q", "r"):
+                if not self.x_updated:
+                    return self._demote(ops[i:])
+                if kind in ("a", "c"):
+                    j = i
+                    while j + 1 < len(ops) and ops[j + 1] == (kind, ops[j][1] + 1):
+                        j += 1
+                    b.update_columns("A" if kind == "a" else "C", idx, ops[j][1] + 1)
+                    i = j + 1
+                elif kind == "q":
+                    b.update_Q(); i += 1
+                else:
+                    b.update_R(); i += 1
             else:
                 i += 1          # observed nodes never update (gaussian.py:109-110)
+
+    def _sync_host(self):
+        """Current device posteriors into the nodes' host attributes."""
+        if not self.x_updated:
+            return              # nothing has run: the host attributes are the state
+        self._pull()
+        for nd in self.Xs + self.As + self.Cs:
+            for name in ("qmu", "qcov"):
+                nd.__dict__["_h_" + name] = self.read(nd, name)
+            try:
+                q = self.read(nd, "q_ln_det")
+                if np.isfinite(q):
+                    nd.__dict__["_h_q_ln_det"] = q
+            except Exception:
+                pass
+        if self.kind == "wishart":
+            self.Q.__dict__["_h_qw"], self.R.__dict__["_h_qw"] = self.read(self.Q, "qw"), self.read(self.R, "qw")
+        else:
+            self.Q.__dict__["_h_qb"], self.R.__dict__["_h_qb"] = self.read(self.Q, "qb"), self.read(self.R, "qb")
+
+    def _demote(self, rest):
+        """Hand the graph to the generic node-by-node plan and replay the remaining update() requests there."""
+        from .generic import GenericPlan
+        lookup = {v: k for k, v in self.index.items()}
+        by_id = {id(n): n for n in self.Xs + self.Ys + self.As + self.Cs + [self.Q, self.R]}
+        self._sync_host()
+        comp = _component(self.Xs[0])
+        for n in comp:
+            n._plan = None
+        self.batch.close()
+        gp = GenericPlan(self.Xs[0])
+        for key in rest:
+            node = by_id[lookup[key]]
+            if not getattr(node, "observed", False):
+                gp.enqueue(node)
+        return gp
 
     # -- attribute traffic -----------------------------------------------------------------------
     def _pull(self):
@@ -111,8 +153,13 @@ class LDSPlan(object):
 
     def read(self, node, name):
         kind, i = self.index[id(node)]
-        if kind == "y" or (kind == "x" and name != "qmu" and not self.x_updated):
-            return node.__dict__.get("_h_" + name)          # observations / not yet updated: host copy
+        if kind == "y":
+            return node.__dict__.get("_h_" + name)          # observations: host copy
+        self.flush()
+        if node._plan is not self:
+            return node._plan.read(node, name)
+        if kind == "x" and name != "qmu" and not self.x_updated:
+            return node.__dict__.get("_h_" + name)          # never updated: the constructor's draw (gaussian.py:70-72)
         c = self._pull()
         st, T = c["st"], self.T
         if kind == "x":
@@ -162,9 +209,17 @@ class LDSPlan(object):
     # -- lower bound -----------------------------------------------------------------------------
     def elbo_parts(self):
         self.flush()
+        if self.Xs[0]._plan is not self:        # the queue held something only the generic plan executes
+            raise NotImplementedError("the graph runs node by node now: use Network.learn or the nodes' log_lower_bound()")
         return self.batch.elbo()[0]
 
     def node_llb(self, node):
+        self.flush()
+        if node._plan is not self:
+            return node._plan.node_llb(node)
+        if not self.x_updated:                  # single terms before any sweep: only the generic plan knows the initial covariances
+            self._demote([])
+            return node._plan.node_llb(node)
         kind, _ = self.index[id(node)]
         if kind == "q":
             return float(self.elbo_parts()[4])
@@ -181,17 +236,7 @@ class LDSPlan(object):
         if getattr(self, "_mirror", None) is None or self._mirror_of is not self.cache or self.cache is None:
             from .generic import GenericPlan
             c = self._pull()
-            for nd in self.Xs + self.As + self.Cs:
-                for name in ("qmu", "qcov"):
-                    nd.__dict__["_h_" + name] = self.read(nd, name)
-                try:
-                    nd.__dict__["_h_q_ln_det"] = self.read(nd, "q_ln_det")
-                except Exception:
-                    pass
-            if self.kind == "wishart":
-                self.Q.__dict__["_h_qw"], self.R.__dict__["_h_qw"] = self.read(self.Q, "qw"), self.read(self.R, "qw")
-            else:
-                self.Q.__dict__["_h_qb"], self.R.__dict__["_h_qb"] = self.read(self.Q, "qb"), self.read(self.R, "qb")
+            self._sync_host()
             if getattr(self, "_mirror", None) is not None:
                 self._mirror.ex and self._mirror.ex.close()
             self._mirror = GenericPlan(self.Xs[0], adopt=False)

@@ -441,6 +441,19 @@ int pyvb_lds_get_posterior_classes(pyvb_lds* h, double* Sigma, double* qld_x) {
     return pyvb_lds_sync(h);
 }
 
+int pyvb_lds_set_posterior_classes(pyvb_lds* h, const double* Sigma, const double* qld_x) {
+    ENTER(h);
+    ARGCHK(Sigma, "Sigma is NULL");
+    const size_t N = h->N, D = h->D;
+    int rc;
+    if ((rc = h2d(h, h->Sigma, Sigma, N * 3 * D * D))) return rc;
+    if ((rc = h2d(h, h->qld_x, qld_x, N * 3))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->classes_valid = true;
+    states_changed(h);
+    return PYVB_OK;
+}
+
 int pyvb_lds_get_column_qld(pyvb_lds* h, double* qld_A, double* qld_C) {
     ENTER(h);
     int rc;
@@ -509,6 +522,7 @@ static int ensure_gains(pyvb_lds* h) {
 static void adopt_classes(pyvb_lds* h) {
     double* t = h->Sigma; h->Sigma = h->Sigma_new; h->Sigma_new = t;
     t = h->qld_x; h->qld_x = h->qld_x_new; h->qld_x_new = t;
+    h->classes_valid = true;
 }
 
 static void mark_all_fresh(pyvb_lds* h) {
@@ -523,6 +537,13 @@ static void mark_all_fresh(pyvb_lds* h) {
 
 static int ensure_stats(pyvb_lds* h) {
     if (h->stats_valid) return PYVB_OK;
+    if (!h->classes_valid) {
+        // the reference's X_t start with individual random covariances (gaussian.py:70-72); the three-class form the
+        // statistics use exists once every X_t has been updated, or once the caller has supplied the classes
+        pyvb_set_error("the posterior covariances of the X_t are undefined before the first complete sweep "
+                       "(run pyvb_lds_sweep, or give them with pyvb_lds_set_posterior_classes)");
+        return PYVB_E_STALE;
+    }
     if (h->mixed_cov || (h->gains_valid && h->fresh_count != 0 && h->fresh_count != h->T)) {
         pyvb_set_error("%d of %d X_t were updated since the parameters changed: their covariances differ; sweep all states first",
                        h->fresh_count, h->T);

@@ -109,6 +109,7 @@ struct pyvb_lds {
     bool gains_valid, stats_valid, resQ_valid, resR_valid;
     int fresh_count; unsigned char* fresh;  // X_t updated since the parameters last changed
     bool mixed_cov;                         // the X_t hold covariances of different parameter generations
+    bool classes_valid;                     // Sigma / qld_x describe the X_t (after the first complete sweep, or set by the caller)
     bool timing; KernelTimer timers[PYVB_K_COUNT];
     void* comm; int rank, world;
     // ---- Wishart noise precisions (nodes_todo.py:205-234): dense expectations, dense column covariances

@@ -123,6 +123,12 @@ class LDSBatch(object):
         C.check(C.lib.pyvb_lds_get_posterior_classes(self._h, C.dptr(S), C.dptr(q)))
         return S, q
 
+    def set_posterior_classes(self, Sigma, qld_x=None):
+        """Initial covariances of X_0, the interior X_t and X_{T-1} ([N,3,D,D]); see include/pyvb_hip.h."""
+        S = _f64(Sigma, (self.N, 3, self.D, self.D), "Sigma")
+        q = None if qld_x is None else _f64(qld_x, (self.N, 3), "qld_x")
+        C.check(C.lib.pyvb_lds_set_posterior_classes(self._h, C.dptr(S), C.dptr(q)))
+
     def get_column_qld(self):
         qa, qc = np.empty((self.N, self.D)), np.empty((self.N, self.D))
         C.check(C.lib.pyvb_lds_get_column_qld(self._h, C.dptr(qa), C.dptr(qc)))

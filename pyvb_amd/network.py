@@ -48,6 +48,16 @@ class Network(object):
         for i in range(niters):
             for n in self.iterable_nodes:
                 n.update()
+            plan.flush()
+            if self.iterable_nodes[0]._plan is not plan:        # an update order the fused kernels do not serve: the graph
+                self.llb = float(sum(n.log_lower_bound() for n in self.iterable_nodes))     # runs node by node from here on
+                if verbose:
+                    print(niters - i, self.llb)
+                if self.llb - old_llb < tol:
+                    if verbose:
+                        print("Convergence!")
+                    return
+                return self._learn_generic(niters - i - 1, tol, verbose, old_llb=self.llb)
             self.llb = float(np.sum(plan.elbo_parts()))        # network.py:49
             if verbose:
                 print(niters - i, self.llb)
@@ -57,7 +67,7 @@ class Network(object):
                 break
             old_llb = self.llb
 
-    def _learn_generic(self, niters, tol, verbose):
+    def _learn_generic(self, niters, tol, verbose, old_llb=-np.inf):
         """network.py:40-56 for a graph that runs node by node: per iteration one launch for all update() calls in
         list order and one for the sum of the log_lower_bound() terms; nodes of several unconnected graphs are grouped
         by plan."""
@@ -69,7 +79,6 @@ class Network(object):
             if p not in plans:
                 plans.append(p)
         groups = [(p, [n for n in self.iterable_nodes if n._plan is p]) for p in plans]
-        old_llb = -np.inf
         for i in range(niters):
             for p, group in groups:
                 p.update_all(group)

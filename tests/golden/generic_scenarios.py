@@ -180,6 +180,34 @@ def lds_missing_outputs(nodes, rng):
     return order, named
 
 
+def lds_parameters_first(nodes, rng):
+    """The complete LDS graph (fused plan), but driven in an order the fused kernels do not serve: the columns and the
+    noise nodes are updated BEFORE the states have ever been swept (so every X_t still has its own initial covariance,
+    gaussian.py:70-72), then one state alone, then a regular iteration.  pyvb_amd hands such a sequence to the generic
+    plan (LDSPlan._demote)."""
+    T, D, K = 5, 2, 3
+    As = [nodes.Gaussian(D, np.zeros((D, 1)), np.eye(D) * 1e-3) for _ in range(D)]
+    A = nodes.hstack(As)
+    Cs = [nodes.Gaussian(K, np.zeros((K, 1)), np.eye(K) * 1e-3) for _ in range(D)]
+    C = nodes.hstack(Cs)
+    Q = nodes.DiagonalGamma(D, np.full(D, 1e-3), np.full(D, 1e-3))
+    R = nodes.DiagonalGamma(K, np.full(K, 1e-3), np.full(K, 1e-3))
+    Y = rng.standard_normal((T, K))
+    Xs = [nodes.Gaussian(D, np.zeros((D, 1)), np.eye(D))]
+    Ys = [nodes.Gaussian(K, C * Xs[0], R)]
+    for t in range(1, T):
+        Xs.append(nodes.Gaussian(D, A * Xs[-1], Q))
+        Ys.append(nodes.Gaussian(K, C * Xs[-1], R))
+    for y, row in zip(Ys, Y):
+        y.observe(row.reshape(K, 1).copy())
+    named = {"Q": Q, "R": R}
+    for nm, lst in (("X", Xs), ("Y", Ys), ("a", As), ("c", Cs)):
+        named.update({"%s%02d" % (nm, i): n for i, n in enumerate(lst)})
+    _init_all(named, rng)
+    order = As + Cs + [Q, R, Xs[2]] + Xs + Xs[::-1] + As + Cs + [Q, R]
+    return order, named
+
+
 def wishart_precision(nodes, rng):
     """A Wishart precision over vector observations with an unknown mean (nodes_todo.py:205-234).  Only the state after
     the FIRST pass is a valid reference target (the reference mutates its prior)."""
@@ -209,7 +237,11 @@ SCENARIOS = {
     "partial_observations": (partial_observations, 109, (1, 3), []),
     "lds_missing_outputs": (lds_missing_outputs, 110, (1, 3), []),
     "wishart_precision": (wishart_precision, 111, (1,), []),
+    "lds_parameters_first": (lds_parameters_first, 112, (1, 2), []),
 }
+
+# scenarios whose graph binds to a fused plan first (needs the GPU even though they end up node by node)
+NEEDS_DEVICE = ("lds_parameters_first",)
 
 
 def snapshot(named):

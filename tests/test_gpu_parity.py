@@ -258,6 +258,31 @@ def test_partial_state_updates_are_refused():
     b.close()
 
 
+def test_parameters_before_any_sweep():
+    """A fresh handle has no covariances for the X_t (the reference draws an individual one per node): the library says so
+    (PYVB_E_STALE) instead of using zeros; with per-class initial covariances supplied it matches the oracle."""
+    from pyvb_amd import _capi
+    T, D, K, N = 30, 4, 5, 2
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=8)
+    b = _batch(Y, st0, pri)
+    for call in (b.update_A, b.update_Q, b.elbo):
+        with pytest.raises(_capi.PyvbHipError) as e:
+            call()
+        assert e.value.code == _capi.E_STALE
+    rng = np.random.default_rng(1)
+    Sig = np.stack([np.eye(D) / u for u in rng.random(N * 3)]).reshape(N, 3, D, D)
+    b.set_posterior_classes(Sig)
+    st = O.expand_state(st0, pri, T)
+    st["Sigma"], st["qld_x"] = Sig, np.zeros((N, 3))
+    S = O.statistics(st, Y)
+    O.update_A(st, pri, S); b.update_A()
+    O.update_C(st, pri, S); b.update_C()
+    O.update_Q(st, pri, S, T); b.update_Q()
+    O.update_R(st, pri, S, T); b.update_R()
+    _compare_params(b, st, "before any sweep ")
+    b.close()
+
+
 def test_not_positive_definite_raises():
     Y, st0, pri = synth.make_problem(20, 4, 4, 1, seed=3)
     st0["Q_b"] = -np.abs(st0["Q_b"]) * 1e-9        # hugely negative expected precision
