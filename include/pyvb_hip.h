@@ -11,8 +11,9 @@
  * the stub a maintainer of the reference would add.
  *
  * Conventions
- *   - plain C, opaque handle, one handle per GPU, no global state besides the
- *     thread-local error string; thread-compatible (one host thread per handle).
+ *   - plain C, opaque handle, one handle per GPU; global state: the thread-local error string and the RCCL entry
+ *     points (dlopen'ed once, under a lock, when a communicator is first asked for); thread-compatible (one host
+ *     thread per handle).
  *   - every function returns 0 on success or a pyvb_status; pyvb_last_error() gives
  *     the message of the last failure on the calling thread.
  *   - all arrays are caller-owned HOST buffers of float64, C-contiguous, leading axis N
@@ -134,6 +135,11 @@ int pyvb_lds_get_elbo(pyvb_lds* h, double* parts);
 int pyvb_lds_elbo_total(pyvb_lds* h, double out[6]);
 /* niters passes of: forward sweep, backward sweep, A, C, Q, R, ELBO (the example's loop body plus network.py:49). */
 int pyvb_lds_iterate(pyvb_lds* h, int niters);
+/* pyvb_lds_iterate evaluates the lower bound of every iteration on a side stream (it feeds nothing in the next one) and
+ * keeps the six parts, summed over the replicates and -- with a communicator attached -- over all ranks, in a ring of the
+ * last 4096 iterations.  out[count][6], oldest first; synchronises. */
+int pyvb_lds_get_elbo_history(pyvb_lds* h, double* out, int max_count, int* count);
+int pyvb_lds_reset_elbo_history(pyvb_lds* h);
 int pyvb_lds_sync(pyvb_lds* h);
 
 /* HIP-event timing of the kernels on the handle's stream (for bench.py's roofline figures). */

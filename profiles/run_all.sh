@@ -22,5 +22,5 @@ python3 $ROOT/profiles/pmc_summary.py $OUT/pmc/p_counter_collection.csv $OUT/pmc
 cd $ROOT && bash profiles/collect_traffic.sh $TAG > $OUT/traffic.log 2>&1
 cp $ROOT/gpurun_out/traffic_$TAG/traffic.json $OUT/traffic_pmc.json
 
-if [ -x $ROOT/profiles/microbench/mb_f64 ]; then $ROOT/profiles/microbench/mb_f64 > $OUT/microbench_f64.txt 2>&1; fi
+for mb in mb_f64 mb_power mb_copy; do if [ -x $ROOT/profiles/microbench/$mb ]; then $ROOT/profiles/microbench/$mb > $OUT/$mb.txt 2>&1; fi; done
 ls -l $OUT

@@ -52,6 +52,8 @@ SIGNATURES = {
     "pyvb_lds_get_elbo": (ctypes.c_int, [_h, _dp]),
     "pyvb_lds_elbo_total": (ctypes.c_int, [_h, _dp]),
     "pyvb_lds_iterate": (ctypes.c_int, [_h, ctypes.c_int]),
+    "pyvb_lds_get_elbo_history": (ctypes.c_int, [_h, _dp, ctypes.c_int, _ip]),
+    "pyvb_lds_reset_elbo_history": (ctypes.c_int, [_h]),
     "pyvb_lds_sync": (ctypes.c_int, [_h]),
     "pyvb_lds_timing_enable": (ctypes.c_int, [_h, ctypes.c_int]),
     "pyvb_lds_timing_reset": (ctypes.c_int, [_h]),

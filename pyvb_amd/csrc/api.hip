@@ -7,6 +7,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <mutex>
 #include <dlfcn.h>
 
 static thread_local char g_err[512] = "";
@@ -22,22 +23,26 @@ int pyvb_hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return PYVB_E_HIP;
 }
 
-TimedLaunch::TimedLaunch(pyvb_lds* h_, int k_) : h(h_), slot(-1) {
+TimedLaunch::TimedLaunch(pyvb_lds* h_, int k_, hipStream_t s_) : h(h_), slot(-1), s(s_ ? s_ : h_->stream) {
     if (!h->timing) return;
     if (h->pool_used == PYVB_EVENT_POOL) pyvb_timing_resolve(h);     // pool exhausted: drain (synchronises)
     slot = h->pool_used++;
     h->pool[slot].kernel = k_;
-    (void)hipEventRecord(h->pool[slot].e0, h->stream);
+    if (hipEventRecord(h->pool[slot].e0, s) != hipSuccess) { h->timing_errors += 1; h->pool[slot].kernel = -1; }
 }
-TimedLaunch::~TimedLaunch() { if (slot >= 0) (void)hipEventRecord(h->pool[slot].e1, h->stream); }
+TimedLaunch::~TimedLaunch() {
+    if (slot >= 0 && hipEventRecord(h->pool[slot].e1, s) != hipSuccess) { h->timing_errors += 1; h->pool[slot].kernel = -1; }
+}
 
 void pyvb_timing_resolve(pyvb_lds* h) {
     for (int i = 0; i < h->pool_used; ++i) {
         float ms = 0;
-        (void)hipEventSynchronize(h->pool[i].e1);
-        if (hipEventElapsedTime(&ms, h->pool[i].e0, h->pool[i].e1) == hipSuccess) {
+        if (h->pool[i].kernel < 0) continue;                          // an event of this pair was never recorded
+        if (hipEventSynchronize(h->pool[i].e1) == hipSuccess && hipEventElapsedTime(&ms, h->pool[i].e0, h->pool[i].e1) == hipSuccess) {
             h->timers[h->pool[i].kernel].total_ms += ms;
             h->timers[h->pool[i].kernel].launches += 1;
+        } else {
+            h->timing_errors += 1;
         }
     }
     h->pool_used = 0;
@@ -83,6 +88,9 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
 #define TRY(x) do { rc = (x); if (rc != PYVB_OK) { pyvb_lds_destroy(h); return rc; } } while (0)
 #define TRYHIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { rc = pyvb_hip_fail(_e, #x, __FILE__, __LINE__); pyvb_lds_destroy(h); return rc; } } while (0)
     TRYHIP(hipStreamCreate(&h->stream));
+    TRYHIP(hipStreamCreate(&h->side));
+    TRYHIP(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
+    TRYHIP(hipEventCreateWithFlags(&h->ev_elbo, hipEventDisableTiming));
     h->pool = (EventPair*)calloc(PYVB_EVENT_POOL, sizeof(EventPair));
     for (int i = 0; i < PYVB_EVENT_POOL; ++i) { TRYHIP(hipEventCreate(&h->pool[i].e0)); TRYHIP(hipEventCreate(&h->pool[i].e1)); }
     const size_t n = (size_t)N;
@@ -134,6 +142,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRY(dev_alloc(&h->sxx, n * (size_t)h->W * L.DP * L.DP));
     TRY(dev_alloc(&h->resQ, n * D)); TRY(dev_alloc(&h->resR, n * K));
     TRY(dev_alloc(&h->elbo, n * 6)); TRY(dev_alloc(&h->elbo_sum, 8));
+    TRY(dev_alloc(&h->elbo_hist, (size_t)PYVB_ELBO_HISTORY * 8));
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int)));
     TRYHIP(hipMemset(h->status, 0, sizeof(int)));
     // priors block: x0_mean D, x0_prec D*D, A_pm D*D, A_pp D*D, C_pm K*D, C_pp D*K, Q_a0 D, Q_b0 D, R_a0 K, R_b0 K
@@ -178,7 +187,12 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     if (!h) return PYVB_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->side) (void)hipStreamSynchronize(h->side);
     pyvb_lds_comm_destroy(h);
+    if (h->elbo_hist) (void)hipFree(h->elbo_hist);
+    if (h->ev_params) (void)hipEventDestroy(h->ev_params);
+    if (h->ev_elbo) (void)hipEventDestroy(h->ev_elbo);
+    if (h->side) (void)hipStreamDestroy(h->side);
     double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
                       h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->sxx, h->U,
@@ -653,6 +667,16 @@ int pyvb_lds_get_elbo(pyvb_lds* h, double* parts) {
     return pyvb_lds_sync(h);
 }
 
+// The main stream may not overwrite what a lower-bound evaluation still in flight on the side stream reads
+// (the states: next backward sweep; the parameters: next column update).
+static int join_elbo(pyvb_lds* h) {
+    if (h->elbo_in_flight) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_elbo, 0));
+        h->elbo_in_flight = false;
+    }
+    return PYVB_OK;
+}
+
 int pyvb_lds_iterate(pyvb_lds* h, int niters) {
     ENTER(h);
     ARGCHK(niters >= 0, "niters must be >= 0");
@@ -660,9 +684,8 @@ int pyvb_lds_iterate(pyvb_lds* h, int niters) {
     for (int it = 0; it < niters; ++it) {
         // the backward sweep follows at once and reads c_t, not the forward states: those are not written out
         if ((rc = sweep(h, PYVB_FORWARD, false))) return rc;
+        if ((rc = join_elbo(h))) return rc;
         if ((rc = sweep(h, PYVB_BACKWARD, true))) return rc;
-        // A and C are independent given the statistics, and so are Q and R given A and C: the pairs
-        // share launches here (same arithmetic as update_A, update_C, update_Q, update_R in turn)
         if (h->dense) {
             if ((rc = pyvb_lds_update_columns(h, 0, 0, h->D))) return rc;
             if ((rc = pyvb_lds_update_columns(h, 1, 0, h->D))) return rc;
@@ -671,18 +694,51 @@ int pyvb_lds_iterate(pyvb_lds* h, int niters) {
             if ((rc = pyvb_lds_elbo(h))) return rc;
             continue;
         }
+        // A and C are independent given the statistics, and so are Q and R given A and C: the pairs
+        // share launches here (same arithmetic as update_A, update_C, update_Q, update_R in turn)
         if ((rc = ensure_stats(h))) return rc;
         if ((rc = launch_cols(h, 2, 0, h->D, 3))) return rc;       // columns, residuals and noise update in one launch
         params_changed(h);
         h->resQ_valid = h->resR_valid = true;
-        if ((rc = pyvb_lds_elbo(h))) return rc;
+        // The lower bound (network.py:49) feeds nothing in the next iteration: it is evaluated on the side stream while
+        // the main one goes on with k_prep and the forward sweep.  Its per-iteration totals (summed over the replicates,
+        // and over the ranks when a communicator is attached) go into a history ring (pyvb_lds_get_elbo_history).
+        HIPCHK(hipEventRecord(h->ev_params, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->side, h->ev_params, 0));
+        if ((rc = launch_elbo(h, h->side))) return rc;
+        double* slot = h->elbo_hist + (size_t)(h->hist_count % PYVB_ELBO_HISTORY) * 8;
+        if ((rc = launch_elbo_sum(h, slot, h->side))) return rc;
+        if (h->comm && (rc = pyvb_allreduce_f64(h->comm, slot, 6, h->side))) return rc;
+        h->hist_count += 1;
+        HIPCHK(hipEventRecord(h->ev_elbo, h->side));
+        h->elbo_in_flight = true;
     }
-    return PYVB_OK;
+    // later calls on the main stream (and the host, through pyvb_lds_sync) see the last lower bound complete
+    return join_elbo(h);
 }
+
+int pyvb_lds_get_elbo_history(pyvb_lds* h, double* out, int max_count, int* count) {
+    ENTER(h);
+    ARGCHK(out && count && max_count >= 0, "bad arguments");
+    int n = h->hist_count < PYVB_ELBO_HISTORY ? h->hist_count : PYVB_ELBO_HISTORY;
+    if (n > max_count) n = max_count;
+    HIPCHK(hipStreamSynchronize(h->side));
+    std::vector<double> tmp((size_t)n * 8);
+    for (int i = 0; i < n; ++i) {            // the most recent n rows, oldest first
+        const size_t row = (size_t)((h->hist_count - n + i) % PYVB_ELBO_HISTORY);
+        HIPCHK(hipMemcpy(tmp.data() + (size_t)i * 8, h->elbo_hist + row * 8, 6 * sizeof(double), hipMemcpyDeviceToHost));
+        for (int p = 0; p < 6; ++p) out[(size_t)i * 6 + p] = tmp[(size_t)i * 8 + p];
+    }
+    *count = n;
+    return pyvb_lds_sync(h);
+}
+
+int pyvb_lds_reset_elbo_history(pyvb_lds* h) { ENTER(h); HIPCHK(hipStreamSynchronize(h->side)); h->hist_count = 0; return PYVB_OK; }
 
 int pyvb_lds_sync(pyvb_lds* h) {
     ENTER(h);
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->side));
     int st = 0;
     HIPCHK(hipMemcpy(&st, h->status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) {
@@ -699,6 +755,7 @@ int pyvb_lds_timing_get(pyvb_lds* h, int kernel, double* total_ms, int* launches
     ENTER(h);
     ARGCHK(kernel >= 0 && kernel < PYVB_K_COUNT, "no such kernel id");
     pyvb_timing_resolve(h);
+    if (h->timing_errors) { pyvb_set_error("%d timing events could not be recorded or resolved", h->timing_errors); h->timing_errors = 0; return PYVB_E_HIP; }
     if (total_ms) *total_ms = h->timers[kernel].total_ms;
     if (launches) *launches = h->timers[kernel].launches;
     return PYVB_OK;
@@ -713,7 +770,10 @@ typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 static struct { void* lib; fn_getuid getuid; fn_initrank initrank; fn_allreduce allreduce; fn_destroy destroy; fn_errstr errstr; } g_nccl;
 
+// The only process-wide state of the library: the dlopen'ed RCCL entry points, set once under a lock.
+static std::mutex g_nccl_lock;
 static int load_rccl() {
+    std::lock_guard<std::mutex> guard(g_nccl_lock);
     if (g_nccl.lib) return PYVB_OK;
     void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);

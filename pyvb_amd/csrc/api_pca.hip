@@ -256,22 +256,33 @@ int pyvb_pca_update_Z(pyvb_pca* h) {
     return PYVB_OK;
 }
 
+// Xs[0].update() alone (the crawl order of fetch_network puts it before Mu): sum x is kept current without a pass over
+// all rows.  With a communicator this is a collective step for every rank: the owner of global row 0 (row_offset == 0)
+// updates it, everyone exchanges [sum z | delta of sum x]; the sum of z travels once, from the owner.
+static int x0_step(pyvb_pca* h) {
+    int rc;
+    if (!h->lin_valid && (rc = ensure_full(h))) return rc;
+    double* v = h->aux + (size_t)4 * h->nchunk * h->QP;
+    HIPCHK(hipMemcpyAsync(v, h->stats + h->SL.osz, h->QP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (h->comm && h->row_offset != 0)
+        HIPCHK(hipMemsetAsync(v, 0, h->QP * sizeof(double), h->stream));
+    if ((rc = pca_launch_small(h, PCA_X0))) return rc;      // a no-op for the data of the other ranks (k_pca.hip checks row_offset)
+    if ((rc = exchange_lin(h))) return rc;
+    h->full_valid = false; h->res_valid = false;
+    return PYVB_OK;
+}
+
+// Xs[lo:hi] updates + every sum over n; collective (the statistics are all-reduced) even for an empty range
+static int x_rows(pyvb_pca* h, long lo, long hi) {
+    if (lo == hi && !h->comm) return PYVB_OK;
+    return full_stats(h, lo, hi);
+}
+
 int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi) {
     ENTER(h);
     ARGCHK(lo >= 0 && lo <= hi && hi <= h->N, "bad row range");
-    if (lo == hi) return PYVB_OK;
-    int rc;
-    if (lo == 0 && hi == 1) {        // Xs[0] alone: keep sum x current without a pass over all rows
-        if (!h->lin_valid && (rc = ensure_full(h))) return rc;
-        HIPCHK(hipMemcpyAsync(h->aux + (size_t)4 * h->nchunk * h->QP, h->stats + h->SL.osz, h->QP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        if (h->comm && h->rank != 0)    // the sum of z travels once: every rank but 0 contributes zero to it
-            HIPCHK(hipMemsetAsync(h->aux + (size_t)4 * h->nchunk * h->QP, 0, h->QP * sizeof(double), h->stream));
-        if ((rc = pca_launch_small(h, PCA_X0))) return rc;
-        if ((rc = exchange_lin(h))) return rc;
-        h->full_valid = false; h->res_valid = false;
-        return PYVB_OK;
-    }
-    return full_stats(h, lo, hi);
+    if (lo == 0 && hi == 1 && h->row_offset == 0) return x0_step(h);        // this rank owns global row 0
+    return x_rows(h, lo, hi);
 }
 
 int pyvb_pca_update_Mu(pyvb_pca* h) {
@@ -312,9 +323,9 @@ int pyvb_pca_iterate(pyvb_pca* h, int niters) {
         if ((rc = pyvb_pca_update_W(h))) return rc;
         if ((rc = pyvb_pca_update_Z(h))) return rc;
         const long first = h->row_offset == 0 ? 1 : 0;         // global row 0 lives on the rank with offset 0
-        if ((rc = pyvb_pca_update_X(h, 0, 1))) return rc;       // (a no-op for the data on other ranks, but the exchange is collective)
+        if ((rc = x0_step(h))) return rc;                       // every rank: the exchange is collective
         if ((rc = pyvb_pca_update_Mu(h))) return rc;
-        if ((rc = pyvb_pca_update_X(h, first, h->N))) return rc;
+        if ((rc = x_rows(h, first, h->N))) return rc;           // every rank, even with no rows left (N == 1 on the owner)
         if ((rc = pyvb_pca_update_Beta(h))) return rc;
         if ((rc = pyvb_pca_elbo(h, nullptr))) return rc;
     }
@@ -323,6 +334,8 @@ int pyvb_pca_iterate(pyvb_pca* h, int niters) {
 
 int pyvb_pca_comm_init(pyvb_pca* h, const char id[128], int rank, int world) {
     ENTER(h);
+    ARGCHK(world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+    ARGCHK((rank == 0) == (h->row_offset == 0), "rows shard contiguously in rank order: rank 0, and only rank 0, holds global row 0");
     int rc = pyvb_comm_create(&h->comm, id, rank, world);
     if (rc) return rc;
     h->rank = rank; h->world = world;

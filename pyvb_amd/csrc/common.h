@@ -110,7 +110,7 @@ struct pyvb_lds {
     int fresh_count; unsigned char* fresh;  // X_t updated since the parameters last changed
     bool mixed_cov;                         // the X_t hold covariances of different parameter generations
     bool classes_valid;                     // Sigma / qld_x describe the X_t (after the first complete sweep, or set by the caller)
-    bool timing; KernelTimer timers[PYVB_K_COUNT];
+    bool timing; KernelTimer timers[PYVB_K_COUNT]; int timing_errors;
     void* comm; int rank, world;
     // ---- Wishart noise precisions (nodes_todo.py:205-234): dense expectations, dense column covariances
     bool dense;                     // noise == PYVB_NOISE_WISHART
@@ -123,7 +123,13 @@ struct pyvb_lds {
     double *SyyF;                   // [N][K][K] sum_t y y^T
     double *RQ, *RR;                // [N][D][D], [N][K][K]: sum over children of 1/2<xx^T> + 1/2<mu mu^T> - <x><mu>^T
     bool expect_valid;              // Qbar, Rbar, lnd belong to the current Q_w, R_w
+    // ---- the lower bound does not feed the next iteration: inside pyvb_lds_iterate it runs on a side stream
+    hipStream_t side;
+    hipEvent_t ev_params, ev_elbo;  // parameters of this iteration complete (main) / lower bound of it read them (side)
+    bool elbo_in_flight;            // ev_elbo has been recorded and not yet waited for by the main stream
+    double* elbo_hist; int hist_count;      // [PYVB_ELBO_HISTORY][8]: parts summed over replicates (and ranks), one row per iteration
 };
+#define PYVB_ELBO_HISTORY 4096
 
 // ---- launchers implemented in the kernel translation units ----
 int launch_prep(pyvb_lds* h);
@@ -137,8 +143,8 @@ int launch_observe(pyvb_lds* h);
 int launch_cols(pyvb_lds* h, int which, int c0, int c1, int fuse = 0);   // which: 0 = A, 1 = C, 2 = both; columns [c0, c1); fuse: see k_cols.hip
 int launch_resid(pyvb_lds* h, int which);     // 0 = Q, 1 = R
 int launch_noise(pyvb_lds* h, int which);
-int launch_elbo(pyvb_lds* h);
-int launch_elbo_sum(pyvb_lds* h);
+int launch_elbo(pyvb_lds* h, hipStream_t stream = nullptr);                           // stream: the handle's main one unless given
+int launch_elbo_sum(pyvb_lds* h, double* out = nullptr, hipStream_t stream = nullptr);    // out: h->elbo_sum unless given
 // k_wishart.hip
 int launch_wexpect(pyvb_lds* h);                    // Qbar, Rbar, lnd from Q_w, R_w
 int launch_dense_pre(pyvb_lds* h);                  // QA, RC, trA, trC
@@ -147,6 +153,11 @@ int launch_wresid(pyvb_lds* h, int which, int update);
 int launch_syy_full(pyvb_lds* h);
 int launch_elbo_dense(pyvb_lds* h);
 int launch_colvar_to_cov(pyvb_lds* h);              // A_var/C_var (diagonals) -> A_cov/C_cov
+
+// RCCL, shared by the LDS and the PCA path (api.hip)
+int pyvb_comm_create(void** comm, const char id[128], int rank, int world);
+void pyvb_comm_free(void* comm);
+int pyvb_allreduce_f64(void* comm, double* buf, size_t count, hipStream_t stream);
 
 void pyvb_set_error(const char* fmt, ...);
 int pyvb_hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -158,8 +169,8 @@ int pyvb_hip_fail(hipError_t e, const char* what, const char* file, int line);
 #define PYVB_EVENT_POOL 2048
 struct EventPair { hipEvent_t e0, e1; int kernel; };
 struct TimedLaunch {
-    pyvb_lds* h; int slot;
-    TimedLaunch(pyvb_lds* h_, int k_);
+    pyvb_lds* h; int slot; hipStream_t s;
+    TimedLaunch(pyvb_lds* h_, int k_, hipStream_t s_ = nullptr);
     ~TimedLaunch();
 };
 void pyvb_timing_resolve(pyvb_lds* h);

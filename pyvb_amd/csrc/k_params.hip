@@ -232,17 +232,18 @@ int launch_noise(pyvb_lds* h, int which) {
     return PYVB_OK;
 }
 
-int launch_elbo(pyvb_lds* h) {
+int launch_elbo(pyvb_lds* h, hipStream_t stream) {
     ParamArgs a = make_args(h);
-    TimedLaunch tl(h, PYVB_K_ELBO);
-    hipLaunchKernelGGL(k_elbo, dim3(h->N), dim3(64), 0, h->stream, a);
+    if (!stream) stream = h->stream;
+    TimedLaunch tl(h, PYVB_K_ELBO, stream);
+    hipLaunchKernelGGL(k_elbo, dim3(h->N), dim3(64), 0, stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
 
-int launch_elbo_sum(pyvb_lds* h) {
-    SumArgs a; a.elbo = h->elbo; a.out = h->elbo_sum; a.N = h->N;
-    hipLaunchKernelGGL(k_elbo_sum, dim3(1), dim3(256), 0, h->stream, a);
+int launch_elbo_sum(pyvb_lds* h, double* out, hipStream_t stream) {
+    SumArgs a; a.elbo = h->elbo; a.out = out ? out : h->elbo_sum; a.N = h->N;
+    hipLaunchKernelGGL(k_elbo_sum, dim3(1), dim3(256), 0, stream ? stream : h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

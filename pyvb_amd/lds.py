@@ -188,6 +188,17 @@ class LDSBatch(object):
         """niters x (forward sweep, backward sweep, A, C, Q, R, lower bound); asynchronous."""
         C.check(C.lib.pyvb_lds_iterate(self._h, int(niters)))
 
+    def elbo_history(self, last=4096):
+        """Lower-bound parts of the most recent iterate() iterations, [count, 6], summed over the replicates (and over
+        the ranks when a communicator is attached); oldest first."""
+        out = np.empty((int(last), 6))
+        cnt = C.ctypes.c_int()
+        C.check(C.lib.pyvb_lds_get_elbo_history(self._h, C.dptr(out), int(last), C.ctypes.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def reset_elbo_history(self):
+        C.check(C.lib.pyvb_lds_reset_elbo_history(self._h))
+
     def sync(self):
         C.check(C.lib.pyvb_lds_sync(self._h))
 

@@ -1,0 +1,66 @@
+"""bench.py itself on the GPU box, at a small shape: the JSON contract, the parity check on the timed batch, and the
+multi-GPU code path as far as one GPU allows (RCCL communicator creation, the all-reduce inside the timed loop, the
+failure policy when no communicator can be made)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--replicates", "6", "--T", "400", "--D", "16", "--K", "16", "--steps", "3", "--warmup", "1", "--parity-replicates", "2"]
+
+
+def _run(cmd, env=None, timeout=600):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run(cmd, cwd=REPO, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_and_parity_of_the_timed_batch():
+    r = _run([sys.executable, "bench.py"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["config"]["elbo_rel_err_vs_numpy"] < 1e-8 and d["config"]["state_rel_err_vs_numpy"] < 1e-8
+    assert "timed batch" in d["config"]["parity_checked_on"] and d["config"]["degraded"] is False
+    rf = d["roofline"]
+    assert rf["frac"] <= 1.0 and all(v["frac"] <= 1.0 for v in rf["secondary"].values())
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+def test_one_rank_rccl_communicator_through_the_multi_gpu_branch():
+    r = _run([sys.executable, "bench.py", "--rccl-single", "--no-cpu-baseline"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["config"]["collective"].startswith("rccl allreduce") and d["config"]["degraded"] is False
+
+
+def test_two_ranks_on_one_gpu_fail_loudly_or_run_over_rccl():
+    """Two processes on the one GPU of this box: RCCL normally refuses two ranks on one device.  Without
+    --allow-gloo-fallback that must end the run with a non-zero status (never a silent gloo number); with it the line is
+    marked degraded.  (If this RCCL build does accept it, the line must say rccl.)"""
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    r = _run(launch + ["--master-port", "29611", "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL, env)
+    if r.returncode == 0:
+        d = _line(r.stdout)
+        assert d["n_gpus"] == 2 and d["config"]["collective"].startswith("rccl") and d["config"]["degraded"] is False
+        assert d["config"]["replicates_total"] == 12
+    else:
+        assert "RCCL communicator could not be created" in (r.stderr + r.stdout)
+        r2 = _run(launch + ["--master-port", "29612", "bench.py", "--gpus", "2", "--no-cpu-baseline", "--allow-gloo-fallback"] + SMALL, env)
+        assert r2.returncode == 0, r2.stderr[-2000:]
+        d = _line(r2.stdout)
+        assert d["n_gpus"] == 2 and d["config"]["degraded"] is True and "DEGRADED" in d["config"]["collective"]

@@ -33,3 +33,13 @@ def test_error_string_and_argument_checks_without_gpu():
     assert b"T must be" in _capi.lib.pyvb_last_error()
     rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 10, 65, 4, 0)
     assert rc == _capi.E_ARG
+
+
+def test_library_has_no_unresolved_symbols_of_its_own():
+    """A shared library links with undefined symbols silently; every pyvb_* symbol one translation unit calls must be
+    defined by another (with the same linkage)."""
+    import subprocess
+    from pyvb_amd import _capi
+    out = subprocess.run(["nm", "-D", "--undefined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    bad = [l for l in out.splitlines() if "pyvb" in l or "launch_" in l]
+    assert not bad, bad

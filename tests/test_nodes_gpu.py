@@ -154,3 +154,28 @@ def test_pca_example_through_network_learn():
             assert abs(net.llb - ref) <= RTOL * abs(ref)
             # the accessor the example prints (PCA_missing_data.py:92)
             assert abs(g["Beta"].pass_down_Ex()[0, 0] - float(z[tag + "beta_a"]) / float(z[tag + "beta_b"])) <= 1e-8 * g["Beta"].pass_down_Ex()[0, 0]
+
+
+def test_integration_stub_runs():
+    """The ctypes stub of INTEGRATION.md section 2 (what a maintainer of the reference would add), executed as printed:
+    node objects in, posteriors and the lower bound out, compared with the oracle."""
+    import os
+    import re
+    from pyvb_amd import nodes, synth, _capi
+    from oracle import lds_closed_form as O
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(repo, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "def lds_iterate" in b]
+    assert len(stub) == 1
+    ns = {}
+    exec(stub[0].replace('"libpyvb_hip.so"', repr(_capi.LIB_PATH)), ns)
+    T, D, K = 60, 3, 4
+    Y, st0, pri = synth.make_problem(T, D, K, 1, 77)
+    g = _golden_module().build_graph(nodes, Y[0], pri, st0)     # stands for a graph built from the reference's classes
+    total = ns["lds_iterate"](g["Xs"], g["Ys"], g["As"], g["Cs"], g["Q"], g["R"], 3)
+    st = O.expand_state(st0, pri, T)
+    for _ in range(3):
+        parts = O.iterate(st, pri, Y)
+    assert abs(total - parts.sum()) <= RTOL * abs(parts.sum())
+    assert _rel(np.hstack([x.__dict__["_h_qmu"] for x in g["Xs"]]).T, st["X"][0]) <= RTOL
