@@ -25,8 +25,11 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X vendor figure for FP64 matrix (= FP64 vector); profiles/r01/microbench_f64.txt measures 73.8 sustained
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X vendor figure for FP64 matrix (= FP64 vector); a pure MFMA loop sustains 77 (profiles/r02/mb_power.txt)
 HBM_PEAK_GBS = 8000.0
+# With real data the sweeps run the chip into its power cap (1343 W, shader clock 2055 of 2400 MHz: profiles/r02/limits.txt);
+# the matrix pipe's peak at that clock, reported next to the contract figure:
+CAPPED_CLOCK_RATIO = 2055.0 / 2400.0
 
 
 def make_inputs(T, D, K, N, seed):
@@ -247,7 +250,10 @@ def main():
                 "kernel": dom.get("kernel"), "launches": dom.get("launches"), "mean_launch_ms": dom.get("mean_launch_ms"),
                 "algorithmic_flops_per_launch": work["sweep_fwd"]["algorithmic_flops"],
                 "algorithmic_bytes_per_launch": work["sweep_fwd"]["algorithmic_bytes"],
-                "secondary": {k: v for k, v in entries.items() if k != "sweep_fwd"}}
+                "secondary": {k: v for k, v in entries.items() if k != "sweep_fwd"},
+                "power_cap": {"peak_at_capped_clock": FP64_MFMA_PEAK_TFLOPS * CAPPED_CLOCK_RATIO,
+                              "frac_of_capped_peak": dom.get("achieved", 0.0) / (FP64_MFMA_PEAK_TFLOPS * CAPPED_CLOCK_RATIO),
+                              "source": "profiles/r02/limits.txt (rocm-smi during the sweeps: 1343 W, sclk 2055 MHz; not measured in this run)"}}
     # the whole iteration against the same peak: SURVEY.md section 8(d) work model (sweeps + statistics) over the wall time
     # of a step -- independent of which kernel a piece of the work is fused into -- and the flops actually executed
     iter_flops = float(N) * T * (12 * D * D + 6 * D * K + 2 * K)

@@ -211,7 +211,11 @@ int pyvb_lds_destroy(pyvb_lds* h) {
 }
 
 static void states_changed(pyvb_lds* h);
-#define ENTER(h) do { ARGCHK(h, "handle is NULL"); HIPCHK(hipSetDevice((h)->device)); } while (0)
+static int join_elbo(pyvb_lds* h);
+// Every entry point but pyvb_lds_iterate first lets the main stream wait for a lower-bound evaluation that the last
+// pyvb_lds_iterate may have left in flight on the side stream (it reads states and parameters).
+#define ENTER_RAW(h) do { ARGCHK(h, "handle is NULL"); HIPCHK(hipSetDevice((h)->device)); } while (0)
+#define ENTER(h) do { ENTER_RAW(h); if ((h)->elbo_in_flight) { int _rc = join_elbo(h); if (_rc) return _rc; } } while (0)
 
 static int h2d(pyvb_lds* h, double* dst, const double* src, size_t n) {
     if (!src) return PYVB_OK;
@@ -678,7 +682,7 @@ static int join_elbo(pyvb_lds* h) {
 }
 
 int pyvb_lds_iterate(pyvb_lds* h, int niters) {
-    ENTER(h);
+    ENTER_RAW(h);
     ARGCHK(niters >= 0, "niters must be >= 0");
     int rc;
     for (int it = 0; it < niters; ++it) {
@@ -713,8 +717,9 @@ int pyvb_lds_iterate(pyvb_lds* h, int niters) {
         HIPCHK(hipEventRecord(h->ev_elbo, h->side));
         h->elbo_in_flight = true;
     }
-    // later calls on the main stream (and the host, through pyvb_lds_sync) see the last lower bound complete
-    return join_elbo(h);
+    // the last lower bound may still be in flight: the next pyvb_lds_iterate overlaps it with its k_prep and forward
+    // sweep, any other entry point joins it first (ENTER), pyvb_lds_sync waits for both streams
+    return PYVB_OK;
 }
 
 int pyvb_lds_get_elbo_history(pyvb_lds* h, double* out, int max_count, int* count) {
