@@ -326,6 +326,8 @@ def describe(start):
     T, D, K = len(Xs), A.shape[0], C.shape[0]
     if T < 2 or A.shape != (D, D) or C.shape != (K, D) or X0.shape[0] != D:
         _fail("shapes")
+    if D > 64 or K > 64:
+        _fail("the fused LDS kernels hold one 64 x 64 matrix per wavefront: D, K <= 64")
     Q, R = Xs[1].precision_parent, Ys[0].precision_parent
     if Q is R or any(x.precision_parent is not Q for x in Xs[1:]) or any(y.precision_parent is not R for y in Ys):
         _fail("noise precisions are not shared along the chain")
@@ -400,6 +402,8 @@ def describe_pca(start):
     W, Beta = stacks[0], gammas[0]
     Ws = W.parents
     d, q = W.shape
+    if d > 256 or q > 32:
+        _fail("the fused PCA kernels are built for d <= 256, q <= 32")
     Mu, Zs, Xs = None, [], []
     # the X_n in construction order = the order in which Beta adopted them as children
     for x in Beta.children:

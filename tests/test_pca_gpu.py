@@ -123,3 +123,37 @@ def test_single_rank_communicator_is_transparent():
         assert np.array_equal(ga[k], gb[k]), k
     assert np.array_equal(a.elbo(), b.elbo())
     a.close(); b.close()
+
+
+def test_baseline_config5_full_size_on_one_gpu():
+    """BASELINE configs[4] at its full size on one GPU: N = 10^6 rows x d = 256, q = 16, Bernoulli(0.1) mask -- one
+    Network.learn iteration against the oracle (about a minute of numpy), then a size-independent property: the rows
+    after the first can be permuted without changing the posteriors of W, Mu and Beta (sums over n in another order)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    from pyvb_amd.pca import PCABatch
+    N, d, q = 1000000, 256, 16
+    init, pri = G.pca_problem(N, d, q, seed=2024, p_missing=0.1)
+    st = P.make_state(init, pri, N, d, q)
+    ref = P.iterate(st, pri)
+    b = PCABatch.from_problem(init, pri)
+    b.iterate(1)
+    got = b.elbo()
+    g = b.get_state()
+    for k in ("W_mean", "W_var", "Z_cov", "Mu_mean", "Mu_var", "beta_a", "beta_b"):
+        _close(g[k], st[k], "N = 10^6: " + k)
+    _close(g["Z"][:2000], st["Z"][:2000], "N = 10^6: Z (first rows)")
+    _close(g["X"][-2000:], st["X"][-2000:], "N = 10^6: X (last rows)")
+    assert np.all(np.abs(got - ref) <= RTOL * np.abs(ref).sum()), (got, ref)
+    b.close()
+    del st
+    perm = np.concatenate([[0], 1 + np.random.default_rng(0).permutation(N - 1)])
+    init2 = {k: (v[perm] if isinstance(v, np.ndarray) and v.shape[:1] == (N,) else v) for k, v in init.items()}
+    b2 = PCABatch.from_problem(init2, pri)
+    b2.iterate(1)
+    g2 = b2.get_state()
+    for k in ("W_mean", "W_var", "Z_cov", "Mu_mean", "Mu_var", "beta_b"):
+        _close(g2[k], g[k], "row permutation: " + k, 1e-10)
+    _close(g2["Z"][:100], g["Z"][perm[:100]], "row permutation: Z", 1e-10)
+    b2.close()
