@@ -101,8 +101,9 @@ def main():
     ap.add_argument("--rccl-single", action="store_true",
                     help="with one process: still create a (one-rank) RCCL communicator and all-reduce the lower bound through it, "
                          "i.e. run the multi-GPU code path as far as one GPU allows")
-    ap.add_argument("--allow-gloo-fallback", action="store_true",
-                    help="if the RCCL communicator cannot be created, reduce the lower bound over gloo (marked degraded) instead of failing")
+    ap.add_argument("--allow-host-fallback", "--allow-gloo-fallback", dest="allow_host_fallback", action="store_true",
+                    help="if the RCCL communicator cannot be created, reduce the lower bound through host memory over the rendezvous "
+                         "sockets (line marked degraded) instead of failing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +115,7 @@ def main():
     from pyvb_amd.lds import LDSBatch      # raises if libpyvb_hip.so is missing: no fallback
     from pyvb_amd import dist as pdist
 
-    comm = pdist.init(world, rank)         # gloo rendezvous for barriers / max-reduce; RCCL inside the library
+    comm = pdist.init(world, rank)         # TCP rendezvous (standard library) for barriers / max-reduce; RCCL inside the library
     T, D, K, N = args.T, args.D, args.K, args.replicates
     Y, st0, pri = make_inputs(T, D, K, N, seed=20240 + 1000 * rank)
     from pyvb_amd import _capi
@@ -154,13 +155,13 @@ def main():
             # fail unless the caller asked for the fallback, and mark the line if so
             if why:
                 sys.stderr.write(why + "\n")
-            if not args.allow_gloo_fallback:
+            if not args.allow_host_fallback:
                 b.close()
                 comm.close()
                 raise SystemExit("RCCL communicator could not be created on every rank (see stderr); "
-                                 "re-run with --allow-gloo-fallback for a degraded (gloo) measurement")
+                                 "re-run with --allow-host-fallback for a degraded measurement (lower bound reduced through host memory)")
             degraded = True
-        collective = ("rccl allreduce(6 x f64) per step, %d rank(s)" % world) if use_rccl else "gloo allreduce(6 x f64) per step (RCCL init failed: DEGRADED)"
+        collective = ("rccl allreduce(6 x f64) per step, %d rank(s)" % world) if use_rccl else "host allreduce(6 x f64) per step over TCP (RCCL init failed: DEGRADED)"
 
     def step():
         # one variational iteration of every replicate on this GPU: forward sweep, backward sweep, A, C, Q, R on the handle's
@@ -169,7 +170,7 @@ def main():
         # per-step lower bounds are read from the library's history ring after the timed region.
         b.iterate(1)
         if world > 1 and not use_rccl:
-            return comm.allreduce_sum(b.elbo().sum(0))          # degraded mode only (--allow-gloo-fallback)
+            return comm.allreduce_sum(b.elbo().sum(0))          # degraded mode only (--allow-host-fallback)
         return None
 
     for _ in range(args.warmup):

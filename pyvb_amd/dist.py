@@ -1,16 +1,27 @@
 """Host-side plumbing for multi-GPU runs: one process per GPU, replicates sharded contiguously.
 
 The data path has exactly one exchange, the all-reduce of the six lower-bound parts; on GPUs it
-runs inside libpyvb_hip.so over RCCL (pyvb_lds_comm_init / pyvb_lds_elbo_total).  This module
+runs inside libpyvb_hip.so over RCCL (pyvb_lds_comm_init / pyvb_lds_iterate).  This module
 only provides the rendezvous around it -- barrier, max over ranks for timing, and the broadcast
-of the RCCL unique id -- over torch.distributed's gloo backend, and the same all-reduce on gloo
-for CPU tests of the sharding logic.  torch is imported only when world > 1.
+of the RCCL unique id.
+
+Two implementations of the same small interface:
+  SocketComm  plain TCP over the loopback / MASTER_ADDR, standard library only: what bench.py uses.  It keeps torch out of
+              the process: torch's wheel bundles its own libhsa-runtime64 / librccl, and a process that has loaded
+              libpyvb_hip.so (system ROCm) AND torch ends up with two HSA runtimes -- RCCL's topology probe then runs in
+              the uninitialised one and ncclCommInitRank fails ("no ROCm-capable device is detected"; seen on the GPU box,
+              profiles/r02/README.md).
+  GlooComm    torch.distributed's gloo backend, for the CPU tests of the sharding logic (tests/test_dist_gloo.py).
 """
 import os
+import pickle
+import socket
+import struct
+import time
 
 import numpy as np
 
-__all__ = ["init", "shard_range", "LocalComm", "GlooComm"]
+__all__ = ["init", "shard_range", "LocalComm", "GlooComm", "SocketComm"]
 
 
 def shard_range(n_total, rank, world):
@@ -73,7 +84,125 @@ class GlooComm(object):
             self._dist.destroy_process_group()
 
 
-def init(world=None, rank=None):
+def _send(sock, obj):
+    data = pickle.dumps(obj, protocol=4)
+    sock.sendall(struct.pack("<Q", len(data)) + data)
+
+
+def _recv(sock):
+    def exact(n):
+        buf = b""
+        while len(buf) < n:
+            chunk = sock.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError("peer closed the rendezvous connection")
+            buf += chunk
+        return buf
+    (n,) = struct.unpack("<Q", exact(8))
+    return pickle.loads(exact(n))
+
+
+class SocketComm(object):
+    """Rank 0 listens, the others connect (MASTER_ADDR; a port derived from MASTER_PORT, which the launcher's own store
+    occupies); every collective is a gather to rank 0 and a broadcast back.  A few bytes per call, a few calls per run."""
+    TOKEN = "pyvb-rendezvous-1"
+
+    def __init__(self, world, rank, timeout=180.0):
+        self.world, self.rank = int(world), int(rank)
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        base = int(os.environ.get("MASTER_PORT", "29500"))
+        run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+        ports = [20000 + (base * 31 + 97 * i) % 30000 for i in range(8)]
+        hello = (self.TOKEN, run, base, self.world)
+        deadline = time.time() + timeout
+        if self.rank == 0:
+            srv = None
+            for p in ports:
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", p))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise RuntimeError("no free rendezvous port among %r" % (ports,))
+            srv.listen(self.world)
+            srv.settimeout(1.0)
+            self.peers = {}
+            while len(self.peers) < self.world - 1:
+                if time.time() > deadline:
+                    raise TimeoutError("rendezvous: %d of %d ranks connected" % (len(self.peers) + 1, self.world))
+                try:
+                    c, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                c.settimeout(timeout)
+                try:
+                    msg = _recv(c)
+                except Exception:
+                    c.close()
+                    continue
+                if msg[:4] != hello or not (0 < msg[4] < self.world) or msg[4] in self.peers:
+                    _send(c, "no")
+                    c.close()
+                    continue
+                _send(c, "ok")
+                self.peers[msg[4]] = c
+            srv.close()
+        else:
+            self.sock = None
+            while self.sock is None:
+                if time.time() > deadline:
+                    raise TimeoutError("rendezvous: rank %d found no rank 0 at %s ports %r" % (self.rank, addr, ports))
+                for p in ports:
+                    try:
+                        c = socket.create_connection((addr, p), timeout=2.0)
+                        c.settimeout(timeout)
+                        _send(c, hello + (self.rank,))
+                        if _recv(c) == "ok":
+                            self.sock = c
+                            break
+                        c.close()
+                    except OSError:
+                        pass
+                else:
+                    time.sleep(0.2)
+
+    def _gather_bcast(self, value, combine):
+        if self.rank == 0:
+            vals = [value] + [_recv(self.peers[r]) for r in sorted(self.peers)]
+            out = combine(vals)
+            for r in sorted(self.peers):
+                _send(self.peers[r], out)
+            return out
+        _send(self.sock, value)
+        return _recv(self.sock)
+
+    def barrier(self):
+        self._gather_bcast(0, lambda v: 0)
+
+    def max_float(self, x):
+        return float(self._gather_bcast(float(x), max))
+
+    def broadcast_bytes(self, b):
+        return self._gather_bcast(b if self.rank == 0 else None, lambda v: v[0])
+
+    def allreduce_sum(self, a):
+        return self._gather_bcast(np.asarray(a, dtype=np.float64), lambda v: np.sum(v, axis=0))
+
+    def close(self):
+        for c in (list(getattr(self, "peers", {}).values()) + ([self.sock] if getattr(self, "sock", None) else [])):
+            try:
+                c.close()
+            except OSError:
+                pass
+
+
+def init(world=None, rank=None, backend="socket"):
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
     rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
-    return LocalComm() if world <= 1 else GlooComm(world, rank)
+    if world <= 1:
+        return LocalComm()
+    return GlooComm(world, rank) if backend == "gloo" else SocketComm(world, rank)

@@ -48,19 +48,25 @@ def test_one_rank_rccl_communicator_through_the_multi_gpu_branch():
 
 
 def test_two_ranks_on_one_gpu_fail_loudly_or_run_over_rccl():
-    """Two processes on the one GPU of this box: RCCL normally refuses two ranks on one device.  Without
-    --allow-gloo-fallback that must end the run with a non-zero status (never a silent gloo number); with it the line is
-    marked degraded.  (If this RCCL build does accept it, the line must say rccl.)"""
+    """Two processes on the one GPU of this box.  RCCL refuses two ranks on one device -- but only after its bootstrap
+    and topology probe have worked, which is what this test is after: with torch in the process (its wheel bundles a second
+    HSA runtime) ncclCommInitRank died earlier with 'no ROCm-capable device is detected', on any number of GPUs.  Without
+    --allow-host-fallback a failed communicator must end the run with a non-zero status (never a silent host-side number);
+    with it the line is marked degraded.  (If this RCCL build does accept the two ranks, the line must say rccl.)"""
     launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
-    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "NCCL_DEBUG": "WARN"}
     r = _run(launch + ["--master-port", "29611", "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL, env)
     if r.returncode == 0:
         d = _line(r.stdout)
         assert d["n_gpus"] == 2 and d["config"]["collective"].startswith("rccl") and d["config"]["degraded"] is False
         assert d["config"]["replicates_total"] == 12
     else:
-        assert "RCCL communicator could not be created" in (r.stderr + r.stdout)
-        r2 = _run(launch + ["--master-port", "29612", "bench.py", "--gpus", "2", "--no-cpu-baseline", "--allow-gloo-fallback"] + SMALL, env)
+        both = r.stderr + r.stdout
+        assert "RCCL communicator could not be created" in both
+        assert "Duplicate GPU detected" in both, both[-3000:]          # the legitimate reason, reached past bootstrap/topology
+        assert "no ROCm-capable device" not in both
+        r2 = _run(launch + ["--master-port", "29612", "bench.py", "--gpus", "2", "--no-cpu-baseline", "--allow-host-fallback"] + SMALL, env)
         assert r2.returncode == 0, r2.stderr[-2000:]
         d = _line(r2.stdout)
         assert d["n_gpus"] == 2 and d["config"]["degraded"] is True and "DEGRADED" in d["config"]["collective"]
+        assert d["config"]["replicates_total"] == 12
