@@ -32,3 +32,17 @@ for r in range(2):
 assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]), "runs differ"
 tr = runs[0][0]
 print("300 iterations twice: bitwise equal; bound %.6e -> %.6e, all finite: %s" % (tr[0], tr[-1], bool(np.all(np.isfinite(tr)))))
+
+# the generic plan: graphs created and dropped (arena, tapes, stream must go with them)
+from pyvb_amd import nodes
+base = free_bytes()
+for i in range(int(os.environ.get("SOAK_GRAPHS", "60"))):
+    mu = nodes.Gaussian(3, np.zeros((3, 1)), np.eye(3) * 1e-2)
+    prec = nodes.DiagonalGamma(3, np.full(3, 1e-3), np.full(3, 1e-3))
+    xs = [nodes.Gaussian(3, mu, prec) for _ in range(20)]
+    [x.observe(np.random.randn(3, 1)) for x in xs]
+    for it in range(3):
+        mu.update(); prec.update()
+    v = mu.qmu
+    mu._plan.release()
+print("generic plan: free memory drift after %s graphs: %d bytes" % (os.environ.get("SOAK_GRAPHS", "60"), base - free_bytes()))

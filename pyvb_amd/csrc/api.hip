@@ -696,6 +696,10 @@ int pyvb_lds_iterate(pyvb_lds* h, int niters) {
             if ((rc = update_noise(h, 0))) return rc;
             if ((rc = update_noise(h, 1))) return rc;
             if ((rc = pyvb_lds_elbo(h))) return rc;
+            double* slot = h->elbo_hist + (size_t)(h->hist_count % PYVB_ELBO_HISTORY) * 8;      // same history, main stream
+            if ((rc = launch_elbo_sum(h, slot, h->stream))) return rc;
+            if (h->comm && (rc = pyvb_allreduce_f64(h->comm, slot, 6, h->stream))) return rc;
+            h->hist_count += 1;
             continue;
         }
         // A and C are independent given the statistics, and so are Q and R given A and C: the pairs
@@ -727,6 +731,7 @@ int pyvb_lds_get_elbo_history(pyvb_lds* h, double* out, int max_count, int* coun
     ARGCHK(out && count && max_count >= 0, "bad arguments");
     int n = h->hist_count < PYVB_ELBO_HISTORY ? h->hist_count : PYVB_ELBO_HISTORY;
     if (n > max_count) n = max_count;
+    HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipStreamSynchronize(h->side));
     std::vector<double> tmp((size_t)n * 8);
     for (int i = 0; i < n; ++i) {            // the most recent n rows, oldest first
