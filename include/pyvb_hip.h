@@ -90,8 +90,19 @@ int pyvb_lds_get_wishart_state(pyvb_lds* h, double* Q_v, double* Q_w, double* R_
 int pyvb_lds_set_column_cov(pyvb_lds* h, const double* A_cov, const double* C_cov);
 int pyvb_lds_get_column_cov(pyvb_lds* h, double* A_cov, double* C_cov);
 
-/* Gaussian.observe for every Y_t (gaussian.py:74-100, full observations only). */
+/* Gaussian.observe for every Y_t (gaussian.py:74-100).  NaN = missing: a row with some NaN is partially observed, a row of
+ * NaN is not observed at all; such Y_t are variational nodes of their own (DiagonalGamma / Gamma noise only):
+ *   pyvb_lds_set_output_state  their initial posterior (mean Yq[N][T][K], isotropic variance Yrowvar[N][T]; rows without NaN
+ *                              ignored) -- until its first update a partially observed node keeps the constructor's draw in
+ *                              ALL its entries (observe() only records the known values); default N(0, I)
+ *   pyvb_lds_update_Y          [y.update() for y in Ys if not y.observed]  (gaussian.py:102-134, parents only)
+ *   pyvb_lds_get_outputs       their posterior means and variances ([N][T][K] each; fully observed rows: value, 0) and the
+ *                              q_ln_det of the rows updated so far ([N][T], NaN otherwise); NULL = skip
+ * The example's loop (pyvb_lds_iterate) never updates the outputs; call pyvb_lds_update_Y where the script does. */
 int pyvb_lds_set_observations(pyvb_lds* h, const double* Y);
+int pyvb_lds_set_output_state(pyvb_lds* h, const double* Yq, const double* Yrowvar);
+int pyvb_lds_update_Y(pyvb_lds* h);
+int pyvb_lds_get_outputs(pyvb_lds* h, double* Yq, double* Yvar, double* Yqld);
 
 /* As[i].observe(v) / Cs[i].observe(v) (gaussian.py:74-100; examples/LDS_knowns_in_A.py:73-74): known entries of the
  * transition / observation matrices, A_obs[D][D] and C_obs[K][D] as (row, col), NaN = not observed; NULL = leave.

@@ -29,6 +29,10 @@ State layout (all float64, N = replicates):
   C_mean   [N,K,D], C_cov [N,D,K,K]
   Q_a,Q_b  [N,D] (diagonal_gamma) or [N] (gamma);  R_a,R_b likewise with K
   Q_v,Q_w  Wishart: [N], [N,D,D]
+Outputs with missing entries (Y holds NaN there; gaussian.py:90-96): the Y_t are then variational nodes too,
+  Yq       [N,T,K]   their posterior means (= Y where a row is fully observed)
+  Yvar     [N,T,K]   the diagonal of their posterior covariances (0 where fully observed)
+  Yqld     [N,T]     q_ln_det of the rows nothing of which is observed (NaN until updated)
 """
 import numpy as np
 from scipy.special import digamma, gammaln
@@ -171,6 +175,7 @@ def _x_step(st, pri, post, Y, t, X):
     T = X.shape[1]
     A, C = st["A_mean"], st["C_mean"]
     Qb, Rb = post["Qbar"], post["Rbar"]
+    Y = st.get("Yq", Y)         # outputs with missing entries message their current posterior mean (gaussian.py:179-183)
     m2 = np.einsum("nki,nk->ni", C, np.einsum("nkl,nl->nk", Rb, Y[:, t]))
     if t < T - 1:
         m2 = m2 + np.einsum("nki,nk->ni", A, np.einsum("nkl,nl->nk", Qb, X[:, t + 1]))
@@ -213,6 +218,8 @@ def statistics(st, Y):
     noise updates ever read (nodes_todo.py:43-62, :187-190)."""
     X, Sig = st["X"], st["Sigma"]
     T = X.shape[1]
+    Yvar = st.get("Yvar")
+    Y = st.get("Yq", Y)
     XX = np.einsum("nti,ntj->nij", X, X)
     x0 = np.einsum("ni,nj->nij", X[:, 0], X[:, 0])
     xL = np.einsum("ni,nj->nij", X[:, -1], X[:, -1])
@@ -227,7 +234,55 @@ def statistics(st, Y):
         "Syy": np.einsum("ntk,ntl->nkl", Y, Y),
         "x0x0": x0 + Sig[:, 0],
     }
+    if Yvar is not None:        # <y y^T> = qmu qmu^T + qcov (gaussian.py:162-168); the covariances are diagonal here
+        K = Y.shape[2]
+        S["Syy"][:, np.arange(K), np.arange(K)] += Yvar.sum(axis=1)
     return S
+
+
+# ----------------------------------------------------------------------------
+# outputs with missing entries  (Gaussian.update for the Y_t that are not fully observed)
+# ----------------------------------------------------------------------------
+def init_missing(st, pri, Yobs, Yq0, Yrowvar0):
+    """State of the outputs when Yobs holds NaN.  A row without NaN is observed (qmu = value, qcov = 0,
+    gaussian.py:97-100).  A row with NaN keeps the constructor's posterior -- here the explicit (Yq0, I * Yrowvar0) --
+    in ALL its entries until its first update(): observe() only records the known values (gaussian.py:92-96)."""
+    full = ~np.isnan(Yobs).any(axis=2)
+    st["Yobs"] = Yobs
+    st["Yq"] = np.where(full[:, :, None], np.nan_to_num(Yobs), Yq0)
+    st["Yvar"] = np.where(full[:, :, None], 0.0, Yrowvar0[:, :, None] * np.ones_like(Yobs))
+    st["Yqld"] = np.full(Yobs.shape[:2], np.nan)
+
+
+def update_Y(st, pri):
+    """[y.update() for y in Ys] for the rows that are not fully observed.  Parents only (no children):
+    qprec = <R>, qmu = <C> mu_t (gaussian.py:112-123); then the known entries are conditioned on (:125-134), which for
+    a diagonal covariance pins them and leaves the others alone."""
+    kind = pri["noise"]
+    assert kind != "wishart", "missing outputs with Wishart noise are not restated"
+    K = st["C_mean"].shape[1]
+    Rb = noise_expect(kind, st["R_a"], st["R_b"], K)
+    rdiag = np.einsum("nkk->nk", Rb)
+    pmu = np.einsum("nkj,ntj->ntk", st["C_mean"], st["X"])
+    miss = np.isnan(st["Yobs"])
+    upd = miss.any(axis=2)                  # partially observed or latent rows
+    st["Yq"] = np.where(upd[:, :, None], np.where(miss, pmu, np.nan_to_num(st["Yobs"])), st["Yq"])
+    st["Yvar"] = np.where(upd[:, :, None], np.where(miss, 1.0 / rdiag[:, None, :], 0.0), st["Yvar"])
+    qld = 0.5 / np.sum(0.5 * np.log(rdiag), axis=1)          # gaussian.py:120 (quirk Q1)
+    st["Yqld"] = np.where(upd, qld[:, None], st["Yqld"])
+
+
+def _y_entropy_terms(st):
+    """What Gaussian.log_lower_bound subtracts for the rows that are not fully observed (gaussian.py:145-150)."""
+    miss = np.isnan(st["Yobs"])
+    K = miss.shape[2]
+    nm = miss.sum(axis=2)
+    latent, partial = nm == K, (nm > 0) & (nm < K)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lv = np.where(miss, np.log(st["Yvar"]), 0.0).sum(axis=2)
+    tp = np.where(partial, 0.5 * nm * LN2PI - 0.5 * lv - 0.5 * nm, 0.0)
+    tl = np.where(latent, -0.5 * K * LN2PI - 0.5 * st["Yqld"] - 0.5 * K, 0.0)
+    return (tp + tl).sum(axis=1)
 
 
 # ----------------------------------------------------------------------------
@@ -387,6 +442,8 @@ def elbo_parts(st, pri, S, T):
     # Y_t observed
     E, HM = _residual_second_moment(S["Syy"], st["C_mean"], st["C_cov"], S["Sxx"], S["Syx"])
     LY = T * (-0.5 * K * LN2PI + 0.5 * lndR) - 0.5 * np.einsum("nij,nji->n", Rb, E - 2 * HM)
+    if "Yobs" in st:
+        LY = LY - _y_entropy_terms(st)
 
     def cols(M, Mcov, pm, pp, qldc, rows, obs):
         # column i: Constant mean pm[:,i], Constant precision diag(pp[i])
@@ -415,9 +472,10 @@ def elbo_parts(st, pri, S, T):
 # ----------------------------------------------------------------------------
 # the driver loop
 # ----------------------------------------------------------------------------
-def expand_state(st0, pri, T):
+def expand_state(st0, pri, T, Y=None):
     """Turn the compact initial state of pyvb_amd.synth.initial_state (diagonal
-    column variances) into this module's dense layout; copies everything."""
+    column variances) into this module's dense layout; copies everything.  With observations Y that hold NaN the
+    outputs become variational nodes: st0 must then carry their initial posterior (Yq, Yrowvar), see init_missing."""
     st = {"X": st0["X"].copy(), "A_mean": st0["A_mean"].copy(), "C_mean": st0["C_mean"].copy(),
           "Q_b": st0["Q_b"].copy(), "R_b": st0["R_b"].copy()}
     st["A_cov"] = np.einsum("nik,kl->nikl", st0["A_colvar"], np.eye(st0["A_colvar"].shape[2]))
@@ -434,17 +492,21 @@ def expand_state(st0, pri, T):
     for which in ("A", "C"):
         if pri.get(which + "_obs") is not None:
             observe_columns(st, which, pri[which + "_obs"])
+    if Y is not None and np.isnan(Y).any():
+        init_missing(st, pri, Y, st0["Yq"], st0["Yrowvar"])
     return st
 
 
-def iterate(st, pri, Y, with_elbo=True):
+def iterate(st, pri, Y, with_elbo=True, update_outputs=False):
     """One pass of the example's loop body (Linear_Dynamic_System.py:69-77) followed by
-    the lower bound (network.py:49): forward sweep, backward sweep, A columns,
-    C columns, Q, R, ELBO."""
+    the lower bound (network.py:49): forward sweep, backward sweep, [outputs with missing entries,]
+    A columns, C columns, Q, R, ELBO."""
     T = st["X"].shape[1]
     post = state_posteriors(st, pri)
     sweep(st, pri, Y, "forward", post)
     sweep(st, pri, Y, "backward", post)
+    if update_outputs:
+        update_Y(st, pri)
     S = statistics(st, Y)
     update_A(st, pri, S)
     update_C(st, pri, S)

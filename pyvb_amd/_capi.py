@@ -35,6 +35,9 @@ SIGNATURES = {
     "pyvb_lds_set_column_cov": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_lds_get_column_cov": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_lds_set_observations": (ctypes.c_int, [_h, _dp]),
+    "pyvb_lds_set_output_state": (ctypes.c_int, [_h, _dp, _dp]),
+    "pyvb_lds_update_Y": (ctypes.c_int, [_h]),
+    "pyvb_lds_get_outputs": (ctypes.c_int, [_h, _dp, _dp, _dp]),
     "pyvb_lds_set_column_observations": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_lds_set_state": (ctypes.c_int, [_h] + [_dp] * 7),
     "pyvb_lds_get_state": (ctypes.c_int, [_h] + [_dp] * 9),

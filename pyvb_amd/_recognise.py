@@ -25,7 +25,14 @@ class LDSPlan(object):
         self.kind = pri["noise"]
         self.batch = LDSBatch(1, T, D, K, self.kind)
         self.batch.set_priors(pri)
-        self.batch.set_observations(np.hstack([y.__dict__["_h_qmu"] for y in Ys]).T.reshape(1, T, K))
+        self.free_ys = [t for t, y in enumerate(Ys) if not y.observed]      # outputs with missing entries: nodes of their own
+        Yarr = np.hstack([y.__dict__["_h_qmu"] if y.observed else
+                          (y.obs_value if y.partially_observed else np.full((K, 1), np.nan)) for y in Ys]).T.reshape(1, T, K)
+        self.batch.set_observations(Yarr)
+        if self.free_ys:
+            Yq = np.hstack([y.__dict__["_h_qmu"] for y in Ys]).T.reshape(1, T, K)
+            Yv = np.array([y.__dict__["_h_qcov"][0, 0] for y in Ys]).reshape(1, T)
+            self.batch.set_output_state(Yq, Yv)
         diag = lambda nodes_: np.stack([np.diag(n.__dict__["_h_qcov"]) for n in nodes_])
         qb = lambda nd, dim: np.broadcast_to(np.asarray(nd.__dict__["_h_qb"], dtype=float), (dim,)).reshape(1, dim)
         state = dict(
@@ -86,6 +93,11 @@ class LDSPlan(object):
                 else:
                     return self._demote(ops[i:])
                 self.x_updated = True
+            elif kind == "y":           # [y.update() for y in Ys if not y.observed]: all of them, in order, or node by node
+                run = [o[1] for o in ops[i:i + len(self.free_ys)] if o[0] == "y"]
+                if run != self.free_ys:
+                    return self._demote(ops[i:])
+                b.update_Y(); i += len(run)
             elif kind in ("a", "c", "q", "r"):
                 if not self.x_updated:
                     return self._demote(ops[i:])
@@ -107,7 +119,7 @@ class LDSPlan(object):
         if not self.x_updated:
             return              # nothing has run: the host attributes are the state
         self._pull()
-        for nd in self.Xs + self.As + self.Cs:
+        for nd in self.Xs + self.As + self.Cs + [self.Ys[t] for t in self.free_ys]:
             for name in ("qmu", "qcov"):
                 nd.__dict__["_h_" + name] = self.read(nd, name)
             try:
@@ -149,11 +161,13 @@ class LDSPlan(object):
             if self.kind == "wishart":
                 self.cache["w"] = self.batch.get_wishart_state()
                 self.cache["A_cov"], self.cache["C_cov"] = [v[0] for v in self.batch.get_column_cov()]
+            if self.free_ys:
+                self.cache["Yq"], self.cache["Yvar"], self.cache["Yqld"] = [v[0] for v in self.batch.get_outputs(with_qld=True)]
         return self.cache
 
     def read(self, node, name):
         kind, i = self.index[id(node)]
-        if kind == "y":
+        if kind == "y" and (node.observed or name not in ("qmu", "qcov", "q_ln_det")):
             return node.__dict__.get("_h_" + name)          # observations: host copy
         self.flush()
         if node._plan is not self:
@@ -162,6 +176,10 @@ class LDSPlan(object):
             return node.__dict__.get("_h_" + name)          # never updated: the constructor's draw (gaussian.py:70-72)
         c = self._pull()
         st, T = c["st"], self.T
+        if kind == "y":
+            if name == "q_ln_det":
+                return float(c["Yqld"][i]) if np.isfinite(c["Yqld"][i]) else node.__dict__.get("_h_q_ln_det")
+            return c["Yq"][i].reshape(-1, 1).copy() if name == "qmu" else np.diag(c["Yvar"][i])
         if kind == "x":
             cls = 0 if i == 0 else (2 if i == T - 1 else 1)
             if name == "qmu":
@@ -303,7 +321,7 @@ def describe(start):
             if not isinstance(m, N.Multiplication) or m.B is not x or not isinstance(m.A, N.hstack) or len(m.children) != 1:
                 _fail("a state has a child that is not hstack * state feeding one Gaussian")
             child = m.children[0]
-            if child.observed:
+            if not child.children:          # an output: observed, partially observed or not at all (NaN entries, gaussian.py:90-96)
                 if C is None:
                     C = m.A
                 if m.A is not C:
@@ -331,8 +349,15 @@ def describe(start):
     Q, R = Xs[1].precision_parent, Ys[0].precision_parent
     if Q is R or any(x.precision_parent is not Q for x in Xs[1:]) or any(y.precision_parent is not R for y in Ys):
         _fail("noise precisions are not shared along the chain")
-    if any(y.partially_observed for y in Ys) or any(x.partially_observed or x.observed for x in Xs):
-        _fail("partial observations")
+    if any(x.partially_observed or x.observed for x in Xs):
+        _fail("observed states")
+    for y in Ys:
+        if not y.observed:
+            if isinstance(Q, N.Wishart):
+                _fail("outputs with missing entries together with Wishart noise")
+            cov = y.__dict__["_h_qcov"]
+            if np.abs(cov - np.eye(K) * cov[0, 0]).max() != 0.0:
+                _fail("the initial covariance of an output with missing entries must be a multiple of the identity")
     As, Cs = A.parents, C.parents
 
     def known_entries(cols, rows):

@@ -196,7 +196,8 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
                       h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->sxx, h->U,
-                      h->Q_w, h->R_w, h->Qbar, h->Rbar, h->lnd, h->QA, h->RC, h->trA, h->trC, h->A_cov, h->C_cov, h->SyyF, h->RQ, h->RR};
+                      h->Q_w, h->R_w, h->Qbar, h->Rbar, h->lnd, h->QA, h->RC, h->trA, h->trC, h->A_cov, h->C_cov, h->SyyF, h->RQ, h->RR,
+                      h->Yobs, h->Yvar, h->Yqld, h->Yent};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
     if (h->status) (void)hipFree(h->status);
@@ -398,12 +399,80 @@ int pyvb_lds_set_column_observations(pyvb_lds* h, const double* A_obs, const dou
 int pyvb_lds_set_observations(pyvb_lds* h, const double* Y) {
     ENTER(h);
     ARGCHK(Y, "Y is NULL");
+    const size_t n = (size_t)h->N * h->T * h->K;
+    bool missing = false;
+    for (size_t i = 0; i < n && !missing; ++i) missing = Y[i] != Y[i];
     int rc;
-    if ((rc = h2d(h, h->Y, Y, (size_t)h->N * h->T * h->K))) return rc;
+    if (missing) {
+        if (h->dense) { pyvb_set_error("outputs with missing entries together with Wishart noise are not supported"); return PYVB_E_UNSUPPORTED; }
+        if (!h->Yobs) {
+            if ((rc = dev_alloc(&h->Yobs, n))) return rc;
+            if ((rc = dev_alloc(&h->Yvar, n))) return rc;
+            if ((rc = dev_alloc(&h->Yqld, (size_t)h->N * h->T))) return rc;
+            if ((rc = dev_alloc(&h->Yent, h->N))) return rc;
+        }
+        if ((rc = h2d(h, h->Yobs, Y, n))) return rc;
+        h->has_missing = true;
+        // rows with NaN start as N(0, I) until pyvb_lds_set_output_state says otherwise
+        if ((rc = launch_missing_init(h, nullptr, nullptr))) return rc;
+        if ((rc = launch_syy_missing(h))) return rc;
+    } else {
+        h->has_missing = false;
+        if ((rc = h2d(h, h->Y, Y, n))) return rc;
+        if ((rc = launch_syy(h))) return rc;
+        if (h->dense && (rc = launch_syy_full(h))) return rc;
+    }
     h->u_valid = false;
-    if ((rc = launch_syy(h))) return rc;
-    if (h->dense && (rc = launch_syy_full(h))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
+    states_changed(h);
+    return PYVB_OK;
+}
+
+int pyvb_lds_set_output_state(pyvb_lds* h, const double* Yq, const double* Yrowvar) {
+    ENTER(h);
+    ARGCHK(h->has_missing, "the observations hold no NaN: every output is observed");
+    ARGCHK(Yq && Yrowvar, "Yq and Yrowvar are required");
+    const size_t n = (size_t)h->N * h->T * h->K;
+    // staged through buffers that are free until the next sweep / statistics pass
+    double* dq = h->U;                  // [N][T][DP] >= [N][T][K]?  not for K > DP: use a temporary then
+    double* tmp = nullptr;
+    if ((size_t)h->K > (size_t)h->L.DP) { HIPCHK(hipMalloc((void**)&tmp, n * sizeof(double))); dq = tmp; }
+    double* dv = h->X[1 - h->cur];      // [N][T][DP] >= [N][T]
+    int rc;
+    if ((rc = h2d(h, dq, Yq, n))) return rc;
+    if ((rc = h2d(h, dv, Yrowvar, (size_t)h->N * h->T))) return rc;
+    if ((rc = launch_missing_init(h, dq, dv))) return rc;
+    if ((rc = launch_syy_missing(h))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (tmp) (void)hipFree(tmp);
+    h->u_valid = false;
+    states_changed(h);
+    return PYVB_OK;
+}
+
+int pyvb_lds_get_outputs(pyvb_lds* h, double* Yq, double* Yvar, double* Yqld) {
+    ENTER(h);
+    const size_t n = (size_t)h->N * h->T * h->K;
+    int rc;
+    if ((rc = d2h(h, Yq, h->Y, n))) return rc;
+    if (Yvar) {
+        if (h->has_missing) { if ((rc = d2h(h, Yvar, h->Yvar, n))) return rc; }
+        else memset(Yvar, 0, n * sizeof(double));
+    }
+    if (Yqld) {
+        if (h->has_missing) { if ((rc = d2h(h, Yqld, h->Yqld, (size_t)h->N * h->T))) return rc; }
+        else for (size_t i = 0; i < (size_t)h->N * h->T; ++i) Yqld[i] = NAN;
+    }
+    return pyvb_lds_sync(h);
+}
+
+int pyvb_lds_update_Y(pyvb_lds* h) {
+    ENTER(h);
+    if (!h->has_missing) return PYVB_OK;            // observed nodes never update (gaussian.py:109-110)
+    int rc;
+    if ((rc = launch_impute(h))) return rc;
+    if ((rc = launch_syy_missing(h))) return rc;
+    h->u_valid = false;                             // c_t = F mu + G y_t was formed with the old y_t
     states_changed(h);
     return PYVB_OK;
 }

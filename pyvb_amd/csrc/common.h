@@ -123,6 +123,9 @@ struct pyvb_lds {
     double *SyyF;                   // [N][K][K] sum_t y y^T
     double *RQ, *RR;                // [N][D][D], [N][K][K]: sum over children of 1/2<xx^T> + 1/2<mu mu^T> - <x><mu>^T
     bool expect_valid;              // Qbar, Rbar, lnd belong to the current Q_w, R_w
+    // ---- outputs with missing entries (k_missing.hip); allocated when set_observations sees NaN
+    bool has_missing;
+    double *Yobs, *Yvar, *Yqld, *Yent;      // [N][T][K] observations (NaN = missing), [N][T][K] variances, [N][T], [N]
     // ---- the lower bound does not feed the next iteration: inside pyvb_lds_iterate it runs on a side stream
     hipStream_t side;
     hipEvent_t ev_params, ev_elbo;  // parameters of this iteration complete (main) / lower bound of it read them (side)
@@ -153,6 +156,10 @@ int launch_wresid(pyvb_lds* h, int which, int update);
 int launch_syy_full(pyvb_lds* h);
 int launch_elbo_dense(pyvb_lds* h);
 int launch_colvar_to_cov(pyvb_lds* h);              // A_var/C_var (diagonals) -> A_cov/C_cov
+// k_missing.hip
+int launch_missing_init(pyvb_lds* h, const double* Yq0, const double* Yrowvar0);     // device pointers or null
+int launch_impute(pyvb_lds* h);
+int launch_syy_missing(pyvb_lds* h);
 
 // RCCL, shared by the LDS and the PCA path (api.hip)
 int pyvb_comm_create(void** comm, const char id[128], int rank, int world);

@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
     double LX = -0.5 * D * LN2PI + 0.5 * a.pri.x0_lndet - 0.5 * e0;
     LX += (double)(T - 1) * (-0.5 * D * LN2PI + 0.5 * lndQ) - trQ;
     LX += (double)T * (0.5 * D * LN2PI + 0.5 * D) + 0.5 * (qx[0] + nint * qx[1] + qx[2]);
-    const double LY = (double)T * (-0.5 * K * LN2PI + 0.5 * lndR) - trR;
+    double LY = (double)T * (-0.5 * K * LN2PI + 0.5 * lndR) - trR;
+    if (a.Yent) LY -= a.Yent[n];
     // --- columns of A and C against their Constant parents (gaussian.py:141-150).  The last term depends
     // on how much of the column was observed: nothing -> the q_ln_det form (:147), some entries -> the
     // covariance of the missing part (:150, with the reference's sign of the 2 pi term), all -> no term.
@@ -200,7 +201,7 @@ ParamArgs make_args(pyvb_lds* h) {
     a.part = h->stats; a.nchunk = h->nchunk; a.mom = h->mom; a.Sigma = h->Sigma; a.qld_x = h->qld_x; a.X = h->X[h->cur]; a.Syy = h->Syy;
     a.A_mean = h->A_mean; a.A_var = h->A_var; a.C_mean = h->C_mean; a.C_var = h->C_var;
     a.Q_a = h->Q_a; a.Q_b = h->Q_b; a.R_a = h->R_a; a.R_b = h->R_b; a.qld_A = h->qld_A; a.qld_C = h->qld_C;
-    a.resQ = h->resQ; a.resR = h->resR; a.elbo = h->elbo; a.pri = h->pri;
+    a.resQ = h->resQ; a.resR = h->resR; a.elbo = h->elbo; a.pri = h->pri; a.Yent = h->has_missing ? h->Yent : nullptr;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L; a.c0 = 0; a.c1 = h->D; a.which0 = 0; a.fuse = 0; a.sxx = nullptr; a.W = 1;
     return a;
 }

@@ -13,6 +13,7 @@ struct ParamArgs {
     // parameters
     double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *qld_A, *qld_C;
     double *resQ, *resR, *elbo;
+    const double* Yent;     // k_elbo: per replicate, what the outputs that are not fully observed subtract (k_missing.hip), or null
     Priors pri;
     int N, T, D, K, noise;
     int c0, c1;             // k_cols: columns [c0, c1) are updated

@@ -64,10 +64,26 @@ class LDSBatch(object):
         C.check(C.lib.pyvb_lds_set_priors(self._h, *[C.dptr(a) for a in arrs]))
 
     def set_observations(self, Y):
+        """Y[N,T,K]; NaN = missing entry (the rows concerned become variational nodes: set_output_state, update_Y)."""
         Y = _f64(Y, (self.N, self.T, self.K), "Y")
-        if np.isnan(Y).any():
-            raise NotImplementedError("missing observations (NaN) have no HIP path yet")
         C.check(C.lib.pyvb_lds_set_observations(self._h, C.dptr(Y)))
+
+    def set_output_state(self, Yq, Yrowvar):
+        """Initial posterior of the outputs that are not fully observed: means [N,T,K], isotropic variances [N,T]."""
+        q, v = _f64(Yq, (self.N, self.T, self.K), "Yq"), _f64(Yrowvar, (self.N, self.T), "Yrowvar")
+        C.check(C.lib.pyvb_lds_set_output_state(self._h, C.dptr(q), C.dptr(v)))
+
+    def update_Y(self):
+        """[y.update() for y in Ys if not y.observed]"""
+        C.check(C.lib.pyvb_lds_update_Y(self._h))
+
+    def get_outputs(self, with_qld=False):
+        """(posterior means [N,T,K], variances [N,T,K]) of the outputs; fully observed rows: (value, 0).
+        with_qld: also q_ln_det [N,T] of the rows updated so far (NaN otherwise)."""
+        q, v = np.empty((self.N, self.T, self.K)), np.empty((self.N, self.T, self.K))
+        ld = np.empty((self.N, self.T)) if with_qld else None
+        C.check(C.lib.pyvb_lds_get_outputs(self._h, C.dptr(q), C.dptr(v), C.dptr(ld)))
+        return (q, v, ld) if with_qld else (q, v)
 
     def set_state(self, X=None, A_mean=None, A_colvar=None, C_mean=None, C_colvar=None, Q_b=None, R_b=None):
         N, T, D, K = self.N, self.T, self.D, self.K
@@ -235,6 +251,8 @@ class LDSBatch(object):
         b = cls(N, T, D, K, pri.get("noise", "diagonal_gamma"), device)
         b.set_priors(pri)
         b.set_observations(Y)
+        if "Yq" in st0 and np.isnan(Y).any():
+            b.set_output_state(st0["Yq"], st0["Yrowvar"])
         if b.noise == "wishart":        # the compact initial state carries the diagonal of qw in Q_b / R_b
             b.set_state(**{k: st0[k] for k in ("X", "A_mean", "A_colvar", "C_mean", "C_colvar")})
             dense = lambda v: np.einsum("nd,de->nde", v, np.eye(v.shape[1])) if v.ndim == 2 else v

@@ -136,10 +136,17 @@ def snapshot(g, out, tag, kind, with_elbo=True, dense_cov=False):
         out[tag + "elbo_parts"] = np.array(parts)
 
 
-def run_case(ref, name, T, D, K, kind, iters, seed, dense_cov=False, knowns=False):
+def run_case(ref, name, T, D, K, kind, iters, seed, dense_cov=False, knowns=False, missing=False):
     from pyvb_amd import synth
     Y, st0, pri = synth.make_problem(T, D, K, 1, seed)
     pri["noise"] = kind
+    if missing:     # outputs with missing entries (gaussian.py:90-96): some rows partly known, two rows not at all
+        rng = np.random.default_rng(seed + 5)
+        mask = rng.random((T, K)) < 0.2
+        mask[1] = True; mask[T - 2] = True; mask[0, 0] = True; mask[3] = False
+        Y = np.where(mask[None], np.nan, Y)
+        st0["Yq"] = rng.standard_normal((1, T, K))
+        st0["Yrowvar"] = 1.0 / rng.uniform(0.5, 1.5, size=(1, T))
     if knowns:      # one and two known entries in columns of A, a fully known column and a known entry in C
         A_obs = np.full((D, D), np.nan); C_obs = np.full((K, D), np.nan)
         A_obs[0, 0] = 1.0; A_obs[0, 1] = 0.05; A_obs[2, 1] = -0.3
@@ -159,6 +166,12 @@ def run_case(ref, name, T, D, K, kind, iters, seed, dense_cov=False, knowns=Fals
             out["prior_" + k] = v
     g = build_graph(ref.nodes, Y[0], pri, st0)
     Xs = g["Xs"]
+    if missing:
+        for t, y in enumerate(g["Ys"]):
+            if not y.observed:
+                y.qmu = st0["Yq"][0, t].reshape(K, 1).copy()
+                y.qcov = np.eye(K) * st0["Yrowvar"][0, t]
+                y.qprec = np.linalg.inv(y.qcov)
     for it in range(1, max(iters) + 1):
         [x.update() for x in Xs]
         if it == 1:
@@ -166,12 +179,18 @@ def run_case(ref, name, T, D, K, kind, iters, seed, dense_cov=False, knowns=Fals
         Xs.reverse()
         [x.update() for x in Xs]
         Xs.reverse()
+        if missing:
+            [y.update() for y in g["Ys"] if not y.observed]
         [a.update() for a in g["As"]]
         [c.update() for c in g["Cs"]]
         g["Q"].update()
         g["R"].update()
         if it in iters:
             snapshot(g, out, "it%d_" % it, kind, with_elbo=(kind != "wishart"), dense_cov=dense_cov)
+            if missing:
+                out["it%d_Yq" % it] = np.hstack([y.qmu for y in g["Ys"]]).T.copy()
+                out["it%d_Yvar" % it] = np.stack([np.diag(y.qcov) for y in g["Ys"]])
+                out["it%d_Ycov_offdiag_max" % it] = np.max([np.abs(y.qcov - np.diag(np.diag(y.qcov))).max() for y in g["Ys"]])
         print(name, "iteration", it, flush=True)
     out["iters"] = np.array(sorted(iters))
     path = os.path.join(HERE, "lds_%s.npz" % name)
@@ -337,6 +356,8 @@ CASES = [
     ("wishart_d3k4_t40", 40, 3, 4, "wishart", (1,), 20247, True),
     ("d64k64_t4", 4, 64, 64, "diagonal_gamma", (1, 2), 20248, False),
     ("knowns_d3k4_t50", 50, 3, 4, "diagonal_gamma", (1, 2, 4), 20249, True, True),
+    ("missing_d3k4_t30", 30, 3, 4, "diagonal_gamma", (1, 3), 20250, True, False, True),
+    ("missing_gamma_d2k5_t20", 20, 2, 5, "gamma", (1, 2), 20251, True, False, True),
 ]
 
 

@@ -19,9 +19,12 @@ RTOL = 1e-9
 
 @pytest.fixture
 def numpy_executor(monkeypatch):
+    """The numpy restatement of the tape interpreter behind GenericPlan, and every graph on the generic plan (an LDS with
+    missing outputs would otherwise bind to the fused kernels, which need the GPU)."""
     from oracle.tape_ref import NumpyExecutor
-    from pyvb_amd import generic
+    from pyvb_amd import generic, _recognise
     monkeypatch.setattr(generic, "EXECUTOR_FACTORY", NumpyExecutor)
+    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
 
 
 def _close(a, b, what, rtol=RTOL):

@@ -17,11 +17,22 @@ from test_generic_cpu import check_scenario, _close  # noqa: E402
 
 
 @pytest.mark.parametrize("name", sorted(GS.SCENARIOS))
-def test_generic_scenarios_on_device(name):
+def test_generic_scenarios_on_device(name, monkeypatch):
+    from pyvb_amd import generic, _recognise
+    if name not in GS.NEEDS_DEVICE:     # node by node even where a fused plan would take the graph (lds_missing_outputs)
+        monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
     named = check_scenario(name)
-    from pyvb_amd.generic import GenericPlan, DeviceExecutor
     plan = next(iter(named.values()))._plan
-    assert isinstance(plan, GenericPlan) and isinstance(plan.ex, DeviceExecutor)
+    assert isinstance(plan, generic.GenericPlan) and isinstance(plan.ex, generic.DeviceExecutor)
+
+
+def test_lds_with_missing_outputs_on_the_fused_plan():
+    """The same graph and reference fixture as the generic scenario `lds_missing_outputs`, left to the recogniser: the
+    fused LDS kernels take it (outputs with NaN are nodes of their own, k_missing.hip), per-node lower-bound terms
+    come from the mirror."""
+    from pyvb_amd._recognise import LDSPlan
+    named = check_scenario("lds_missing_outputs")
+    assert isinstance(named["X00"]._plan, LDSPlan) and named["X00"]._plan.free_ys == [2, 4]
 
 
 def test_every_opcode_against_the_numpy_interpreter():
@@ -105,10 +116,15 @@ def test_single_messages_and_terms_of_the_fused_lds_plan(golden):
         pytest.skip("node-by-node evaluation is for small graphs")
     g = MG.build_graph(nodes, Y[0], pri, {k: v for k, v in st0.items()})
     Xs, Ys, As, Cs, Q, R = g["Xs"], g["Ys"], g["As"], g["Cs"], g["Q"], g["R"]
+    for t, y in enumerate(Ys):          # outputs with missing entries: the fixture's explicit initial posterior
+        if not y.observed:
+            y.qmu = st0["Yq"][0, t].reshape(-1, 1).copy()
+            y.qcov = np.eye(meta["K"]) * st0["Yrowvar"][0, t]
     it = meta["iters"][0]
     for _ in range(it):
         [x.update() for x in Xs]
         Xs.reverse(); [x.update() for x in Xs]; Xs.reverse()
+        [y.update() for y in Ys if not y.observed]
         [a.update() for a in As]; [c.update() for c in Cs]
         Q.update(); R.update()
     ref = z["it%d_elbo_parts" % it]

@@ -63,7 +63,8 @@ def _stagewise(Y, st0, pri, iters):
     """Run the example's loop on the GPU and in the oracle, comparing after every stage."""
     N, T, K = Y.shape
     b = _batch(Y, st0, pri)
-    st = O.expand_state(st0, pri, T)
+    st = O.expand_state(st0, pri, T, Y)
+    missing = bool(np.isnan(Y).any())
     for it in range(iters):
         tag = "it%d " % it
         post = O.state_posteriors(st, pri)
@@ -77,6 +78,11 @@ def _stagewise(Y, st0, pri, iters):
         cls = [0, 1, 2] if T > 2 else [0, 2]
         _close(Sig[:, cls], st["Sigma"][:, cls], tag + "Sigma")
         _close_qld(qld[:, cls], st["qld_x"][:, cls], tag + "qld_x")
+        if missing:
+            O.update_Y(st, pri); b.update_Y()
+            q, v = b.get_outputs()
+            _close(q, st["Yq"], tag + "Yq after update_Y")
+            _close(v, st["Yvar"], tag + "Yvar after update_Y")
         S = O.statistics(st, Y)
         O.update_A(st, pri, S); b.update_A()
         _close(b.get_state(("A_mean",))["A_mean"], st["A_mean"], tag + "A_mean after update_A")
@@ -98,6 +104,7 @@ def test_golden_fixtures(golden):
     """The reference's own outputs (tests/golden/*.npz), reproduced by the HIP path."""
     meta, Y, st0, pri, z = golden
     T = meta["T"]
+    missing = bool(np.isnan(Y).any())
     b = _batch(Y, st0, pri)
     b.sweep("forward")
     _close(b.get_state(("X",))["X"][0], z["it1_fwd_X"], "forward sweep vs reference")
@@ -105,6 +112,8 @@ def test_golden_fixtures(golden):
     for it in range(1, max(meta["iters"]) + 1):
         if it > 1:
             b.sweep("forward"); b.sweep("backward")
+        if missing:
+            b.update_Y()
         b.update_A(); b.update_C(); b.update_Q(); b.update_R()
         if it in meta["iters"]:
             tag = "it%d_" % it
@@ -130,6 +139,10 @@ def test_golden_fixtures(golden):
                 continue
             for nm in ("Q_a", "Q_b", "R_a", "R_b"):
                 _close(g[nm][0], np.broadcast_to(z[tag + nm], g[nm][0].shape), tag + nm)
+            if missing:
+                q, v = b.get_outputs()
+                _close(q[0], z[tag + "Yq"], tag + "Yq")
+                _close(v[0], z[tag + "Yvar"], tag + "Yvar")
             parts = b.elbo()[0]
             ref = z[tag + "elbo_parts"]
             assert np.all(np.abs(parts - ref) <= RTOL * np.abs(ref).sum()), "%s elbo parts %r vs %r" % (tag, parts, ref)
@@ -186,6 +199,45 @@ def test_wishart_noise_vs_oracle(T, D, K, N, proper):
     _close(b.get_state(("X",))["X"], st["X"], "X after iterate (Wishart)")
     _close(b.elbo().sum(1), parts.sum(1), "elbo after iterate (Wishart)")
     b.close()
+
+
+@pytest.mark.parametrize("T,D,K,N,kind", [(60, 5, 6, 2, "diagonal_gamma"), (300, 16, 16, 2, "diagonal_gamma"), (40, 64, 33, 1, "gamma"), (1200, 8, 64, 2, "diagonal_gamma")])
+def test_outputs_with_missing_entries(T, D, K, N, kind):
+    """Y with NaN (gaussian.py:90-96): partially observed and unobserved outputs are variational nodes; stage by stage
+    against the oracle (pinned to the reference by lds_missing_*.npz), then iterate() interleaved with update_Y."""
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=700 + T)
+    rng = np.random.default_rng(T + K)
+    mask = rng.random((N, T, K)) < 0.15
+    mask[:, 1] = True; mask[:, T // 2] = True; mask[:, 0, 0] = True; mask[:, 3] = False
+    Y = np.where(mask, np.nan, Y)
+    st0["Yq"] = rng.standard_normal((N, T, K)); st0["Yrowvar"] = 1.0 / rng.uniform(0.5, 1.5, size=(N, T))
+    pri["noise"] = kind
+    if kind == "gamma":
+        for k in ("Q_a0", "Q_b0", "R_a0", "R_b0"):
+            pri[k] = np.float64(1e-3)
+    _stagewise(Y, st0, pri, iters=3)
+    b = _batch(Y, st0, pri)
+    st = O.expand_state(st0, pri, T, Y)
+    for it in range(2):
+        O.iterate(st, pri, Y)           # the example's loop does not update the outputs ...
+        b.iterate(1)
+        O.update_Y(st, pri); b.update_Y()       # ... a script that does, between iterations
+    parts = O.iterate(st, pri, Y)
+    b.iterate(1)
+    _close(b.get_state(("X",))["X"], st["X"], "X, iterate + update_Y")
+    got = b.elbo()
+    assert np.all(np.abs(got - parts) <= RTOL * np.abs(parts).sum(axis=1, keepdims=True)), (got, parts)
+    b.close()
+
+
+def test_missing_outputs_are_refused_with_wishart_noise():
+    from pyvb_amd import _capi
+    Y, st0, pri = synth.make_problem(20, 3, 4, 1, seed=1)
+    _wishart_priors(pri, 3, 4)
+    Y[0, 2, 1] = np.nan
+    with pytest.raises(_capi.PyvbHipError) as e:
+        _batch(Y, st0, pri)
+    assert e.value.code == _capi.E_UNSUPPORTED
 
 
 def test_nondefault_priors():

@@ -119,10 +119,14 @@ def test_graphs_without_a_fused_plan_go_node_by_node():
     with pytest.raises(NotImplementedError):
         _recognise.describe(mu)
     assert isinstance(_recognise.bind(mu), GenericPlan) and prec._plan is mu._plan and xs[3]._plan is mu._plan
-    # an LDS whose outputs have missing values
+    # an LDS whose outputs have missing values is still the fused plan's graph (the outputs concerned become nodes of
+    # their own) -- unless their initial covariance is not a multiple of the identity
     g, Y, st0, pri = _graph()
     g["Ys"][2].observed = False
     g["Ys"][2].observe(np.array([[1.0], [np.nan], [0.5], [np.nan]]))
+    d = _recognise.describe(g["Xs"][0])
+    assert d["Ys"][2] is g["Ys"][2] and g["Ys"][2].partially_observed and len(d["Ys"]) == len(d["Xs"])
+    g["Ys"][2].qcov = np.diag([1.0, 2.0, 1.0, 1.0])
     with pytest.raises(NotImplementedError):
         _recognise.describe(g["Xs"][0])
     assert isinstance(_recognise.bind(g["Xs"][0]), GenericPlan)

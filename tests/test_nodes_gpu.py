@@ -29,6 +29,12 @@ def test_example_loop_through_the_node_api(golden):
         pytest.skip("node-by-node reads are slow for the large fixture; covered by test_gpu_parity")
     g = _golden_module().build_graph(nodes, Y[0], pri, {k: v for k, v in st0.items()})
     Xs, As, Cs, Q, R = g["Xs"], g["As"], g["Cs"], g["Q"], g["R"]
+    missing = bool(np.isnan(Y).any())
+    if missing:         # explicit initial posterior of the outputs that are not fully observed (as make_golden.run_case does)
+        for t, y in enumerate(g["Ys"]):
+            if not y.observed:
+                y.qmu = st0["Yq"][0, t].reshape(-1, 1).copy()
+                y.qcov = np.eye(meta["K"]) * st0["Yrowvar"][0, t]
     plan = None
     for it in range(1, max(meta["iters"]) + 1):
         # examples/Linear_Dynamic_System.py:69-77
@@ -38,6 +44,8 @@ def test_example_loop_through_the_node_api(golden):
         Xs.reverse()
         [x.update() for x in Xs]
         Xs.reverse()
+        if missing:
+            [y.update() for y in g["Ys"] if not y.observed]
         [a.update() for a in As]
         [c.update() for c in Cs]
         Q.update()
@@ -64,6 +72,11 @@ def test_example_loop_through_the_node_api(golden):
             assert _rel(np.asarray(Q.qb, dtype=float), z[tag + "Q_b"]) <= RTOL
             assert _rel(np.asarray(R.qb, dtype=float), z[tag + "R_b"]) <= RTOL
             assert _rel(np.asarray(Q.qa, dtype=float), z[tag + "Q_a"]) <= RTOL
+            if missing:
+                from pyvb_amd._recognise import LDSPlan
+                assert isinstance(plan, LDSPlan)        # still the fused kernels
+                assert _rel(np.hstack([y.qmu for y in g["Ys"]]).T, z[tag + "Yq"]) <= RTOL
+                assert _rel(np.stack([np.diag(y.qcov) for y in g["Ys"]]), z[tag + "Yvar"]) <= RTOL
             parts = plan.elbo_parts()
             ref = z[tag + "elbo_parts"]
             assert abs(parts.sum() - ref.sum()) <= RTOL * abs(ref.sum())

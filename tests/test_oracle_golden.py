@@ -27,8 +27,8 @@ def _close_qld(a, b, what):
     assert np.all(np.abs(sa - sb)[ok] <= 1e-10 * np.maximum(1.0, np.abs(sb[ok]))), what
 
 
-def _prepare(st0, pri, T):
-    st = O.expand_state(st0, pri, T)
+def _prepare(st0, pri, T, Y=None):
+    st = O.expand_state(st0, pri, T, Y)
     if pri["noise"] == "wishart":   # the fixture stores qw as the diagonal matrix diag(init Q_b)
         st["Q_b"] = np.einsum("nd,de->nde", st0["Q_b"], np.eye(st0["Q_b"].shape[1]))
         st["R_b"] = np.einsum("nd,de->nde", st0["R_b"], np.eye(st0["R_b"].shape[1]))
@@ -74,24 +74,29 @@ def test_forward_sweep_order(golden):
     """State after the first forward sweep only: pins the Gauss-Seidel order
     (new mu_{t-1}, old mu_{t+1})."""
     meta, Y, st0, pri, z = golden
-    st = _prepare(st0, pri, meta["T"])
+    st = _prepare(st0, pri, meta["T"], Y)
     O.sweep(st, pri, Y, "forward")
     _close(st["X"][0], z["it1_fwd_X"], "forward sweep")
 
 
 def test_iterations_match_reference(golden):
     meta, Y, st0, pri, z = golden
-    st = _prepare(st0, pri, meta["T"])
+    st = _prepare(st0, pri, meta["T"], Y)
+    missing = bool(np.isnan(Y).any())
     for it in range(1, max(meta["iters"]) + 1):
-        parts = O.iterate(st, pri, Y, with_elbo=(meta["noise"] != "wishart"))
+        parts = O.iterate(st, pri, Y, with_elbo=(meta["noise"] != "wishart"), update_outputs=missing)
         if it in meta["iters"]:
             _check_snapshot(st, parts, z, "it%d_" % it, meta["noise"])
+            if missing:     # the outputs that are not fully observed: posterior means and (diagonal) covariances
+                _close(st["Yq"][0], z["it%d_Yq" % it], "Yq")
+                _close(st["Yvar"][0], z["it%d_Yvar" % it], "Yvar")
+                assert z["it%d_Ycov_offdiag_max" % it] == 0.0
 
 
 def test_single_updates_equal_sweep(golden):
     """update_x(t) for t = 0..T-1 is the forward sweep."""
     meta, Y, st0, pri, z = golden
-    st = _prepare(st0, pri, meta["T"])
+    st = _prepare(st0, pri, meta["T"], Y)
     for t in range(meta["T"]):
         O.update_x(st, pri, Y, t)
     _close(st["X"][0], z["it1_fwd_X"], "stepwise forward sweep")
