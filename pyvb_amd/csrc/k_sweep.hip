@@ -31,9 +31,6 @@ struct SweepArgs {
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-#ifndef SWEEP_VARIANT
-#define SWEEP_VARIANT 0     // 0: round robin over the accumulators (round 1), 1: chains, 2: chains + G y of the next step in the select's shadow
-#endif
 
 // Xs[0].update() / Xs[T-1].update() (Gaussian.update gaussian.py:102-123 with the messages of
 // Multiplication.pass_up_m1_m2 / pass_down_Ex, node.py:182-242), lane = row, one wavefront:
@@ -217,19 +214,6 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[m][r] = act ? acc[m][r] : x[m][r];
         };
-        // The same select for one tile, pinned where it is written: the accumulators are held in AGPRs up to this
-        // point and the new state is complete behind it (otherwise the compiler reads all accumulators back into
-        // VGPRs as soon as the last MFMA has issued, and waits there with the matrix pipe idle).
-        auto select_here = [&](int m, bool act, const d4* acc) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double t = acc[m][r];
-                asm volatile("" : "+a"(t));
-                x[m][r] = act ? t : x[m][r];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(x[m][r]));
-        };
         auto pending_row = [&](int j, bool act) {
             return (act && j >= 0 && (a.keep_x || before + j == Tint - 1)) ? Xn + (size_t)(tbase + sgn * j) * DP : trash;
         };
@@ -239,26 +223,15 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
             for (int m = 0; m < DT; ++m) select_tile(m, act, acc);
             out_pending = pending_row(j, act);
         };
-        // acc += M v for a matrix resident in registers as A operands (R or I) and a state tile set v.
-        // SWEEP_VARIANT >= 1: the DS k-steps of a row tile back to back -- a chain of dependent MFMAs on one
-        // accumulator issues every ~72 cycles, the same MFMAs dealt round robin over four accumulators every
-        // ~87 (profiles/r01/microbench_f64.txt: the accumulator of a dependent MFMA is forwarded inside the
-        // pipe, that of an independent one is read from the register file).  The fences keep the compiler's
-        // scheduler from interleaving the chains again.
+        // acc += M v for a matrix resident in registers as A operands (R or I) and a state tile set v.  The MFMAs go
+        // round robin over the row tiles' accumulators; dependent chains per accumulator, the next step's G y in the
+        // shadow of the select and accumulators pinned in AGPRs were built and measured in round 2 -- same time, the
+        // chip is at its power cap (profiles/r02/limits.txt; the variants: profiles/experiments/sweep_mfma_order.patch).
         auto mul_resident = [&](d4* acc, auto& M, const d4* v) {
-#if SWEEP_VARIANT >= 1
-#pragma unroll
-            for (int m = 0; m < DT; ++m) {
-#pragma unroll
-                for (int s = 0; s < DS; ++s) acc[m] = MFMA(M[m][s], v[s >> 2][s & 3], acc[m]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#else
 #pragma unroll
             for (int s = 0; s < DS; ++s)
 #pragma unroll
                 for (int m = 0; m < DT; ++m) acc[m] = MFMA(M[m][s], v[s >> 2][s & 3], acc[m]);
-#endif
         };
         if constexpr (MODE == 2) {
             // One product per step: the sweep is bound by the c_t stream, so c rows are fetched PF
@@ -315,27 +288,10 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                     mul_resident(acc, rn, x);
                     const bool act = active(j + p);
                     const bool keep = act && j + p >= 0;      // warm-up steps and idle columns do not count
-#if SWEEP_VARIANT >= 1
-                    // Sxx tile by tile (chains of 4 on one accumulator); behind every row of tiles the select of the
-                    // new state's tile m and its way into LDS, in the shadow of the MFMAs still in the pipe
-#pragma unroll
-                    for (int m = 0; m < DT; ++m) {
-#pragma unroll
-                        for (int k = m; k < DT; ++k)
-#pragma unroll
-                            for (int s4 = 0; s4 < 4; ++s4) sxx[m][k] = MFMA(xt[m][s4], xt[k][s4], sxx[m][k]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        select_here(m, act, acc);
-                        tile_stage(m, keep);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    out_pending = pending_row(j + p, act);
-#else
                     tile_accumulate(xt);
                     finish_step(j + p, acc);
 #pragma unroll
                     for (int m = 0; m < DT; ++m) tile_stage(m, keep);
-#endif
                 }
             }
             {
@@ -356,79 +312,6 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                         if (k > m) Sn[(size_t)col * DP + row] = sxx[m][k][e];
                     }
         } else {
-#if SWEEP_VARIANT >= 2
-        // Software pipeline over the steps: G y_{t+1} does not depend on the state, so it is formed at the END of
-        // step t into a second accumulator set, tile by tile, and the select that turns step t's accumulators
-        // into the state runs in the shadow of those MFMAs instead of between two steps with the pipe idle.
-        //   step t:   acc += R mu_{t-1}(new)  [c_t out]   acc += I mu_{t+1}(old)   nxt = G y_{t+1} || x <- acc
-        // The loop is unrolled by two so that both accumulator sets have fixed registers.  An extra step past the
-        // end is inactive for every column (active() is false from Lseg on) and changes nothing.
-        // Prologue: G y of the first step, then the same sequence of vector-memory operations as one loop step
-        // (see the note on vmcnt below).
-        // nxt = G y: tile by tile, the KS k-steps of a tile back to back; G's operands come from LDS four k-steps at a
-        // time, the next four on their way while the current four are multiplied.  after(m) runs behind tile m.
-        auto mul_G = [&](d4* nxt, auto&& after) {
-            // the LDS offset is made opaque: G is loop invariant and the compiler would otherwise hoist all of it
-            // into registers that R and I already fill
-            int goff = lane;
-            asm volatile("" : "+v"(goff));
-            constexpr int NQ = KS / 4;              // groups of four k-steps per tile
-            double gq[2][4];
-            auto fetch = [&](int m, int g, double* dst) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) dst[u] = gl[(m * KS + 4 * g + u) * 64 + goff];
-            };
-            fetch(0, 0, gq[0]);
-#pragma unroll
-            for (int m = 0; m < DT; ++m) {
-                nxt[m] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int g = 0; g < NQ; ++g) {
-                    const int cur = (m * NQ + g) & 1;
-                    if (g + 1 < NQ) fetch(m, g + 1, gq[cur ^ 1]);
-                    else if (m + 1 < DT) fetch(m + 1, 0, gq[cur ^ 1]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int k = 4 * g + u;
-                        nxt[m] = MFMA(gq[cur][u], yv[k >> 1][k & 1], nxt[m]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                after(m);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        // (moved up: select_here)
-        d4 accA[DT], accB[DT];
-        load_y(jstart, yv);
-        mul_G(accA, [](int) {});
-        if constexpr (MODE == 1) store_x(trash + 64);  // stands for the c_t store
-        load_o(jstart, mo);
-        load_y(jstart + 1, yv);
-        store_x(trash);
-        __builtin_amdgcn_sched_barrier(0);
-        auto step = [&](int j, d4* acc, d4* nxt) {
-            mul_resident(acc, rn, x);               // R mu_{t-dir} (new): the previous accumulators are the B operands
-            if constexpr (MODE == 1) {              // c_t = G y_t + R mu_{t-1} for the backward sweep
-                double* ur = u_row(j);
-#pragma unroll
-                for (int m = 0; m < DT; ++m) *reinterpret_cast<d4*>(ur + (m * 4 + q) * 4) = acc[m];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            mul_resident(acc, ip, mo);              // I mu_{t+dir} (old)
-            load_o(j + 1, mo);
-            __builtin_amdgcn_sched_barrier(0);
-            const bool act = active(j);
-            mul_G(nxt, [&](int m) { select_here(m, act, acc); });
-            load_y(j + 2, yv);
-            store_x(pending_row(j, act));
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        for (int j = jstart; j < Lseg; j += 2) {
-            step(j, accA, accB);
-            step(j + 1, accB, accA);
-        }
-#else
         // Prologue: the same sequence of vector-memory operations as one loop iteration (loads, stores
         // -- into the trash row -- , loads), so that the compiler's in-order vmcnt bookkeeping at the
         // loop head sees the same number of younger operations on both incoming edges and the wait
@@ -446,19 +329,10 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
                 // compiler would otherwise hoist all of it into registers that R and I already fill.
                 int goff = lane;
                 asm volatile("" : "+v"(goff));
-#if SWEEP_VARIANT >= 1
-#pragma unroll
-                for (int m = 0; m < DT; ++m) {
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) acc[m] = MFMA(gl[(m * KS + s) * 64 + goff], yv[s >> 1][s & 1], acc[m]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#else
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
                     for (int m = 0; m < DT; ++m) acc[m] = MFMA(gl[(m * KS + s) * 64 + goff], yv[s >> 1][s & 1], acc[m]);
-#endif
                 // Next step's y goes into the registers just consumed; it has the R and I blocks
                 // (2/3 of a step) to arrive.  The store of the PREVIOUS step's state is issued right
                 // behind those loads: vector-memory operations retire in order, so a wait for the
@@ -488,7 +362,6 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a) {
             finish_step(j, acc);
         }
         store_x(out_pending);
-#endif
         }
         // the column that holds the last interior node hands its state to the closing boundary step
         const int clast = (Tw - 1) / Lseg;
