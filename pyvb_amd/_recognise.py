@@ -62,6 +62,7 @@ class LDSPlan(object):
         self.index[id(R)] = ("r", 0)
         self.pending = []
         self.cache = None
+        self.stale = False              # set when a node of the graph gains a child or an observation after binding
         self.x_updated = False
         self.n_random_nodes = 2 * self.T + 2 * self.D + 2
         for n in _component(Xs[0]):         # the operation nodes and Constants too: their messages go through mirror()
@@ -132,6 +133,17 @@ class LDSPlan(object):
             self.Q.__dict__["_h_qw"], self.R.__dict__["_h_qw"] = self.read(self.Q, "qw"), self.read(self.R, "qw")
         else:
             self.Q.__dict__["_h_qb"], self.R.__dict__["_h_qb"] = self.read(self.Q, "qb"), self.read(self.R, "qb")
+
+    def release(self):
+        """Device state back into the nodes and the graph unbound (it is bound anew, as it is now, at the next use)."""
+        self.flush()
+        if self.Xs[0]._plan is not self:
+            return
+        self._sync_host()
+        for n in _component(self.Xs[0]):
+            if n._plan is self:
+                n._plan = None
+        self.batch.close()
 
     def _demote(self, rest):
         """Hand the graph to the generic node-by-node plan and replay the remaining update() requests there."""
@@ -502,6 +514,7 @@ class PCAPlan(object):
         self.index[id(Mu)] = ("mu", 0)
         self.index[id(Beta)] = ("beta", 0)
         self.pending, self.cache = [], None
+        self.stale = False
         self.n_random_nodes = 2 * self.N + self.q + 2
         for n in _component(W):
             n._plan = self
@@ -578,16 +591,29 @@ class PCAPlan(object):
             return float(parts[4])
         return self.mirror().node_llb(node)
 
+    def _sync_host(self):
+        self._pull()
+        for nd in self.Ws + self.Zs + self.Xs + [self.Mu]:
+            for name in ("qmu", "qcov"):
+                nd.__dict__["_h_" + name] = self.read(nd, name)
+        self.Beta.__dict__["_h_qb"] = self.read(self.Beta, "qb")
+
+    def release(self):
+        """See LDSPlan.release."""
+        self.flush()
+        self._sync_host()
+        for n in _component(self.W):
+            if n._plan is self:
+                n._plan = None
+        self.batch.close()
+
     def mirror(self):
         """See LDSPlan.mirror."""
         self.flush()
         if getattr(self, "_mirror", None) is None or self._mirror_of is not self.cache or self.cache is None:
             from .generic import GenericPlan
             c = self._pull()
-            for nd in self.Ws + self.Zs + self.Xs + [self.Mu]:
-                for name in ("qmu", "qcov"):
-                    nd.__dict__["_h_" + name] = self.read(nd, name)
-            self.Beta.__dict__["_h_qb"] = self.read(self.Beta, "qb")
+            self._sync_host()
             if getattr(self, "_mirror", None) is not None:
                 self._mirror.ex and self._mirror.ex.close()
             self._mirror = GenericPlan(self.W, adopt=False)

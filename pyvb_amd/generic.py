@@ -309,8 +309,7 @@ class GenericPlan(object):
         self.temp_base = off
         self.temp_high = off
         self._init = init
-        self._tapes = {}                  # key -> (tape id, result refs)
-        self._pending_tapes = []          # (key, ops) built but not uploaded (the arena size is only known then)
+        self._tapes = {}                  # key -> (tape id or None while not uploaded, records, result refs)
         self._executor_factory = executor_factory or EXECUTOR_FACTORY
         self.ex = None
         self.n_random_nodes = len([n for n in self.nodes if isinstance(n, (N.Gaussian, N.Gamma, N.DiagonalGamma, N.Wishart))])

@@ -71,11 +71,11 @@ def _wrap(x):
 
 
 def _graph_changed(node):
-    """A node gained a child or an observation: a generic plan that was built for the old graph is stale (its tapes
-    spell the old message structure) and is rebuilt at the next use.  The fused LDS / PCA plans are bound to complete
-    graphs and do not follow later changes."""
+    """A node gained a child or an observation: the plan that was built for the old graph is stale (the generic plan's
+    tapes spell the old message structure, a fused plan was recognised on the old graph).  At the next use its state is
+    pulled back into the nodes and the graph is bound again as it is then."""
     plan = getattr(node, "_plan", None)
-    if plan is not None and getattr(plan, "generic", False):
+    if plan is not None:
         plan.stale = True
 
 
@@ -219,9 +219,12 @@ class _DeviceAttr(object):
         return obj.__dict__.get("_h_" + self.name)
 
     def __set__(self, obj, value):
+        plan = getattr(obj, "_plan", None)
+        if plan is not None and getattr(plan, "stale", False):
+            plan.release()              # device state back into the nodes first: the assignment below must win
         obj.__dict__["_h_" + self.name] = value
         if getattr(obj, "_plan", None) is not None:
-            _plan_of(obj).write(obj, self.name, value)
+            obj._plan.write(obj, self.name, value)
 
 
 class Gaussian(Node):

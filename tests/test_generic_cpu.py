@@ -110,6 +110,28 @@ def test_graph_growing_after_the_first_update(numpy_executor):
     _close(mu.qmu, np.linalg.solve(np.eye(2) * 8.01, 4.0 * np.array([[4.0], [2.0]])), "two children")
 
 
+def test_observing_a_node_of_a_bound_graph(numpy_executor):
+    """observe() on a node whose graph already runs on the device: the observation must survive the re-bind (the plan's
+    state is pulled back into the nodes before the new value is stored)."""
+    from pyvb_amd import nodes
+    rng = np.random.default_rng(4)
+    mu = nodes.Gaussian(2, np.zeros((2, 1)), np.eye(2) * 1e-2)
+    ys = [nodes.Gaussian(2, mu, np.eye(2) * 4.0) for _ in range(3)]
+    for n in [mu] + ys:
+        n.qmu, n.qcov = rng.standard_normal((2, 1)), np.eye(2)
+    ys[0].observe(np.array([[1.0], [2.0]]))
+    mu.update()
+    ys[1].update()                                     # a latent child: follows its parent
+    _close(ys[1].qmu, mu.qmu, "latent child")
+    ys[1].observe(np.array([[5.0], [-1.0]]))            # ... and is observed afterwards
+    _close(ys[1].qmu, np.array([[5.0], [-1.0]]), "the observation is what the node holds")
+    assert np.abs(ys[1].qcov).max() == 0.0
+    mu.update()
+    P = np.eye(2) * (1e-2 + 12.0)
+    w = 4.0 * (np.array([[1.0], [2.0]]) + np.array([[5.0], [-1.0]]) + ys[2].qmu)
+    _close(mu.qmu, np.linalg.solve(P, w), "three children, two of them observed")
+
+
 def test_constant_matrix_lds(numpy_executor):
     """The constant-parameter LDS of src/tests.py:223-286 (Constant A, C, Q, R).  The reference is numerically wrong
     there (Multiplication.pass_up_m1_m2 returns a bare matrix for a Constant left operand and

@@ -140,3 +140,39 @@ def test_single_messages_and_terms_of_the_fused_lds_plan(golden):
     if T > 2:
         m1, m2 = Xs[1].children[0].pass_up_m1_m2(Xs[1])         # Mult(., X_1), hstack branch node.py:213-227
         assert m1.shape == (meta["D"], meta["D"]) and np.all(np.isfinite(m1)) and np.all(np.isfinite(m2))
+
+
+def test_fused_plan_follows_a_late_observation(monkeypatch):
+    """A node of a graph that already runs on the fused LDS kernels is observed afterwards (a known entry of A,
+    examples/LDS_knowns_in_A.py:73-74, but after the first iterations): the plan is re-bound with its state carried over.
+    Checked against the same script run node by node on the generic plan."""
+    from pyvb_amd import nodes, synth, generic, _recognise
+    import make_golden as MG
+    T, D, K = 25, 3, 4
+    Y, st0, pri = synth.make_problem(T, D, K, 1, 61)
+
+    def script(force_generic):
+        if force_generic:
+            monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+        else:
+            monkeypatch.undo()
+        g = MG.build_graph(nodes, Y[0], pri, st0)
+        Xs, As, Cs, Q, R = g["Xs"], g["As"], g["Cs"], g["Q"], g["R"]
+
+        def iteration():
+            [x.update() for x in Xs]
+            Xs.reverse(); [x.update() for x in Xs]; Xs.reverse()
+            [a.update() for a in As]; [c.update() for c in Cs]
+            Q.update(); R.update()
+        iteration()
+        first_plan = Xs[0]._plan
+        As[1].observe(np.array([[0.5], [np.nan], [np.nan]]))
+        iteration(); iteration()
+        return (np.hstack([x.qmu for x in Xs]), np.hstack([a.qmu for a in As]), np.asarray(Q.qb), As[1].qcov, first_plan, Xs[0]._plan)
+
+    ref = script(True)
+    got = script(False)
+    assert isinstance(got[4], _recognise.LDSPlan) and isinstance(got[5], _recognise.LDSPlan) and got[4] is not got[5]
+    assert abs(got[1][0, 1] - 0.5) < 1e-15 and got[3][0, 0] == 0.0
+    for a, b, what in zip(got[:4], ref[:4], ("X", "A", "Q.qb", "cov of the column")):
+        _close(a, b, what, 1e-9)
