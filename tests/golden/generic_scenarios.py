@@ -208,6 +208,20 @@ def lds_parameters_first(nodes, rng):
     return order, named
 
 
+def diagonal_gaussian_scaling(nodes, rng):
+    """A DiagonalGaussian (gaussian.py:185-203) as the left operand of a Multiplication: the elementwise branches of
+    Multiplication.pass_up_m1_m2 (node.py:228-230) and pass_down_ExxT (:273-276).  Only the right operand is updated: as a
+    requester the DiagonalGaussian gets the hstack tuple of node.py:202, which Gaussian.update cannot use."""
+    d = 3
+    S = nodes.DiagonalGaussian(d, np.ones((d, 1)), np.eye(d) * 4.0)
+    B = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 0.1)
+    C = nodes.Gaussian(d, S * B, np.eye(d) * 10.0)
+    C.observe(np.array([[1.0], [-2.0], [0.5]]))
+    named = {"S": S, "B": B, "C": C}
+    _init_all(named, rng)
+    return [B], named
+
+
 def wishart_precision(nodes, rng):
     """A Wishart precision over vector observations with an unknown mean (nodes_todo.py:205-234).  Only the state after
     the FIRST pass is a valid reference target (the reference mutates its prior)."""
@@ -238,6 +252,7 @@ SCENARIOS = {
     "lds_missing_outputs": (lds_missing_outputs, 110, (1, 3), []),
     "wishart_precision": (wishart_precision, 111, (1,), []),
     "lds_parameters_first": (lds_parameters_first, 112, (1, 2), []),
+    "diagonal_gaussian_scaling": (diagonal_gaussian_scaling, 113, (1, 2), [("C", "B")]),
 }
 
 # scenarios whose graph binds to a fused plan first (needs the GPU even though they end up node by node)
