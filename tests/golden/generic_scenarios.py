@@ -208,6 +208,41 @@ def lds_parameters_first(nodes, rng):
     return order, named
 
 
+def lds_network_crawl(nodes, rng):
+    """The complete LDS graph updated in the order Network.fetch_network() discovers it from [A] (network.py:58-96): the
+    columns of A, then states, outputs and the rest interleaved -- what `Network([A]).fetch_network(); learn()` does.  Not a
+    sweep order, so pyvb_amd runs it node by node (LDSPlan._demote)."""
+    import sys
+    T, D, K = 5, 2, 3
+    As = [nodes.Gaussian(D, np.zeros((D, 1)), np.eye(D) * 1e-3) for _ in range(D)]
+    A = nodes.hstack(As)
+    Cs = [nodes.Gaussian(K, np.zeros((K, 1)), np.eye(K) * 1e-3) for _ in range(D)]
+    C = nodes.hstack(Cs)
+    Q = nodes.DiagonalGamma(D, np.full(D, 1e-3), np.full(D, 1e-3))
+    R = nodes.DiagonalGamma(K, np.full(K, 1e-3), np.full(K, 1e-3))
+    Y = rng.standard_normal((T, K))
+    Xs = [nodes.Gaussian(D, np.zeros((D, 1)), np.eye(D))]
+    Ys = [nodes.Gaussian(K, C * Xs[0], R)]
+    for t in range(1, T):
+        Xs.append(nodes.Gaussian(D, A * Xs[-1], Q))
+        Ys.append(nodes.Gaussian(K, C * Xs[-1], R))
+    for y, row in zip(Ys, Y):
+        y.observe(row.reshape(K, 1).copy())
+    named = {"Q": Q, "R": R}
+    for nm, lst in (("X", Xs), ("Y", Ys), ("a", As), ("c", Cs)):
+        named.update({"%s%02d" % (nm, i): n for i, n in enumerate(lst)})
+    _init_all(named, rng)
+    pkg = sys.modules[nodes.__name__.rsplit(".", 1)[0]]
+    net = pkg.Network([A])
+    try:
+        net.fetch_network(verbose=False)
+    except TypeError:                   # the reference's fetch_network takes no arguments (and prints)
+        net.fetch_network()
+    net.find_iterable()
+    order = [n for n in net.iterable_nodes if not getattr(n, "observed", False)]
+    return order, named
+
+
 def diagonal_gaussian_scaling(nodes, rng):
     """A DiagonalGaussian (gaussian.py:185-203) as the left operand of a Multiplication: the elementwise branches of
     Multiplication.pass_up_m1_m2 (node.py:228-230) and pass_down_ExxT (:273-276).  Only the right operand is updated: as a
@@ -253,10 +288,11 @@ SCENARIOS = {
     "wishart_precision": (wishart_precision, 111, (1,), []),
     "lds_parameters_first": (lds_parameters_first, 112, (1, 2), []),
     "diagonal_gaussian_scaling": (diagonal_gaussian_scaling, 113, (1, 2), [("C", "B")]),
+    "lds_network_crawl": (lds_network_crawl, 114, (1, 3), []),
 }
 
 # scenarios whose graph binds to a fused plan first (needs the GPU even though they end up node by node)
-NEEDS_DEVICE = ("lds_parameters_first",)
+NEEDS_DEVICE = ("lds_parameters_first", "lds_network_crawl")
 
 
 def snapshot(named):

@@ -176,3 +176,26 @@ def test_fused_plan_follows_a_late_observation(monkeypatch):
     assert abs(got[1][0, 1] - 0.5) < 1e-15 and got[3][0, 0] == 0.0
     for a, b, what in zip(got[:4], ref[:4], ("X", "A", "Q.qb", "cov of the column")):
         _close(a, b, what, 1e-9)
+
+
+def test_network_learn_in_crawl_order_on_the_lds_graph():
+    """`Network([A]).fetch_network(); learn(3)` (network.py:40-96) on the LDS graph: the crawl order is not a sweep order,
+    so after binding to the fused plan the graph moves to the generic one inside learn(); states, parameters and
+    Network.llb against the reference's fixture (generic_lds_network_crawl.npz)."""
+    from pyvb_amd import nodes
+    from pyvb_amd.network import Network
+    from pyvb_amd.generic import GenericPlan
+    build, seed, _, _ = GS.SCENARIOS["lds_network_crawl"]
+    order, named = build(nodes, np.random.default_rng(seed))
+    z = dict(np.load(os.path.join(HERE, "golden", "generic_lds_network_crawl.npz"), allow_pickle=False))
+    A = named["a00"].children[0]
+    net = Network([A])
+    net.fetch_network(verbose=False)
+    net.learn(3, tol=-np.inf, verbose=False)
+    assert isinstance(named["X00"]._plan, GenericPlan)
+    for k, v in GS.snapshot(named).items():
+        if k.endswith(".qcov") and np.abs(z["it3." + k]).max() == 0.0:
+            continue
+        _close(v, z["it3." + k], "after learn(3): " + k, 1e-9)
+    ref = sum(float(z[k]) for k in z if k.startswith("it3.") and k.endswith(".llb"))
+    assert abs(net.llb - ref) <= 1e-8 * abs(ref), (net.llb, ref)
