@@ -470,9 +470,12 @@ def describe_pca(start):
         cov = col.__dict__["_h_qcov"]
         if np.abs(cov - np.diag(np.diag(cov))).max() != 0.0:
             _fail("initial covariances of the columns must be diagonal")
+    # The kernels keep ONE covariance for all Z_n (they share it from their first update on).  The constructors draw an
+    # individual one per node (gaussian.py:70-72); everything that reads them before that first update -- the W columns,
+    # Beta, the lower bound's trace terms -- is linear in them and sums over n, so their mean serves exactly.
     zc = Zs[0].__dict__["_h_qcov"]
     if any(np.abs(z.__dict__["_h_qcov"] - zc).max() != 0.0 for z in Zs):
-        _fail("the device path keeps one covariance for all Z_n: give them equal initial covariances")
+        zc = np.mean([z.__dict__["_h_qcov"] for z in Zs], axis=0)
     pri = {
         "W_prior_mean": np.hstack([w.mean_parent.value for w in Ws]).astype(float),
         "W_prior_prec": np.stack([_diag_constant(w.precision_parent, "a column's prior precision") for w in Ws]),
@@ -515,6 +518,7 @@ class PCAPlan(object):
         self.index[id(Beta)] = ("beta", 0)
         self.pending, self.cache = [], None
         self.stale = False
+        self.z_updated = False          # until then Z_n.qcov reads the node's own initial covariance (host)
         self.n_random_nodes = 2 * self.N + self.q + 2
         for n in _component(W):
             n._plan = self
@@ -535,13 +539,14 @@ class PCAPlan(object):
                 j += 1
             lo, hi = idx, ops[j][1] + 1
             if kind == "w":
-                if (lo, hi) != (0, self.q):
-                    raise NotImplementedError("the columns of W update together on the device: call update() on all of them in order")
+                if (lo, hi) != (0, self.q):     # a single column: not what the fused kernels serve -> node by node
+                    return self._demote(ops[i:])
                 b.update_W()
             elif kind == "z":
                 if (lo, hi) != (0, self.N):
-                    raise NotImplementedError("the Z_n update together on the device: call update() on all of them in order")
+                    return self._demote(ops[i:])
                 b.update_Z()
+                self.z_updated = True
             elif kind == "x":
                 b.update_X(lo, hi)
             elif kind == "mu":
@@ -558,10 +563,15 @@ class PCAPlan(object):
 
     def read(self, node, name):
         kind, i = self.index[id(node)]
+        self.flush()
+        if node._plan is not self:
+            return node._plan.read(node, name)
         st = self._pull()
         if kind == "w":
             return st["W_mean"][:, [i]].copy() if name == "qmu" else (np.diag(st["W_var"][i]) if name == "qcov" else node.__dict__.get("_h_" + name))
         if kind == "z":
+            if name == "qcov" and not self.z_updated:
+                return node.__dict__.get("_h_qcov")
             return st["Z"][i].reshape(-1, 1).copy() if name == "qmu" else (st["Z_cov"].copy() if name == "qcov" else node.__dict__.get("_h_" + name))
         if kind == "x":
             if name == "qmu":
@@ -580,9 +590,14 @@ class PCAPlan(object):
 
     def elbo_parts(self):
         self.flush()
+        if self.W._plan is not self:
+            raise NotImplementedError("the graph runs node by node now: use Network.learn or the nodes' log_lower_bound()")
         return self.batch.elbo()
 
     def node_llb(self, node):
+        self.flush()
+        if node._plan is not self:
+            return node._plan.node_llb(node)
         kind, _ = self.index[id(node)]
         parts = self.elbo_parts()
         if kind == "mu":
@@ -592,20 +607,50 @@ class PCAPlan(object):
         return self.mirror().node_llb(node)
 
     def _sync_host(self):
-        self._pull()
+        st = self._pull()
         for nd in self.Ws + self.Zs + self.Xs + [self.Mu]:
             for name in ("qmu", "qcov"):
                 nd.__dict__["_h_" + name] = self.read(nd, name)
         self.Beta.__dict__["_h_qb"] = self.read(self.Beta, "qb")
+        # q_ln_det (gaussian.py:120, quirk Q1) follows from the covariances the device holds: 0.5 / sum log diag chol(qprec)
+        qld = lambda cov: 0.5 / np.sum(np.log(np.diag(np.linalg.cholesky(np.linalg.inv(cov)))))
+        with np.errstate(all="ignore"):
+            for nd in self.Ws + [self.Mu]:
+                nd.__dict__["_h_q_ln_det"] = float(qld(nd.__dict__["_h_qcov"]))
+            if self.z_updated:
+                qz = float(qld(st["Z_cov"]))
+                for z in self.Zs:
+                    z.__dict__["_h_q_ln_det"] = qz
+            for n, x in enumerate(self.Xs):
+                if not self.obs[n].any():           # a row without any observation is a latent node: qprec = <beta> I, with the
+                    x.__dict__["_h_q_ln_det"] = 0.5 / (0.5 * self.d * np.log(1.0 / st["X_rowvar"][n]))    # <beta> of its last update
 
     def release(self):
         """See LDSPlan.release."""
         self.flush()
+        if self.W._plan is not self:
+            return
         self._sync_host()
         for n in _component(self.W):
             if n._plan is self:
                 n._plan = None
         self.batch.close()
+
+    def _demote(self, rest):
+        """See LDSPlan._demote."""
+        from .generic import GenericPlan
+        lookup = {v: k for k, v in self.index.items()}
+        by_id = {id(n): n for n in self.Ws + self.Zs + self.Xs + [self.Mu, self.Beta]}
+        self._sync_host()
+        for n in _component(self.W):
+            n._plan = None
+        self.batch.close()
+        gp = GenericPlan(self.W)
+        for key in rest:
+            node = by_id[lookup[key]]
+            if not getattr(node, "observed", False):
+                gp.enqueue(node)
+        return gp
 
     def mirror(self):
         """See LDSPlan.mirror."""

@@ -199,3 +199,29 @@ def test_network_learn_in_crawl_order_on_the_lds_graph():
         _close(v, z["it3." + k], "after learn(3): " + k, 1e-9)
     ref = sum(float(z[k]) for k in z if k.startswith("it3.") and k.endswith(".llb"))
     assert abs(net.llb - ref) <= 1e-8 * abs(ref), (net.llb, ref)
+
+
+def test_single_terms_of_the_fused_pca_plan():
+    """Per-node log_lower_bound() and pass_up_m1_m2 on a graph that runs through the fused VB-PCA kernels (mirror of the
+    plan's state on the generic plan): the per-node terms add up to the class sums of the reference's fixture."""
+    from pyvb_amd import nodes
+    import pyvb_amd
+    import make_golden as MG
+    from test_pca_oracle_golden import load_pca
+    N, d, q, init, pri, z = load_pca(os.path.join(HERE, "golden", "pca_n60_d12_q3.npz"))
+
+    class Mod(object):
+        pass
+    mod = Mod(); mod.nodes = nodes; mod.Network = pyvb_amd.Network
+    g = MG.pca_build_graph(mod, init, pri)
+    net = g["net"]
+    net.learn(1, tol=-np.inf, verbose=False)
+    from pyvb_amd._recognise import PCAPlan
+    assert isinstance(g["W"]._plan, PCAPlan)
+    ref = z["it1_elbo_parts"]
+    scale = np.abs(ref).sum()
+    got = [sum(n.log_lower_bound() for n in grp) for grp in (g["Ws"], g["Zs"], g["Xs"], [g["Mu"]], [g["Beta"]])]
+    for v, r in zip(got, ref):
+        assert abs(v - r) <= 1e-8 * scale, (got, ref)
+    m1, m2 = g["Xs"][5].pass_up_m1_m2(g["Xs"][5].mean_parent)
+    _close(m1, g["Beta"].pass_down_Ex(), "m1 of an output row", 1e-9)

@@ -192,3 +192,37 @@ def test_integration_stub_runs():
         parts = O.iterate(st, pri, Y)
     assert abs(total - parts.sum()) <= RTOL * abs(parts.sum())
     assert _rel(np.hstack([x.__dict__["_h_qmu"] for x in g["Xs"]]).T, st["X"][0]) <= RTOL
+
+
+def test_pca_demo_of_the_reference_tests_file():
+    """src/tests.py:289-344 `PCA()`: complete data, the constructors' individual random covariances for the Z_n, update
+    order Ws, Mu, Zs, Beta.  Runs on the fused PCA kernels (the mean of the initial Z covariances is all that is read
+    before their first update) and agrees with the same script node by node on the generic plan."""
+    from pyvb_amd import nodes, generic, _recognise
+    rng = np.random.default_rng(8)
+    q, d, N = 2, 3, 40
+    X = rng.standard_normal((N, q)) @ (rng.standard_normal((d, q)) * 3).T + rng.standard_normal(d) + rng.standard_normal((N, d)) * 0.1
+
+    def script(force_generic):
+        np.random.seed(5)               # the constructors draw their initial posteriors from the global stream (Q11)
+        Ws = [nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3) for _ in range(q)]
+        W = nodes.hstack(Ws)
+        Mu = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3)
+        Beta = nodes.Gamma(d, 1e-3, 1e-3)
+        Zs = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q)) for _ in range(N)]
+        Xs = [nodes.Gaussian(d, W * z + Mu, Beta) for z in Zs]
+        [x.observe(v.reshape(d, 1)) for x, v in zip(Xs, X)]
+        if force_generic:
+            generic.GenericPlan(W)
+        for it in range(4):
+            [w.update() for w in Ws]
+            Mu.update()
+            [z.update() for z in Zs]
+            Beta.update()
+        return np.hstack([w.qmu for w in Ws]), Mu.qmu, np.hstack([z.qmu for z in Zs]), Zs[3].qcov, float(Beta.qb), W._plan
+
+    ref = script(True)
+    got = script(False)
+    assert isinstance(got[5], _recognise.PCAPlan) and isinstance(ref[5], generic.GenericPlan)
+    for a, b, what in zip(got[:5], ref[:5], ("W", "Mu", "Z", "cov of a Z_n", "Beta.qb")):
+        assert _rel(a, b) <= 1e-8, what
