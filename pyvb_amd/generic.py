@@ -188,9 +188,7 @@ class Tape(object):
 
 
 class DeviceExecutor(object):
-    """Arena + tape runner behind GenericPlan: binds include/pyvb_hip.h's pyvb_graph_*.  (The CPU tests substitute the
-    numpy restatement of the interpreter, oracle/tape_ref.py, through GenericPlan(executor_factory=...); the product
-    has no such path.)"""
+    """Arena + tape runner behind GenericPlan: binds include/pyvb_hip.h's pyvb_graph_*."""
 
     def __init__(self, arena_doubles, device=0):
         from . import _capi as C
@@ -233,11 +231,6 @@ class DeviceExecutor(object):
             self.close()
         except Exception:
             pass
-
-
-# What GenericPlan runs its tapes on.  The product has exactly one: the device.  tests/test_generic_cpu.py swaps in the
-# numpy restatement of the interpreter (oracle/tape_ref.py) to check the emitters without a GPU.
-EXECUTOR_FACTORY = DeviceExecutor
 
 
 def _component(start):
@@ -310,7 +303,9 @@ class GenericPlan(object):
         self.temp_high = off
         self._init = init
         self._tapes = {}                  # key -> (tape id or None while not uploaded, records, result refs)
-        self._executor_factory = executor_factory or EXECUTOR_FACTORY
+        # what the tapes run on: the device.  (executor_factory exists for tests/test_generic_cpu.py, which checks the emitters
+        # without a GPU by handing in the numpy restatement of the interpreter; nothing in the package passes it.)
+        self._executor_factory = executor_factory or DeviceExecutor
         self.ex = None
         self.n_random_nodes = len([n for n in self.nodes if isinstance(n, (N.Gaussian, N.Gamma, N.DiagonalGamma, N.Wishart))])
         if adopt:

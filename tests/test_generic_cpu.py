@@ -23,8 +23,7 @@ def numpy_executor(monkeypatch):
     missing outputs would otherwise bind to the fused kernels, which need the GPU)."""
     from oracle.tape_ref import NumpyExecutor
     from pyvb_amd import generic, _recognise
-    monkeypatch.setattr(generic, "EXECUTOR_FACTORY", NumpyExecutor)
-    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node, executor_factory=NumpyExecutor))
 
 
 def _close(a, b, what, rtol=RTOL):
