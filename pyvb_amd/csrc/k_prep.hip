@@ -51,6 +51,29 @@ __device__ __forceinline__ void mm(int wave, int lane, FA a_at, FB b_at, FS stor
     }
 }
 
+// The same product in two phases, for operands that live in the LDS matrix the result goes to (or that is about to be
+// reused): row tile m of the product into registers, and -- after whatever barrier the caller needs -- out of them.
+template <int NT, int KS, class FA, class FB>
+__device__ __forceinline__ void mm_acc(int m, int lane, FA a_at, FB b_at, d4 (&acc)[NT]) {
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = d4{0, 0, 0, 0};
+#pragma unroll 4
+    for (int s = 0; s < KS; ++s) {
+        const double av = a_at(16 * m + r, 4 * s + q);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = MFMA(av, b_at(4 * s + q, 16 * n + r), acc[n]);
+    }
+}
+template <int NT, class FS>
+__device__ __forceinline__ void mm_out(int m, int lane, const d4 (&acc)[NT], FS store) {
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store(16 * m + 4 * e + q, 16 * n + r, acc[n][e]);
+}
+
 // max_i sum_j |A_ij|: four threads per row (16 columns each), rows and then wavefronts combined by
 // shuffles; two barriers.  red: 4 doubles of LDS.
 __device__ static double inf_norm(const double* A, int LD, int D, int tid, double* red) {
@@ -163,6 +186,32 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     }
     __syncthreads();
     // <C^T R C> -> W;  <C^T R C> + <A^T Q A> -> P     (node.py:213-227)
+    // STAGE: <C>, then <A>, are copied into the matrix that is free at that moment and the products run out of LDS (an
+    // operand fetched from L2 inside the k loop makes a 64^3 product three times as long: profiles/r02/limits.txt section 8).
+    constexpr bool STAGE = !DENSE && KT <= DT;
+    if constexpr (STAGE) {
+        constexpr int KP = 16 * KT;
+        for (int idx = tid; idx < KP * DP; idx += PREP_THREADS) P[(idx / DP) * LD + idx % DP] = C_at(idx / DP, idx % DP);
+        __syncthreads();
+        d4 acc[DT];
+        if (wave < DT) {
+            mm_acc<DT, KS>(wave, lane, [&](int i, int k) { return P[k * LD + i] * rbar[k]; }, [&](int k, int j) { return P[k * LD + j]; }, acc);
+            mm_out<DT>(wave, lane, acc, [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += rowp[i]; W[i * LD + j] = v; } });
+        }
+        __syncthreads();
+        for (int idx = tid; idx < DP * DP; idx += PREP_THREADS) P[(idx / DP) * LD + idx % DP] = A_at(idx / DP, idx % DP);
+        __syncthreads();
+        if (wave < DT)
+            mm_acc<DT, DS>(wave, lane, [&](int i, int k) { return P[k * LD + i] * qbar[k]; }, [&](int k, int j) { return P[k * LD + j]; }, acc);
+        __syncthreads();            // every read of the staged <A> is done: P takes the result
+        if (wave < DT)
+            mm_out<DT>(wave, lane, acc, [&](int i, int j, double v) {
+                const bool in = i < D && j < D;
+                if (in && i == j) v += colp[i];
+                P[i * LD + j] = in ? W[i * LD + j] + v : 0.0;
+            });
+        __syncthreads();
+    } else {
     mm<DT, DT, KS>(wave, lane,
                    [&](int i, int k) { return DENSE ? C_at(k, i) : C_at(k, i) * rbar[k]; },
                    [&](int k, int j) { if constexpr (DENSE) return RC_at(k, j); else return C_at(k, j); },
@@ -173,6 +222,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
                    [&](int k, int j) { if constexpr (DENSE) return QA_at(k, j); else return A_at(k, j); },
                    [&](int i, int j, double v) { if (i < D && j < D) { if (i == j) v += colp[i]; P[i * LD + j] = W[i * LD + j] + v; } });
     __syncthreads();
+    }
 
     // the three posterior precisions, qprec = pprec + (m1 from Mult(C,.) + m1 from Mult(A,.))  gaussian.py:117,
     // inverted together in registers (qcov, gaussian.py:118-119)
@@ -250,6 +300,30 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
             if (i < D && j < D) P[i * LD + j] = sig[1][4 * ra + cb];
         }
     __syncthreads();
+    if constexpr (STAGE) {
+        constexpr int KP = 16 * KT;
+        // <Q><A> staged in W: F = Sigma (<Q><A>), B = Sigma (<Q><A>)^T (the expectations are symmetric)
+        for (int idx = tid; idx < DP * DP; idx += PREP_THREADS) W[(idx / DP) * LD + idx % DP] = qbar[idx / DP] * A_at(idx / DP, idx % DP);
+        __syncthreads();
+        d4 facc[DT], acc[DT], gacc[KT];
+        if (wave < DT) {
+            mm_acc<DT, DS>(wave, lane, [&](int i, int k) { return P[i * LD + k]; }, [&](int k, int j) { return W[k * LD + j]; }, facc);
+            mm_out<DT>(wave, lane, facc, [&](int i, int j, double v) { if (i < D && j < D) g[L.oFn + pos_nat(i, j, DS)] = v; });
+            mm_acc<DT, DS>(wave, lane, [&](int i, int k) { return P[i * LD + k]; }, [&](int k, int j) { return W[j * LD + k]; }, acc);
+            mm_out<DT>(wave, lane, acc, [&](int i, int j, double v) { if (i < D && j < D) g[L.oBn + pos_nat(i, j, DS)] = v; });
+        }
+        __syncthreads();
+        // <R><C> staged in W: G = Sigma (<R><C>)^T
+        for (int idx = tid; idx < KP * DP; idx += PREP_THREADS) W[(idx / DP) * LD + idx % DP] = rbar[idx / DP] * C_at(idx / DP, idx % DP);
+        __syncthreads();
+        if (wave < DT) {
+            mm_acc<KT, DS>(wave, lane, [&](int i, int k) { return P[i * LD + k]; }, [&](int k, int l) { return W[l * LD + k]; }, gacc);
+            mm_out<KT>(wave, lane, gacc, [&](int i, int l, double v) { if (i < D && l < K) g[L.oGp + pos_perm(i, l, KS)] = v; });
+        }
+        __syncthreads();
+        // F, zero padded, into W: the matrix whose powers give the forward warm-up length
+        if (wave < DT) mm_out<DT>(wave, lane, facc, [&](int i, int j, double v) { W[i * LD + j] = (i < D && j < D) ? v : 0.0; });
+    } else
     {
         // Sigma <Q><A>: multiplies the mean of X_{t-1}
         mm<DT, DT, DS>(wave, lane,
