@@ -350,11 +350,15 @@ int pyvb_lds_get_wishart_state(pyvb_lds* h, double* Q_v, double* Q_w, double* R_
     ARGCHK(h->dense, "the handle was not created with PYVB_NOISE_WISHART");
     const size_t N = h->N, D = h->D, K = h->K;
     int rc;
-    if (Q_v) HIPCHK(hipMemcpy2DAsync(Q_v, sizeof(double), h->Q_a, D * sizeof(double), sizeof(double), N, hipMemcpyDeviceToHost, h->stream));
-    if (R_v) HIPCHK(hipMemcpy2DAsync(R_v, sizeof(double), h->R_a, K * sizeof(double), sizeof(double), N, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> qa(Q_v ? N * D : 0), ra(R_v ? N * K : 0);       // qv is stored once per dimension, like the Gamma kinds' qa
+    if (Q_v && (rc = d2h(h, qa.data(), h->Q_a, N * D))) return rc;
+    if (R_v && (rc = d2h(h, ra.data(), h->R_a, N * K))) return rc;
     if ((rc = d2h(h, Q_w, h->Q_w, N * D * D))) return rc;
     if ((rc = d2h(h, R_w, h->R_w, N * K * K))) return rc;
-    return pyvb_lds_sync(h);
+    if ((rc = pyvb_lds_sync(h))) return rc;
+    for (size_t n = 0; Q_v && n < N; ++n) Q_v[n] = qa[n * D];
+    for (size_t n = 0; R_v && n < N; ++n) R_v[n] = ra[n * K];
+    return PYVB_OK;
 }
 
 int pyvb_lds_set_column_cov(pyvb_lds* h, const double* A_cov, const double* C_cov) {
@@ -364,9 +368,7 @@ int pyvb_lds_set_column_cov(pyvb_lds* h, const double* A_cov, const double* C_co
     int rc;
     if ((rc = h2d(h, h->A_cov, A_cov, N * D * D * D))) return rc;
     if ((rc = h2d(h, h->C_cov, C_cov, N * D * K * K))) return rc;
-    // keep the diagonals (what the lower bound reads) in step
-    if (A_cov) HIPCHK(hipMemcpy2DAsync(h->A_var, sizeof(double), h->A_cov, (D + 1) * sizeof(double), sizeof(double), N * D * D, hipMemcpyDeviceToDevice, h->stream));
-    if (C_cov) HIPCHK(hipMemcpy2DAsync(h->C_var, sizeof(double), h->C_cov, (K + 1) * sizeof(double), sizeof(double), N * D * K, hipMemcpyDeviceToDevice, h->stream));
+    if ((A_cov || C_cov) && (rc = launch_cov_to_colvar(h))) return rc;      // the diagonals (what the lower bound reads) follow
     HIPCHK(hipStreamSynchronize(h->stream));
     params_changed(h);
     h->resQ_valid = h->resR_valid = false;

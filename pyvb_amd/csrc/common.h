@@ -156,6 +156,7 @@ int launch_wresid(pyvb_lds* h, int which, int update);
 int launch_syy_full(pyvb_lds* h);
 int launch_elbo_dense(pyvb_lds* h);
 int launch_colvar_to_cov(pyvb_lds* h);              // A_var/C_var (diagonals) -> A_cov/C_cov
+int launch_cov_to_colvar(pyvb_lds* h);              // and back
 // k_missing.hip
 int launch_missing_init(pyvb_lds* h, const double* Yq0, const double* Yrowvar0);     // device pointers or null
 int launch_impute(pyvb_lds* h);

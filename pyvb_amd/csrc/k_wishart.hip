@@ -317,6 +317,15 @@ __global__ void __launch_bounds__(256) k_colvar_to_cov(WArgs a) {
     for (int idx = threadIdx.x; idx < rows * rows; idx += 256) cov[idx] = (idx / rows == idx % rows) ? var[idx / rows] : 0.0;
 }
 
+// ... and back: the diagonals (what the lower bound reads) of column covariances the caller supplied
+__global__ void __launch_bounds__(64) k_cov_to_colvar(WArgs a) {
+    const int WHICH = blockIdx.z, n = blockIdx.x, i = blockIdx.y, D = a.D, k = threadIdx.x;
+    const int rows = WHICH == 0 ? a.D : a.K;
+    const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + ((size_t)n * D + i) * rows * rows;
+    double* var = (WHICH == 0 ? a.A_var : a.C_var) + ((size_t)n * D + i) * rows;
+    if (k < rows) var[k] = cov[(size_t)k * rows + k];
+}
+
 __device__ static double psi_multi(double x, int D) {       // sum_{i<D} psi(x - i/2)
     double s = 0.0;
     for (int i = 0; i < D; ++i) s += digamma_pos(x - 0.5 * i);
@@ -435,6 +444,13 @@ int launch_syy_full(pyvb_lds* h) {
 int launch_colvar_to_cov(pyvb_lds* h) {
     WArgs a = make_wargs(h);
     hipLaunchKernelGGL(k_colvar_to_cov, dim3(h->N, h->D, 2), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+int launch_cov_to_colvar(pyvb_lds* h) {
+    WArgs a = make_wargs(h);
+    hipLaunchKernelGGL(k_cov_to_colvar, dim3(h->N, h->D, 2), dim3(64), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

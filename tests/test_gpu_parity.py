@@ -547,3 +547,22 @@ def test_known_matrix_entries_vs_oracle():
     C_obs[2, 1] = 3.0; C_obs[:, 3] = np.arange(K) - 2.0
     pri["A_obs"], pri["C_obs"] = A_obs, C_obs
     _stagewise(Y, st0, pri, iters=3)
+
+
+def test_wishart_column_covariances_round_trip():
+    """pyvb_lds_set_column_cov / get_column_cov / get_wishart_state: what goes in comes out, the diagonals follow."""
+    T, D, K, N = 12, 5, 3, 4
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=2)
+    _wishart_priors(pri, D, K)
+    b = _batch(Y, st0, pri)
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((N, D, D, D)); A = A @ np.swapaxes(A, -1, -2) + np.eye(D)
+    Cc = rng.standard_normal((N, D, K, K)); Cc = Cc @ np.swapaxes(Cc, -1, -2) + np.eye(K)
+    b.set_column_cov(A, Cc)
+    A2, C2 = b.get_column_cov()
+    assert np.array_equal(A, A2) and np.array_equal(Cc, C2)
+    g = b.get_state(("A_colvar", "C_colvar"))
+    assert np.array_equal(g["A_colvar"], np.einsum("nikk->nik", A)) and np.array_equal(g["C_colvar"], np.einsum("nikk->nik", Cc))
+    w = b.get_wishart_state()
+    assert np.allclose(w["Q_v"], 1e-3 + 0.5 * (T - 1)) and np.allclose(w["R_v"], 1e-3 + 0.5 * T)
+    b.close()
