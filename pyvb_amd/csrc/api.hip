@@ -762,10 +762,15 @@ int pyvb_lds_iterate(pyvb_lds* h, int niters) {
         if ((rc = join_elbo(h))) return rc;
         if ((rc = sweep(h, PYVB_BACKWARD, true))) return rc;
         if (h->dense) {
-            if ((rc = pyvb_lds_update_columns(h, 0, 0, h->D))) return rc;
-            if ((rc = pyvb_lds_update_columns(h, 1, 0, h->D))) return rc;
-            if ((rc = update_noise(h, 0))) return rc;
-            if ((rc = update_noise(h, 1))) return rc;
+            // as below: A and C are independent given the statistics, Q and R given A and C -- the pairs share launches
+            if ((rc = ensure_stats(h))) return rc;
+            if ((rc = ensure_expect(h))) return rc;
+            if ((rc = launch_cols_dense(h, 2, 0, h->D))) return rc;
+            params_changed(h);
+            if ((rc = launch_wresid(h, 2, 1))) return rc;          // both residual matrices and both qw = w0 + residual
+            h->resQ_valid = h->resR_valid = true;
+            h->expect_valid = false;
+            params_changed(h);
             if ((rc = pyvb_lds_elbo(h))) return rc;
             double* slot = h->elbo_hist + (size_t)(h->hist_count % PYVB_ELBO_HISTORY) * 8;      // same history, main stream
             if ((rc = launch_elbo_sum(h, slot, h->stream))) return rc;

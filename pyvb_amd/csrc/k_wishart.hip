@@ -114,8 +114,10 @@ __global__ void __launch_bounds__(256) k_dense_pre(WArgs a) {
     double s = 0.0;
     if (i < D) {
         const double* Si = cov + (size_t)i * rows * rows;
-        for (int k = part; k < rows; k += 4)
+        for (int k = part; k < rows; k += 4) {
+#pragma unroll 16
             for (int l = 0; l < rows; ++l) s += Si[k * rows + l] * Lb[k * WLD + l];      // both symmetric
+        }
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
@@ -208,14 +210,15 @@ __global__ void __launch_bounds__(64) k_colmean(WArgs a) {
         double r = 0.0;
         if (live) {
             r = H[(size_t)lane * D + i];
-            for (int j = 0; j < D; ++j)
-                if (j != i) r -= Mb[j * WLD + lane] * gv[j];
+#pragma unroll 8
+            for (int j = 0; j < D; ++j) r -= (j != i) ? Mb[j * WLD + lane] * gv[j] : 0.0;
         }
         rv[lane] = r;
         __syncthreads();
         double w = 0.0;
         if (live) {
             w = pp[(size_t)i * rows + lane] * pm[(size_t)lane * D + i];
+#pragma unroll 8
             for (int l = 0; l < rows; ++l) w += Lb[lane * WLD + l] * rv[l];
         }
         wv[lane] = w;
@@ -223,7 +226,8 @@ __global__ void __launch_bounds__(64) k_colmean(WArgs a) {
         if (live) {
             const double* Si = cov + (size_t)i * rows * rows;
             double mu = 0.0;
-            for (int l = 0; l < rows; ++l) mu += Si[(size_t)l * rows + lane] * wv[l];      // symmetric: read down a column
+#pragma unroll 16
+            for (int l = 0; l < rows; ++l) mu += Si[(size_t)l * rows + lane] * wv[l];      // symmetric: read down a column (16 loads in flight)
             Mb[i * WLD + lane] = mu;
         }
         __syncthreads();
@@ -253,6 +257,7 @@ __global__ void __launch_bounds__(256) k_wresid(WArgs a) {
     for (int idx = tid; idx < rows * D; idx += 256) {       // T1 = <M> G
         const int k = idx / D, j = idx % D;
         double s = 0.0;
+#pragma unroll 16
         for (int i = 0; i < D; ++i) s += Mb[k * WLD + i] * G[(size_t)i * D + j];
         T1[k * WLD + j] = s;
     }
@@ -263,7 +268,9 @@ __global__ void __launch_bounds__(256) k_wresid(WArgs a) {
     for (int idx = tid; idx < rows * rows; idx += 256) {
         const int k = idx / rows, l = idx % rows;
         double e = 0.0, hm = 0.0;
+#pragma unroll 16
         for (int j = 0; j < D; ++j) { e += T1[k * WLD + j] * Mb[l * WLD + j]; hm += H[(size_t)k * D + j] * Mb[l * WLD + j]; }
+#pragma unroll 16
         for (int i = 0; i < D; ++i) e += cov[(size_t)i * rows * rows + idx] * G[(size_t)i * D + i];
         double own;
         if (WHICH == 0) own = GC[idx] - x0[xpos(k)] * x0[xpos(l)] - S0[idx];          // sum_{t >= 1} <x x^T>
