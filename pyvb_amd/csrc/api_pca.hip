@@ -49,7 +49,7 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     h->DP = (d + 15) & ~15; h->QP = (q + 15) & ~15; h->DT = h->DP / 16; h->QT = h->QP / 16;
     h->SL = pca_stats_layout(h->DP, h->QP);
     h->world = 1;
-    long nchunk = (16384 + h->DT - 1) / h->DT;      // pass 2 runs nchunk x DT wavefronts, pass 1 nchunk x 4
+    long nchunk = (16384 + h->DT - 1) / h->DT;      // pass 2 runs nchunk workgroups of ceil(DT / 2) wavefronts, pass 1 nchunk x 4
     const long ntile = (N + 15) / 16;
     if (nchunk > ntile) nchunk = ntile;
     if (nchunk < 1) nchunk = 1;
@@ -74,7 +74,7 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     TRY(alloc_d(&h->Gz, (size_t)h->QT * (DP / 4) * 64)); TRY(alloc_d(&h->g0, QP));
     TRY(alloc_d(&h->part, (size_t)h->nchunk * (h->SL.total + h->DT)));
     TRY(alloc_d(&h->stats, h->SL.total));
-    TRY(alloc_d(&h->red2, (size_t)32 * h->SL.total));
+    TRY(alloc_d(&h->red2, (size_t)PCA_RED * h->SL.total));
     TRY(alloc_d(&h->aux, (size_t)4 * h->nchunk * QP + QP + DP));
     TRY(alloc_d(&h->elbo, 8));
     TRYHIP(hipMalloc((void**)&h->status, sizeof(int))); TRYHIP(hipMemset(h->status, 0, sizeof(int)));

@@ -7,7 +7,7 @@
 //   pass 2  [x.update() for x in Xs]     missing entries <- <W><z_n> + <Mu>, variance 1/beta, known entries
 //           pinned (gaussian.py:125-134 on a diagonal covariance), and, on the same tiles, the sums over n that
 //           the W, Mu and Beta updates and the lower bound read: sum x z^T, sum z z^T, sum x, sum z, sum |x|^2.
-// A wavefront of pass 2 owns one 16-column tile of X: the imputed tile comes out of the MFMA in accumulator
+// A wavefront of pass 2 owns two 16-column tiles of X: an imputed tile comes out of the MFMA in accumulator
 // layout (row = 4*reg + lane/16, col = lane%16), which is exactly the A-operand layout of X^T for the product
 // X^T Z, so the statistics take it straight from registers.
 // Small single-workgroup kernels do the q x q / d-vector work (W columns, Sigma_z, Mu, Beta, lower bound).
@@ -45,6 +45,8 @@ __device__ __forceinline__ size_t gz_pos(int i, int k, int DS) {
 // ---------------------------------------------------------------------------------------------------
 // pass 1: Z <- X Gz^T - g0 for a chunk of rows; partial column sums of the new Z
 // ---------------------------------------------------------------------------------------------------
+__device__ static double bsum(double v, double* red);
+
 template <int QT>
 __global__ void __launch_bounds__(256) k_pca_pass1(PcaArgs a) {
     extern __shared__ double gl[];                       // Gz^T as B operands [QT][DS][64], shared by the 4 wavefronts
@@ -92,86 +94,123 @@ __global__ void __launch_bounds__(256) k_pca_pass1(PcaArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pass 2: impute + statistics.  grid (nchunk, DT); the wavefront owns columns [16m, 16m+16) of X.
+// pass 2: impute + statistics.  One workgroup per row chunk; wavefront w owns columns [32w, 32w+32) of X as two
+// INTERLEAVED 16-column tiles -- tile p holds columns 32w + 2c + p, c = lane % 16 -- so a lane's elements of the two
+// accumulator tiles are two consecutive doubles of a row: X is read and written 16 B per lane, 256 contiguous bytes per
+// row and wavefront, a whole 2 KB row per workgroup at a time (the column tiles of a row used to be separate
+// wavefronts launched ~1000 chunks apart, 128 B per row each).  About 100 registers: four wavefronts per SIMD.
 // ---------------------------------------------------------------------------------------------------
+#define P2T 2           // tiles per wavefront
+#ifndef P2_OCC
+#define P2_OCC (QT == 1 ? 4 : 2)        // workgroups per CU the register budget is set for
+#endif
 template <int QT>
-__global__ void __launch_bounds__(64) k_pca_pass2(PcaArgs a) {
-    const int lane = threadIdx.x, c = lane & 15, qk = lane >> 4, m = blockIdx.y;
+__global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
+    const int lane = threadIdx.x & 63, wave = 4 * blockIdx.y + (threadIdx.x >> 6), c = lane & 15, qk = lane >> 4;
     const int DP = a.DP, QP = a.QP, d = a.d, q = a.q;
     constexpr int QS = 4 * QT;
     const long r0 = (long)blockIdx.x * a.chunk_rows;
     const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
-    const int dim = 16 * m + c;
-    // B operand of the prediction  pred[n][dim] = sum_i Z[n][i] W[dim][i]:  B[k = i][col = dim]
-    double wb[QS];
+    const int col0 = 16 * P2T * wave + P2T * c;         // this lane's columns
+    const bool colok = col0 < DP;                       // DP is a multiple of 16: both or none
+    // B operands of the prediction  pred[n][dim] = sum_i Z[n][i] W[dim][i]:  B[k = i][col = c <-> dim = col0 + p]
+    double wb[P2T][QS], mu[P2T];
 #pragma unroll
-    for (int s = 0; s < QS; ++s) { const int i = 4 * s + qk; wb[s] = (dim < d && i < q) ? a.W_mean[(size_t)dim * q + i] : 0.0; }
-    const double mu = dim < d ? a.Mu_mean[dim] : 0.0;
+    for (int p = 0; p < P2T; ++p) {
+        const int dim = col0 + p;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) { const int i = 4 * s + qk; wb[p][s] = (dim < d && i < q) ? a.W_mean[(size_t)dim * q + i] : 0.0; }
+        mu[p] = dim < d ? a.Mu_mean[dim] : 0.0;
+    }
     const double var_new = a.scal[PS_BETA_B] / a.scal[PS_BETA_A];          // 1 / <beta>
-    if (blockIdx.x == 0 && m == 0 && lane == 0 && a.hi_upd > a.lo_upd)       // q_ln_det of rows without any observation
+    if (blockIdx.x == 0 && wave == 0 && lane == 0 && a.hi_upd > a.lo_upd)    // q_ln_det of rows without any observation
         a.scal[PS_QLD_X] = 0.5 / (0.5 * d * log(1.0 / var_new));
-    d4 sxz[QT], szz[QT][QT];
+    d4 sxz[P2T][QT], szz[QT][QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        sxz[t] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int p = 0; p < P2T; ++p) sxz[p][t] = d4{0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < QT; ++u) szz[t][u] = d4{0, 0, 0, 0};
     }
-    double sx = 0.0, sxx = 0.0, sz[QT], sxv = 0.0, slv = 0.0;
+    double sx[P2T], sxx = 0.0, sz[QT];
+#pragma unroll
+    for (int p = 0; p < P2T; ++p) sx[p] = 0.0;
 #pragma unroll
     for (int t = 0; t < QT; ++t) sz[t] = 0.0;
-    for (long n0 = r0; n0 < r1; n0 += 16) {
-        // Z tile, A layout (row = lane%16, k = i) for the prediction ...
-        const long rowA = (n0 + c < a.N) ? n0 + c : a.N - 1;
-        double za[QS];
-#pragma unroll
-        for (int s = 0; s < QS; ++s) za[s] = a.Z[rowA * QP + 4 * s + qk];
-        // ... and B layout (k = row, col = i) for the statistics; rows past the chunk contribute nothing
-        double zb[4][QT];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const long row = n0 + 4 * s + qk;
-            const bool ok = row < r1;
-#pragma unroll
-            for (int t = 0; t < QT; ++t) { const double v = a.Z[(ok ? row : a.N - 1) * QP + 16 * t + c]; zb[s][t] = ok ? v : 0.0; }
-        }
-        d4 pred = d4{mu, mu, mu, mu};
-#pragma unroll
-        for (int s = 0; s < QS; ++s) pred = MFMA(za[s], wb[s], pred);
-        // accumulator element r: row n0 + 4r + qk, column dim
-        double xn[4];
+    // chunk-relative 32-bit offsets (a chunk of X is a few MB); rows past the chunk read its last row and count for nothing;
+    // a lane whose columns lie past DP (DP = 16 mod 32) reads column 0 and counts for nothing
+    double* const Xc = a.X + (size_t)r0 * DP;
+    const unsigned char* const Mc = a.M + (size_t)r0 * DP;
+    const double* const Zc = a.Z + (size_t)r0 * QP;
+    const unsigned nrows = (unsigned)(r1 - r0), colL = colok ? col0 : 0;
+    const unsigned lo = a.lo_upd > r0 ? (unsigned)((a.lo_upd < r1 ? a.lo_upd : r1) - r0) : 0u;     // rows [lo, hi) of the chunk are updated
+    const unsigned hi = a.hi_upd > r0 ? (unsigned)((a.hi_upd < r1 ? a.hi_upd : r1) - r0) : 0u;
+    for (unsigned n0 = 0; n0 < nrows; n0 += 16) {
+        // the rows of this lane's accumulator elements: n0 + 4r + qk
+        d2 xo[4]; unsigned mk[4], xoff[4]; bool ok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long row = n0 + 4 * r + qk;
-            const bool ok = row < r1;
-            const size_t off = (size_t)(ok ? row : a.N - 1) * DP + dim;
-            const double xo = a.X[off];
-            const bool known = a.M[off] != 0;
-            const bool upd = ok && !known && row >= a.lo_upd && row < a.hi_upd;
-            const double v = upd ? pred[r] : xo;
-            if (upd) a.X[off] = v;
-            xn[r] = ok ? v : 0.0;
-            sx += xn[r]; sxx += xn[r] * xn[r];
+            const unsigned row = n0 + 4 * r + qk;
+            ok[r] = row < nrows;
+            xoff[r] = (ok[r] ? row : nrows - 1) * DP + colL;
+            xo[r] = *reinterpret_cast<const d2*>(Xc + xoff[r]);
+            mk[r] = *reinterpret_cast<const unsigned short*>(Mc + xoff[r]);
         }
-        if (m == 0 && c == 0) {          // one lane per row: variance of the row's missing entries
+        // Z tile, A layout (row = lane%16, k = i) for the prediction ...
+        const unsigned rowA = (n0 + c < nrows) ? n0 + c : nrows - 1;
+        double za[QS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long row = n0 + 4 * r + qk;
-                if (row < r1) {
-                    const int nm = a.nmiss[row];
-                    double v = a.xvar[row];
-                    if (nm > 0 && row >= a.lo_upd && row < a.hi_upd) { v = var_new; a.xvar[row] = v; }
-                    sxv += nm * v;
-                    if (nm > 0 && nm < d) slv += nm * log(v);
-                }
-            }
-        }
-        // statistics: the imputed tile is X^T's A operand (row = dim = lane%16, k = row index = lane/16)
+        for (int s = 0; s < QS; ++s) za[s] = Zc[rowA * QP + 4 * s + qk];
+        // ... and B layout (k = row, col = i) for the statistics
+        double zb[4][QT];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t = 0; t < QT; ++t) sxz[t] = MFMA(xn[s], zb[s][t], sxz[t]);
-        if (m == 0) {
+            for (int t = 0; t < QT; ++t) { const double v = Zc[(xoff[s] - colL) / DP * QP + 16 * t + c]; zb[s][t] = ok[s] ? v : 0.0; }
+        d4 xn[P2T];                     // [p]: the tile of columns col0 + p; element r: row n0 + 4r + qk
+#pragma unroll
+        for (int p = 0; p < P2T; ++p) {
+            d4 pred = d4{mu[p], mu[p], mu[p], mu[p]};
+#pragma unroll
+            for (int s = 0; s < QS; ++s) pred = MFMA(za[s], wb[p][s], pred);
+            xn[p] = pred;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned row = n0 + 4 * r + qk;
+            const bool live = ok[r] && colok;
+            const bool rowupd = live && row >= lo && row < hi;
+            d2 v = xo[r];
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < P2T; ++p)
+                if (rowupd && ((mk[r] >> (8 * p)) & 0xffu) == 0) { v[p] = xn[p][r]; any = true; }
+            // whole rows go back, known entries with their own bits: full-line writes (a masked 8-byte store is a
+            // read-modify-write at the memory side, measured 0.3 ms slower per pass)
+#ifndef P2_GROUP
+#define P2_GROUP 2
+#endif
+            bool st = rowupd;
+            if (P2_GROUP > 0) {
+                const unsigned long long b = __ballot(any);
+                st = ((b >> (lane & ~(P2_GROUP - 1))) & ((1ull << P2_GROUP) - 1)) != 0;
+            }
+            if (st) *reinterpret_cast<d2*>(Xc + xoff[r]) = v;
+#pragma unroll
+            for (int p = 0; p < P2T; ++p) {
+                const double x = live ? v[p] : 0.0;
+                xn[p][r] = x; sx[p] += x; sxx += x * x;
+            }
+        }
+        // statistics: an imputed tile is X^T's A operand (row = its column = lane%16, k = row index = lane/16)
+#pragma unroll
+        for (int p = 0; p < P2T; ++p)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) sxz[p][t] = MFMA(xn[p][s], zb[s][t], sxz[p][t]);
+        if (wave == 0) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -182,17 +221,28 @@ __global__ void __launch_bounds__(64) k_pca_pass2(PcaArgs a) {
                 }
         }
     }
-    // partial sums of this (chunk, column tile)
+    // partial sums of this chunk; accumulator row 4r + qk of tile p is column 32w + 2(4r + qk) + p
     double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
 #pragma unroll
-    for (int t = 0; t < QT; ++t)
+    for (int p = 0; p < P2T; ++p)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) P[a.SL.oSxz + (size_t)(16 * m + 4 * r + qk) * QP + 16 * t + c] = sxz[t][r];
-    sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
-    if (qk == 0) P[a.SL.osx + dim] = sx;
+        for (int r = 0; r < 4; ++r) {
+            const int dim = 16 * P2T * wave + P2T * (4 * r + qk) + p;
+            if (dim < DP) {
+#pragma unroll
+                for (int t = 0; t < QT; ++t) P[a.SL.oSxz + (size_t)dim * QP + 16 * t + c] = sxz[p][t][r];
+            }
+        }
+#pragma unroll
+    for (int p = 0; p < P2T; ++p) {
+        double s = sx[p];
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        if (qk == 0 && colok) P[a.SL.osx + col0 + p] = s;
+    }
     sxx = wsum(sxx);
-    if (lane == 0) P[a.SL.total + m] = sxx;
-    if (m == 0) {
+    if (lane == 0) P[a.SL.total + wave] = sxx;            // DT slots, one per wavefront here, the rest zero
+    if (wave == 0 && lane >= (a.DT + P2T - 1) / P2T && lane < a.DT) P[a.SL.total + lane] = 0.0;
+    if (wave == 0) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             double s = sz[t];
@@ -203,15 +253,32 @@ __global__ void __launch_bounds__(64) k_pca_pass2(PcaArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) P[a.SL.oSzz + (size_t)(16 * t + 4 * r + qk) * QP + 16 * u + c] = szz[t][u][r];
         }
-        sxv = wsum(sxv); slv = wsum(slv);
-        if (lane == 0) { P[a.SL.osxv] = sxv; P[a.SL.oslv] = slv; }
     }
+}
+
+// the variances of the missing entries of the chunk's rows (1 / <beta> for the rows being updated) and their sums:
+// sum_n #missing_n var_n, and sum over partially observed rows of #missing_n log var_n.  One workgroup per chunk.
+__global__ void __launch_bounds__(256) k_pca_rowvar(PcaArgs a) {
+    __shared__ double red[4];
+    const long r0 = (long)blockIdx.x * a.chunk_rows;
+    const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
+    const double var_new = a.scal[PS_BETA_B] / a.scal[PS_BETA_A];
+    double sxv = 0.0, slv = 0.0;
+    for (long row = r0 + threadIdx.x; row < r1; row += 256) {
+        const int nm = a.nmiss[row];
+        double v = a.xvar[row];
+        if (nm > 0 && row >= a.lo_upd && row < a.hi_upd) { v = var_new; a.xvar[row] = v; }
+        sxv += nm * v;
+        if (nm > 0 && nm < a.d) slv += nm * log(v);
+    }
+    double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
+    sxv = bsum(sxv, red); slv = bsum(slv, red);
+    if (threadIdx.x == 0) { P[a.SL.osxv] = sxv; P[a.SL.oslv] = slv; }
 }
 
 // sum the per-chunk partials in two deterministic stages (no atomics: results must not depend on timing)
 //   what = 0: full statistics of pass 2 -> stats;  what = 1: [sum z (QP)] of pass 1 -> tail of aux
 //   stage 0: slice y of the chunks -> red2[y][idx];  stage 1: the PCA_RED slices -> destination
-#define PCA_RED 32
 __global__ void __launch_bounds__(256) k_pca_reduce(PcaArgs a, int what, int stage, double* red2) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t n = what == 1 ? (size_t)a.QP : a.SL.total;
@@ -262,25 +329,31 @@ __device__ static double digamma_pos(double x) {
     return r + log(x) - 0.5 / x - ser;
 }
 
-// <W^T W>[i][j] for independent Gaussian columns (node.py:213-227 with an isotropic child precision) -> wtw [q][q] in LDS
-__device__ static void wtw_lds(const PcaArgs& a, double* wtw) {
-    const int d = a.d, q = a.q;
+// <W^T W>[i][j] for independent Gaussian columns (node.py:213-227 with an isotropic child precision) -> wtw [q][q] in LDS.
+// <W> is staged into wst [d][q] first (one coalesced sweep instead of d dependent trips to L2 per thread) and stays there.
+__device__ static void wtw_lds(const PcaArgs& a, double* wtw, double* wst) {
+    const int d = a.d, q = a.q, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int idx = threadIdx.x; idx < d * q; idx += 256) wst[idx] = a.W_mean[idx];
+    __syncthreads();
     for (int idx = threadIdx.x; idx < q * q; idx += 256) {
         const int i = idx / q, j = idx % q;
         double s = 0.0;
 #pragma unroll 8
-        for (int k = 0; k < d; ++k) s += a.W_mean[(size_t)k * q + i] * a.W_mean[(size_t)k * q + j];
-        if (i == j) {
-#pragma unroll 8
-            for (int k = 0; k < d; ++k) s += a.W_var[(size_t)i * d + k];
-        }
+        for (int k = 0; k < d; ++k) s += wst[k * q + i] * wst[k * q + j];
         wtw[idx] = s;
+    }
+    __syncthreads();
+    for (int i = wave; i < q; i += 4) {                 // + sum_k var(W[k][i]) on the diagonal, a wavefront per column
+        double s = 0.0;
+        for (int k = lane; k < d; k += 64) s += a.W_var[(size_t)i * d + k];
+        s = wsum(s);
+        if (lane == 0) wtw[i * q + i] += s;
     }
     __syncthreads();
 }
 
 // residual  sum_n tr[<x x^T> + <m m^T> - 2 <x><m>^T],  m = W z_n + Mu   (node.py:121-129, :260-271); all threads get it
-__device__ static double residual(const PcaArgs& a, const double* wtw, double* red) {
+__device__ static double residual(const PcaArgs& a, const double* wtw, const double* wst, double* red) {
     const int d = a.d, q = a.q, QP = a.QP;
     const double* S = a.stats;
     const double N = (double)a.N_total;
@@ -293,7 +366,7 @@ __device__ static double residual(const PcaArgs& a, const double* wtw, double* r
     for (int k = threadIdx.x; k < d; k += 256) {
         const double mu = a.Mu_mean[k];
         double wsz = 0.0, xzw = 0.0;
-        for (int i = 0; i < q; ++i) { const double w = a.W_mean[(size_t)k * q + i]; wsz += w * S[a.SL.osz + i]; xzw += w * S[a.SL.oSxz + (size_t)k * QP + i]; }
+        for (int i = 0; i < q; ++i) { const double w = wst[k * q + i]; wsz += w * S[a.SL.osz + i]; xzw += w * S[a.SL.oSxz + (size_t)k * QP + i]; }
         mm += N * (mu * mu + a.Mu_var[k]) + 2.0 * wsz * mu;
         cross += xzw + S[a.SL.osx + k] * mu;
     }
@@ -302,7 +375,7 @@ __device__ static double residual(const PcaArgs& a, const double* wtw, double* r
 }
 
 __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
-    __shared__ double sm[64 * 64 + 64 * 64 + 64], red[4];
+    __shared__ double sm[64 * 64 + 64 * 64 + 64], red[4], wst[256 * 32];     // wst: <W> [d][q] staged by wtw_lds
     const int tid = threadIdx.x, d = a.d, q = a.q, QP = a.QP, DP = a.DP;
     const double* S = a.stats;
     const double beta = a.scal[PS_BETA_A] / a.scal[PS_BETA_B];
@@ -345,7 +418,7 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
     } else if (a.mode == PCA_PREPZ) {
         // posterior of the Z_n: precision I + beta <W^T W>, shared by all n; Gz = beta Sigma_z <W>^T
         double* P = sm; double* Sg = sm + 64 * 64;
-        wtw_lds(a, Sg);
+        wtw_lds(a, Sg, wst);
         for (int idx = tid; idx < q * q; idx += 256) P[idx] = ((idx / q == idx % q) ? 1.0 : 0.0) + beta * Sg[idx];
         __syncthreads();
         // Gauss-Jordan inverse in place (SPD, no pivoting); log det from the pivots
@@ -377,12 +450,15 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         for (int idx = tid; idx < q * d; idx += 256) {
             const int i = idx / d, k = idx % d;
             double s = 0.0;
-            for (int j = 0; j < q; ++j) s += P[i * q + j] * a.W_mean[(size_t)k * q + j];
+            for (int j = 0; j < q; ++j) s += P[i * q + j] * wst[k * q + j];
             a.Gz[gz_pos(i, k, DS)] = beta * s;
         }
-        if (tid < q) {                                      // t_j = sum_k W[k][j] <Mu>_k
+        double* mus = Sg + 64;                              // <Mu> staged; Sg[0..q) then holds t_j = sum_k W[k][j] <Mu>_k
+        if (tid < d) mus[tid] = a.Mu_mean[tid];
+        __syncthreads();
+        if (tid < q) {
             double s = 0.0;
-            for (int k = 0; k < d; ++k) s += a.W_mean[(size_t)k * q + tid] * a.Mu_mean[k];
+            for (int k = 0; k < d; ++k) s += wst[k * q + tid] * mus[k];
             Sg[tid] = s;
         }
         __syncthreads();
@@ -425,16 +501,16 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         if (tid == 0) a.scal[PS_QLD_MU] = 0.5 / lp;
     } else if (a.mode == PCA_BETA) {
         // Beta.update(): Gamma, traces (nodes_todo.py:130-138)
-        wtw_lds(a, sm);
-        const double res = residual(a, sm, red);
+        wtw_lds(a, sm, wst);
+        const double res = residual(a, sm, wst, red);
         if (tid == 0) { a.scal[PS_BETA_B] = a.scal[PS_BETA_B0] + 0.5 * res; a.scal[PS_RES] = res; }
     } else if (a.mode == PCA_ELBO) {
         double res;
         if (a.res_cached) {
             res = a.scal[PS_RES];
         } else {
-            wtw_lds(a, sm);
-            res = residual(a, sm, red);
+            wtw_lds(a, sm, wst);
+            res = residual(a, sm, wst, red);
         }
         const double qa = a.scal[PS_BETA_A], qb = a.scal[PS_BETA_B];
         const double lnd_beta = d * (log(qa) - log(qb));                  // Gamma.pass_down_lndet (quirk Q2)
@@ -511,8 +587,11 @@ int pca_launch_pass1(pyvb_pca* h) {
 
 int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
     PcaArgs a = pca_args(h); a.lo_upd = lo_upd; a.hi_upd = hi_upd;
-    if (h->QT == 1) hipLaunchKernelGGL(k_pca_pass2<1>, dim3(h->nchunk, h->DT), dim3(64), 0, h->stream, a);
-    else hipLaunchKernelGGL(k_pca_pass2<2>, dim3(h->nchunk, h->DT), dim3(64), 0, h->stream, a);
+    const unsigned nw = (h->DT + P2T - 1) / P2T;          // wavefronts per row chunk: 32 columns each, four to a workgroup
+    const dim3 grid(h->nchunk, (nw + 3) / 4), block(64 * (nw < 4 ? nw : 4));
+    if (h->QT == 1) hipLaunchKernelGGL(k_pca_pass2<1>, grid, block, 0, h->stream, a);
+    else hipLaunchKernelGGL(k_pca_pass2<2>, grid, block, 0, h->stream, a);
+    hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

@@ -20,6 +20,8 @@ static inline PcaStatsLayout pca_stats_layout(int DP, int QP) {
     return L;
 }
 
+#define PCA_RED 128     // slices of the chunk partials summed in parallel (stage 0 of k_pca_reduce)
+
 // device scalars
 enum { PS_BETA_A = 0, PS_BETA_B, PS_QLD_Z, PS_QLD_X, PS_QLD_MU, PS_BETA_A0, PS_BETA_B0, PS_RES, PS_COUNT = 16 };   // PS_RES: the residual of the last Beta update (see res_valid)
 
@@ -37,7 +39,7 @@ struct pyvb_pca {
     double *part; int nchunk; long chunk_rows;   // [nchunk][DT+1][stats.total] partial statistics
     double *stats;                       // [stats.total] reduced (global after the all-reduce)
     double *aux;                         // [nchunk][QP] pass-1 partials, then [QP + DP]: new sum z | delta of sum x
-    double *red2;                        // [32][stats.total] second-stage partials of the reductions
+    double *red2;                        // [PCA_RED][stats.total] second-stage partials of the reductions
     double *elbo;                        // [5]
     int *status;
     PcaStatsLayout SL;
