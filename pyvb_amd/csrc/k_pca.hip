@@ -148,12 +148,13 @@ __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
     const unsigned hi = a.hi_upd > r0 ? (unsigned)((a.hi_upd < r1 ? a.hi_upd : r1) - r0) : 0u;
     for (unsigned n0 = 0; n0 < nrows; n0 += 16) {
         // the rows of this lane's accumulator elements: n0 + 4r + qk
-        d2 xo[4]; unsigned mk[4], xoff[4]; bool ok[4];
+        d2 xo[4]; unsigned mk[4], xoff[4], rowc[4]; bool ok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const unsigned row = n0 + 4 * r + qk;
             ok[r] = row < nrows;
-            xoff[r] = (ok[r] ? row : nrows - 1) * DP + colL;
+            rowc[r] = ok[r] ? row : nrows - 1;
+            xoff[r] = rowc[r] * DP + colL;
             xo[r] = *reinterpret_cast<const d2*>(Xc + xoff[r]);
             mk[r] = *reinterpret_cast<const unsigned short*>(Mc + xoff[r]);
         }
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t = 0; t < QT; ++t) { const double v = Zc[(xoff[s] - colL) / DP * QP + 16 * t + c]; zb[s][t] = ok[s] ? v : 0.0; }
+            for (int t = 0; t < QT; ++t) { const double v = Zc[rowc[s] * QP + 16 * t + c]; zb[s][t] = ok[s] ? v : 0.0; }
         d4 xn[P2T];                     // [p]: the tile of columns col0 + p; element r: row n0 + 4r + qk
 #pragma unroll
         for (int p = 0; p < P2T; ++p) {

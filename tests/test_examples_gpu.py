@@ -26,3 +26,10 @@ def test_pca_example():
     out = _run("pca_missing_data.py", "300", "30")
     m = re.search(r"rms error of the imputed entries: ([0-9.e+-]+)\s+\(spread of the data: ([0-9.e+-]+)", out)
     assert m and float(m.group(1)) < 0.5 * float(m.group(2)), out
+
+
+def test_lds_knowns_example():
+    out = _run("lds_knowns_in_a.py", "200", "30")
+    assert "known row kept exactly: True" in out, out
+    m = re.search(r"rms of y - <C><x> : ([0-9.e+-]+)\s+rms of y : ([0-9.e+-]+)", out)
+    assert m and float(m.group(1)) < 0.5 * float(m.group(2)), out
