@@ -214,7 +214,9 @@ int pyvb_pca_comm_init(pyvb_pca* h, const char id[128], int rank, int world);
  *   Gamma.* :125-157, DiagonalGamma.* :183-204, Wishart.* :224-234, Constant.* node.py:304-311
  * -- is a TAPE of small dense operations on arena offsets (records of 8 int32: opcode, dst, a, b, m, n, p, flags; the
  * opcodes are documented in pyvb_amd/csrc/k_tape.hip and mirrored by pyvb_amd/generic.py), interpreted by one workgroup
- * per launch.  Tapes are uploaded once and replayed (the graph is static). */
+ * per launch.  Tapes are uploaded once and replayed (the graph is static).  pyvb_graph_tape_create checks every extent a
+ * record touches against the arena (PYVB_E_ARG names the record); gather / scatter indices are data: the kernel skips one
+ * that points outside and the next pyvb_graph_sync / pyvb_graph_read returns PYVB_E_ARG. */
 typedef struct pyvb_graph pyvb_graph;
 int pyvb_graph_create(pyvb_graph** out, int device, size_t arena_doubles);
 int pyvb_graph_destroy(pyvb_graph* g);

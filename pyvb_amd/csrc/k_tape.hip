@@ -20,12 +20,15 @@ enum {
     T_CHOLINV = 8,    // dst[m x m] = inverse of the s.p.d. a[m x m]; arena[b] = 0.5 / sum log diag chol (quirk Q1), arena[b+1] = sum log diag chol; p0 = scratch (2 m^2)
     T_DOT = 9,        // dst[0] (+)= sum_ij a_ij b_ij (m x n); flags 4: accumulate
     T_UNARY = 10,     // dst = f(a) elementwise, m x n; flags: 0 log, 1 digamma, 2 lgamma, 3 reciprocal, 4 negate, 5 exp
-    T_GATHER = 11,    // dst[i*n + j] = a[r_i * p0 + c_j], r = (int)arena[b + i], c = (int)arena[p1 + j]
-    T_SCATTER = 12,   // dst[r_i * p0 + c_j] (+)= a[i*n + j]  (flags 4: accumulate)
+    T_GATHER = 11,    // dst[i*n + j] = a[r_i * p + c_j], r = (int)arena[b + i], c = (int)arena[flags + j]
+    T_SCATTER = 12,   // dst[r_i * p + c_j] (+)= a[i*n + j], c = (int)arena[(flags & ~T_ACC) + j]; flags & T_ACC: accumulate
     T_MUL = 13,       // dst = a .* b elementwise, m x n
 };
 
-struct TapeArgs { double* arena; const int* ops; int nops; int* status; };
+#define T_ACC 0x40000000
+// record layout: o[0] opcode, o[1] dst, o[2] a, o[3] b (or a leading dimension / scalar offset), o[4] m, o[5] n, o[6] p, o[7] flags
+
+struct TapeArgs { double* arena; size_t arena_n; const int* ops; int nops; int* status; };
 
 #define TAPE_THREADS 256
 
@@ -151,14 +154,18 @@ __global__ void __launch_bounds__(TAPE_THREADS) k_tape(TapeArgs t) {
                 dst[idx] = y;
             }
             break;
-        case T_GATHER:
-            for (int idx = tid; idx < m * n; idx += TAPE_THREADS)
-                dst[idx] = a[(int)A[o[3] + idx / n] * o[6] + (int)A[flags + idx % n]];
+        case T_GATHER:          // the indices are data: checked here (status bit 1), everything else in pyvb_graph_tape_create
+            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) {
+                const long pos = (long)o[2] + (long)A[o[3] + idx / n] * o[6] + (long)A[flags + idx % n];
+                if (pos < 0 || (size_t)pos >= t.arena_n) { atomicOr(t.status, 2); continue; }
+                dst[idx] = A[pos];
+            }
             break;
         case T_SCATTER:
             for (int idx = tid; idx < m * n; idx += TAPE_THREADS) {
-                double* p = dst + (int)A[o[3] + idx / n] * o[6] + (int)A[(flags & ~0x40000000) + idx % n];
-                *p = (flags & 0x40000000) ? *p + a[idx] : a[idx];
+                const long pos = (long)o[1] + (long)A[o[3] + idx / n] * o[6] + (long)A[(flags & ~T_ACC) + idx % n];
+                if (pos < 0 || (size_t)pos >= t.arena_n) { atomicOr(t.status, 2); continue; }
+                A[pos] = (flags & T_ACC) ? A[pos] + a[idx] : a[idx];
             }
             break;
         case T_MUL:
@@ -227,8 +234,9 @@ int pyvb_graph_sync(pyvb_graph* g) {
     int st = 0;
     HIPCHK(hipMemcpy(&st, g->status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) {
-        pyvb_set_error("a posterior precision was not positive definite (numpy.linalg.LinAlgError in the reference)");
         HIPCHK(hipMemset(g->status, 0, sizeof(int)));
+        if (st & 2) { pyvb_set_error("a gather / scatter index of a tape pointed outside the arena (skipped)"); return PYVB_E_ARG; }
+        pyvb_set_error("a posterior precision was not positive definite (numpy.linalg.LinAlgError in the reference)");
         return PYVB_E_LINALG;
     }
     return PYVB_OK;
@@ -241,17 +249,45 @@ int pyvb_graph_read(pyvb_graph* g, size_t offset, double* dst, size_t n) {
     return pyvb_graph_sync(g);
 }
 
-/* A tape: nops records of 8 int32 (opcode, dst, a, b, m, n, p, flags; see the enum at the top of k_tape.hip).  Offsets are
- * checked against the arena here, once, so the kernel does not have to. */
+// does [off, off + len) lie inside the arena (len == 0: nothing is touched)
+static bool tape_fits(const pyvb_graph* g, long off, size_t len) { return len == 0 || (off >= 0 && (size_t)off + len <= g->arena_n); }
+static size_t tape_span(int rows, int cols, int ld) { return rows > 0 && cols > 0 ? (size_t)(rows - 1) * (size_t)ld + cols : 0; }
+
+// every extent a record touches, per opcode (the layouts of the enum at the top); gather / scatter indices are data and are
+// checked by the kernel
+static bool tape_record_ok(const pyvb_graph* g, const int* o) {
+    const int op = o[0], m = o[4], n = o[5], p = o[6], flags = o[7];
+    const size_t mn = (size_t)m * n, mm = (size_t)m * m;
+    if (m < 0 || n < 0) return false;
+    switch (op) {
+    case T_NOP: return true;
+    case T_COPY2D: return o[3] >= n && p >= n && tape_fits(g, o[1], tape_span(m, n, o[3])) && tape_fits(g, o[2], tape_span(m, n, p));
+    case T_FILL: return o[3] >= n && tape_fits(g, o[1], tape_span(m, n, o[3]));
+    case T_AXPBY: return tape_fits(g, o[1], mn) && tape_fits(g, o[2], mn) && tape_fits(g, p, 1) && (o[3] < 0 || (tape_fits(g, o[3], mn) && tape_fits(g, flags, 1)));
+    case T_GEMM: return p >= 0 && tape_fits(g, o[1], mn) && tape_fits(g, o[2], (size_t)m * p) && tape_fits(g, o[3], (size_t)p * n);
+    case T_SCALE: return tape_fits(g, o[1], mn) && tape_fits(g, o[2], mn) && tape_fits(g, o[3], 1);
+    case T_TRACE: return tape_fits(g, o[1], 1) && tape_fits(g, o[2], mm);
+    case T_DOT: return tape_fits(g, o[1], 1) && tape_fits(g, o[2], mn) && tape_fits(g, o[3], mn);
+    case T_DIAG: return (flags & 1) ? (tape_fits(g, o[1], mm) && tape_fits(g, o[2], m)) : (tape_fits(g, o[1], m) && tape_fits(g, o[2], mm));
+    case T_CHOLINV: return tape_fits(g, o[1], mm) && tape_fits(g, o[2], mm) && tape_fits(g, o[3], 2) && tape_fits(g, p, 2 * mm);
+    case T_UNARY: return flags >= 0 && flags <= 5 && tape_fits(g, o[1], mn) && tape_fits(g, o[2], mn);
+    case T_GATHER: return p >= 0 && tape_fits(g, o[1], mn) && tape_fits(g, o[2], 1) && tape_fits(g, o[3], m) && tape_fits(g, flags, n);
+    case T_SCATTER: return p >= 0 && tape_fits(g, o[1], 1) && tape_fits(g, o[2], mn) && tape_fits(g, o[3], m) && tape_fits(g, flags & ~T_ACC, n);
+    case T_MUL: return tape_fits(g, o[1], mn) && tape_fits(g, o[2], mn) && tape_fits(g, o[3], mn);
+    default: return false;
+    }
+}
+
+/* A tape: nops records of 8 int32 (opcode, dst, a, b, m, n, p, flags; see the enum at the top of k_tape.hip).  Every extent a
+ * record touches is checked against the arena here, once, so the kernel does not have to. */
 int pyvb_graph_tape_create(pyvb_graph* g, const int* ops, int nops, int* tape_id) {
     ARGCHK(g && ops && nops > 0 && tape_id, "bad arguments");
     HIPCHK(hipSetDevice(g->device));
     for (int i = 0; i < nops; ++i) {
-        const int* o = ops + 8 * i;
-        ARGCHK(o[0] >= T_NOP && o[0] <= T_MUL, "unknown opcode in tape");
-        ARGCHK(o[1] >= 0 && (size_t)o[1] < g->arena_n && o[2] >= 0 && (size_t)o[2] < g->arena_n && (o[3] < 0 || (size_t)o[3] < g->arena_n || o[0] == T_COPY2D || o[0] == T_FILL),
-               "tape operand outside the arena");
-        ARGCHK(o[4] >= 0 && o[5] >= 0, "negative dimension in tape");
+        if (!tape_record_ok(g, ops + 8 * i)) {
+            pyvb_set_error("tape record %d (opcode %d) is malformed or touches memory outside the arena", i, ops[8 * i]);
+            return PYVB_E_ARG;
+        }
     }
     int* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, (size_t)nops * 8 * sizeof(int)));
@@ -265,7 +301,7 @@ int pyvb_graph_tape_create(pyvb_graph* g, const int* ops, int nops, int* tape_id
 int pyvb_graph_tape_run(pyvb_graph* g, int tape_id) {
     ARGCHK(g && tape_id >= 0 && tape_id < (int)g->tapes.size() && g->tapes[tape_id], "no such tape");
     HIPCHK(hipSetDevice(g->device));
-    TapeArgs t; t.arena = g->arena; t.ops = g->tapes[tape_id]; t.nops = g->tape_len[tape_id]; t.status = g->status;
+    TapeArgs t; t.arena = g->arena; t.arena_n = g->arena_n; t.ops = g->tapes[tape_id]; t.nops = g->tape_len[tape_id]; t.status = g->status;
     hipLaunchKernelGGL(k_tape, dim3(1), dim3(TAPE_THREADS), 0, g->stream, t);
     HIPCHK(hipGetLastError());
     return PYVB_OK;

@@ -94,6 +94,37 @@ def test_every_opcode_against_the_numpy_interpreter():
     _close(got[inv.off:inv.off + 81].reshape(9, 9), np.linalg.inv(S), "inverse", 1e-11)
 
 
+def test_malformed_tapes_are_refused_and_bad_indices_skipped():
+    """pyvb_graph_tape_create checks every extent a record touches against the arena; gather indices are data and are
+    checked by the kernel (error reported at the next sync, nothing read or written outside)."""
+    from pyvb_amd import _capi, generic
+    ex = generic.DeviceExecutor(64)
+    G = generic
+    bad = [
+        [G.T_GEMM, 0, 16, 32, 4, 4, 4, 0],          # b = 32..47 fine, a = 16..31 fine, dst fine -> but k * n beyond: see next
+        [G.T_GEMM, 56, 0, 16, 4, 4, 4, 0],          # dst 56..71 leaves the arena of 64
+        [G.T_COPY2D, 0, 8, 2, 3, 4, 4, 0],          # leading dimension of dst (2) smaller than n (4)
+        [G.T_CHOLINV, 0, 16, 32, 4, 0, 40, 0],      # scratch 40 .. 40 + 2 * 16 leaves the arena
+        [G.T_UNARY, 0, 8, 0, 2, 2, 0, 9],           # no such function
+        [99, 0, 0, 0, 1, 1, 0, 0],                  # no such opcode
+        [G.T_AXPBY, 0, 8, -1, 70, 1, 1, 0],         # 70 elements
+    ]
+    ex.tape([bad[0]])                                # the first one is well formed
+    for rec in bad[1:]:
+        with pytest.raises(_capi.PyvbHipError):
+            ex.tape([rec])
+    # gather with a row index that points outside: rows at 40, cols at 44
+    ex.write(0, np.arange(16.0))
+    ex.write(40, np.array([1.0, 1e6])); ex.write(44, np.array([0.0, 2.0]))
+    ex.write(48, np.full(4, -7.0))
+    t = ex.tape([[G.T_GATHER, 48, 0, 40, 2, 2, 4, 44]])
+    ex.run(t)
+    with pytest.raises(_capi.PyvbHipError):
+        ex.sync()
+    np.testing.assert_array_equal(ex.read(48, 4), [4.0, 6.0, -7.0, -7.0])    # the valid row gathered, the other left alone
+    ex.close()
+
+
 def test_not_positive_definite_raises_linalgerror():
     from pyvb_amd import nodes
     mu = nodes.Gaussian(2, np.zeros((2, 1)), -np.eye(2))
