@@ -169,6 +169,12 @@ int pyvb_lds_set_time_split(pyvb_lds* h, int W);
 int pyvb_comm_unique_id(char id[128]);
 int pyvb_lds_comm_init(pyvb_lds* h, const char id[128], int rank, int world);
 int pyvb_lds_comm_destroy(pyvb_lds* h);
+/* The same exchange through the caller's own transport instead of RCCL: fn sums buf[0..count) over all ranks in place
+ * (host memory, blocking, every rank calls it in the same order) and returns 0.  A rehearsal transport -- several ranks
+ * on ONE GPU, where RCCL refuses duplicate devices, or hosts without a working RCCL: every collective then costs a
+ * device-host round trip and a stream synchronisation, so it is never what a scaling number should be measured with. */
+typedef int (*pyvb_host_allreduce_fn)(double* buf, size_t count, void* user);
+int pyvb_lds_comm_init_host(pyvb_lds* h, pyvb_host_allreduce_fn fn, void* user, int rank, int world);
 
 /* ------------------------------------------------------------------------------------------------
  * VB-PCA with missing data: the graph of examples/PCA_missing_data.py:31-42 --
@@ -205,6 +211,7 @@ int pyvb_pca_elbo(pyvb_pca* h, double parts[5]);
 int pyvb_pca_iterate(pyvb_pca* h, int niters);
 int pyvb_pca_sync(pyvb_pca* h);
 int pyvb_pca_comm_init(pyvb_pca* h, const char id[128], int rank, int world);
+int pyvb_pca_comm_init_host(pyvb_pca* h, pyvb_host_allreduce_fn fn, void* user, int rank, int world);
 
 /* ------------------------------------------------------------------------------------------------
  * Generic graphs, node by node (network.py:40-56 over arbitrary node lists; src/tests.py:9-202): every posterior,

@@ -20,6 +20,8 @@ K_PREP, K_SWEEP_FWD, K_STATS, K_PARAMS, K_STEP, K_SWEEP_BWD, K_ELBO = range(7)
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
 _h = ctypes.c_void_p
+# include/pyvb_hip.h: pyvb_host_allreduce_fn -- int (*)(double* buf, size_t count, void* user)
+HOST_ALLREDUCE = ctypes.CFUNCTYPE(ctypes.c_int, _dp, ctypes.c_size_t, ctypes.c_void_p)
 
 # name -> (restype, argtypes): every symbol include/pyvb_hip.h declares
 SIGNATURES = {
@@ -67,6 +69,7 @@ SIGNATURES = {
     "pyvb_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "pyvb_lds_comm_init": (ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "pyvb_lds_comm_destroy": (ctypes.c_int, [_h]),
+    "pyvb_lds_comm_init_host": (ctypes.c_int, [_h, HOST_ALLREDUCE, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "pyvb_graph_create": (ctypes.c_int, [ctypes.POINTER(_h), ctypes.c_int, ctypes.c_size_t]),
     "pyvb_graph_destroy": (ctypes.c_int, [_h]),
     "pyvb_graph_write": (ctypes.c_int, [_h, ctypes.c_size_t, _dp, ctypes.c_size_t]),
@@ -90,6 +93,7 @@ SIGNATURES = {
     "pyvb_pca_iterate": (ctypes.c_int, [_h, ctypes.c_int]),
     "pyvb_pca_sync": (ctypes.c_int, [_h]),
     "pyvb_pca_comm_init": (ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    "pyvb_pca_comm_init_host": (ctypes.c_int, [_h, HOST_ALLREDUCE, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
 }
 
 

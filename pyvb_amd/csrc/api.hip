@@ -888,18 +888,51 @@ int pyvb_comm_unique_id(char id[128]) {
 }  // extern "C"
 
 // shared with the PCA path (api_pca.hip)
-int pyvb_comm_create(void** comm, const char id[128], int rank, int world) {
+int pyvb_comm_create(pyvb_comm** comm, const char id[128], int rank, int world) {
     ARGCHK(comm && id && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+    ARGCHK(!*comm, "a communicator is attached already");
     int rc = load_rccl();
     if (rc) return rc;
     nccl_uid u;
     memcpy(u.internal, id, 128);
-    NCCLCHK(g_nccl.initrank(comm, world, u, rank));
+    void* nc = nullptr;
+    NCCLCHK(g_nccl.initrank(&nc, world, u, rank));
+    pyvb_comm* c = new pyvb_comm();
+    c->nccl = nc; c->fn = nullptr; c->user = nullptr; c->host = nullptr; c->cap = 0;
+    *comm = c;
     return PYVB_OK;
 }
-void pyvb_comm_free(void* comm) { if (comm && g_nccl.destroy) g_nccl.destroy(comm); }
-int pyvb_allreduce_f64(void* comm, double* buf, size_t count, hipStream_t stream) {
-    NCCLCHK(g_nccl.allreduce(buf, buf, count, 8, 0, comm, stream));     // ncclDouble = 8, ncclSum = 0
+int pyvb_comm_create_host(pyvb_comm** comm, pyvb_host_allreduce_fn fn, void* user) {
+    ARGCHK(comm && fn, "bad communicator arguments");
+    pyvb_comm* c = new pyvb_comm();
+    c->nccl = nullptr; c->fn = fn; c->user = user; c->host = nullptr; c->cap = 0;
+    *comm = c;
+    return PYVB_OK;
+}
+void pyvb_comm_free(pyvb_comm* c) {
+    if (!c) return;
+    if (c->nccl && g_nccl.destroy) g_nccl.destroy(c->nccl);
+    if (c->host) (void)hipHostFree(c->host);
+    delete c;
+}
+int pyvb_allreduce_f64(pyvb_comm* c, double* buf, size_t count, hipStream_t stream) {
+    if (c->nccl) {
+        NCCLCHK(g_nccl.allreduce(buf, buf, count, 8, 0, c->nccl, stream));     // ncclDouble = 8, ncclSum = 0
+        return PYVB_OK;
+    }
+    // host transport: device -> pinned host, the caller's all-reduce (blocking, in place), back.  The stream waits for it.
+    if (c->cap < count) {
+        if (c->host) (void)hipHostFree(c->host);
+        c->host = nullptr; c->cap = 0;
+        HIPCHK(hipHostMalloc((void**)&c->host, count * sizeof(double), hipHostMallocDefault));
+        c->cap = count;
+    }
+    HIPCHK(hipMemcpyAsync(c->host, buf, count * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    const int r = c->fn(c->host, count, c->user);
+    if (r != 0) { pyvb_set_error("the host all-reduce callback failed (%d)", r); return PYVB_E_RCCL; }
+    HIPCHK(hipMemcpyAsync(buf, c->host, count * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));          // the staging buffer is reused by the next call
     return PYVB_OK;
 }
 
@@ -907,18 +940,24 @@ extern "C" {
 
 int pyvb_lds_comm_init(pyvb_lds* h, const char id[128], int rank, int world) {
     ENTER(h);
-    ARGCHK(id && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
-    int rc = load_rccl();
+    int rc = pyvb_comm_create(&h->comm, id, rank, world);
     if (rc) return rc;
-    nccl_uid u;
-    memcpy(u.internal, id, 128);
-    NCCLCHK(g_nccl.initrank(&h->comm, world, u, rank));
+    h->rank = rank; h->world = world;
+    return PYVB_OK;
+}
+
+int pyvb_lds_comm_init_host(pyvb_lds* h, pyvb_host_allreduce_fn fn, void* user, int rank, int world) {
+    ENTER(h);
+    ARGCHK(fn && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+    ARGCHK(!h->comm, "a communicator is attached already");
+    int rc = pyvb_comm_create_host(&h->comm, fn, user);
+    if (rc) return rc;
     h->rank = rank; h->world = world;
     return PYVB_OK;
 }
 
 int pyvb_lds_comm_destroy(pyvb_lds* h) {
-    if (h && h->comm && g_nccl.destroy) { g_nccl.destroy(h->comm); h->comm = nullptr; h->world = 1; }
+    if (h && h->comm) { pyvb_comm_free(h->comm); h->comm = nullptr; h->world = 1; }
     return PYVB_OK;
 }
 
@@ -927,8 +966,7 @@ int pyvb_lds_elbo_total(pyvb_lds* h, double out[6]) {
     ARGCHK(out, "out is NULL");
     int rc = launch_elbo_sum(h);
     if (rc) return rc;
-    if (h->comm)   // ncclDouble = 8, ncclSum = 0
-        NCCLCHK(g_nccl.allreduce(h->elbo_sum, h->elbo_sum, 6, 8, 0, h->comm, h->stream));
+    if (h->comm && (rc = pyvb_allreduce_f64(h->comm, h->elbo_sum, 6, h->stream))) return rc;
     if ((rc = d2h(h, out, h->elbo_sum, 6))) return rc;
     return pyvb_lds_sync(h);
 }

@@ -9,9 +9,6 @@
 #define ARGCHK(cond, msg) do { if (!(cond)) { pyvb_set_error("%s", msg); return PYVB_E_ARG; } } while (0)
 #define ENTER(h) do { ARGCHK(h, "handle is NULL"); HIPCHK(hipSetDevice((h)->device)); } while (0)
 
-int pyvb_allreduce_f64(void* comm, double* buf, size_t count, hipStream_t stream);   // api.hip (RCCL)
-int pyvb_comm_create(void** comm, const char id[128], int rank, int world);
-void pyvb_comm_free(void* comm);
 
 static int alloc_d(double** p, size_t n) {
     HIPCHK(hipMalloc((void**)p, n * sizeof(double)));
@@ -337,6 +334,17 @@ int pyvb_pca_comm_init(pyvb_pca* h, const char id[128], int rank, int world) {
     ARGCHK(world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
     ARGCHK((rank == 0) == (h->row_offset == 0), "rows shard contiguously in rank order: rank 0, and only rank 0, holds global row 0");
     int rc = pyvb_comm_create(&h->comm, id, rank, world);
+    if (rc) return rc;
+    h->rank = rank; h->world = world;
+    return PYVB_OK;
+}
+
+int pyvb_pca_comm_init_host(pyvb_pca* h, pyvb_host_allreduce_fn fn, void* user, int rank, int world) {
+    ENTER(h);
+    ARGCHK(fn && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+    ARGCHK((rank == 0) == (h->row_offset == 0), "rows shard contiguously in rank order: rank 0, and only rank 0, holds global row 0");
+    ARGCHK(!h->comm, "a communicator is attached already");
+    int rc = pyvb_comm_create_host(&h->comm, fn, user);
     if (rc) return rc;
     h->rank = rank; h->world = world;
     return PYVB_OK;

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include "../../include/pyvb_hip.h"
 
+struct pyvb_comm;
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -111,7 +112,7 @@ struct pyvb_lds {
     bool mixed_cov;                         // the X_t hold covariances of different parameter generations
     bool classes_valid;                     // Sigma / qld_x describe the X_t (after the first complete sweep, or set by the caller)
     bool timing; KernelTimer timers[PYVB_K_COUNT]; int timing_errors;
-    void* comm; int rank, world;
+    pyvb_comm* comm; int rank, world;
     // ---- Wishart noise precisions (nodes_todo.py:205-234): dense expectations, dense column covariances
     bool dense;                     // noise == PYVB_NOISE_WISHART
     double *Q_w, *R_w;              // [N][D][D], [N][K][K] posterior qw as the reference stores it (qv is in Q_a / R_a)
@@ -162,10 +163,17 @@ int launch_missing_init(pyvb_lds* h, const double* Yq0, const double* Yrowvar0);
 int launch_impute(pyvb_lds* h);
 int launch_syy_missing(pyvb_lds* h);
 
-// RCCL, shared by the LDS and the PCA path (api.hip)
-int pyvb_comm_create(void** comm, const char id[128], int rank, int world);
-void pyvb_comm_free(void* comm);
-int pyvb_allreduce_f64(void* comm, double* buf, size_t count, hipStream_t stream);
+// communicators, shared by the LDS and the PCA path (api.hip): RCCL, or the caller's own host-side all-reduce
+// (pyvb_*_comm_init_host: the sums travel through host memory -- a rehearsal transport for boxes where RCCL cannot run)
+struct pyvb_comm {
+    void* nccl;                                    // ncclComm_t, or null
+    pyvb_host_allreduce_fn fn; void* user;         // host transport
+    double* host; size_t cap;                      // its staging buffer
+};
+int pyvb_comm_create(pyvb_comm** comm, const char id[128], int rank, int world);
+int pyvb_comm_create_host(pyvb_comm** comm, pyvb_host_allreduce_fn fn, void* user);
+void pyvb_comm_free(pyvb_comm* comm);
+int pyvb_allreduce_f64(pyvb_comm* comm, double* buf, size_t count, hipStream_t stream);
 
 void pyvb_set_error(const char* fmt, ...);
 int pyvb_hip_fail(hipError_t e, const char* what, const char* file, int line);

@@ -46,7 +46,7 @@ struct pyvb_pca {
     long n_part_missing, n_none_rows, n_part_rows;   // global counts (from the mask)
     bool full_valid, lin_valid;          // all statistics current / at least sum x and sum z current
     bool res_valid;                      // scal[PS_RES] is the residual of the current W, Z, X, Mu (nothing but Beta updated since)
-    void* comm; int rank, world;
+    pyvb_comm* comm; int rank, world;
 };
 
 int pca_launch_small(pyvb_pca* h, int mode);

@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-__all__ = ["init", "shard_range", "LocalComm", "GlooComm", "SocketComm"]
+__all__ = ["init", "shard_range", "host_allreduce_callback", "LocalComm", "GlooComm", "SocketComm"]
 
 
 def shard_range(n_total, rank, world):
@@ -29,6 +29,24 @@ def shard_range(n_total, rank, world):
     base, extra = divmod(int(n_total), int(world))
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def host_allreduce_callback(comm):
+    """comm.allreduce_sum as the C callback of pyvb_lds_comm_init_host / pyvb_pca_comm_init_host (include/pyvb_hip.h):
+    the library's collectives then travel through this process group instead of RCCL -- the rehearsal transport for
+    several ranks on one GPU.  The caller keeps the returned object alive as long as the handle."""
+    from . import _capi
+
+    def fn(buf, count, user):
+        try:
+            a = np.ctypeslib.as_array(buf, shape=(int(count),))
+            a[:] = comm.allreduce_sum(a)
+            return 0
+        except Exception:                   # an exception must not unwind through the C frame
+            import traceback
+            traceback.print_exc()
+            return 1
+    return _capi.HOST_ALLREDUCE(fn)
 
 
 class LocalComm(object):

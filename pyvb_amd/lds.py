@@ -243,6 +243,13 @@ class LDSBatch(object):
     def comm_init(self, uid, rank, world):
         C.check(C.lib.pyvb_lds_comm_init(self._h, uid, int(rank), int(world)))
 
+    def comm_init_host(self, comm, rank, world):
+        """The ELBO all-reduce through a host process group (pyvb_amd.dist) instead of RCCL: rehearsal of the sharded
+        path with several ranks on one GPU (pyvb_lds_comm_init_host)."""
+        from .dist import host_allreduce_callback
+        self._host_cb = host_allreduce_callback(comm)          # kept alive with the handle
+        C.check(C.lib.pyvb_lds_comm_init_host(self._h, self._host_cb, None, int(rank), int(world)))
+
     # -- convenience ------------------------------------------------------------------------
     @classmethod
     def from_problem(cls, Y, st0, pri, device=0):

@@ -39,6 +39,13 @@ class PCABatch(object):
         """Attach the RCCL communicator (before set_data, so that the row counts become global)."""
         C.check(C.lib.pyvb_pca_comm_init(self._h, uid, int(rank), int(world)))
 
+    def comm_init_host(self, comm, rank, world):
+        """The same collectives through a host process group (pyvb_amd.dist: SocketComm / GlooComm) instead of RCCL:
+        rehearsal of the sharded path with several ranks on one GPU (pyvb_pca_comm_init_host)."""
+        from .dist import host_allreduce_callback
+        self._host_cb = host_allreduce_callback(comm)          # kept alive with the handle
+        C.check(C.lib.pyvb_pca_comm_init_host(self._h, self._host_cb, None, int(rank), int(world)))
+
     def set_priors(self, pri):
         d, q = self.d, self.q
         a = [_f64(pri["W_prior_mean"], (d, q), "W_prior_mean"), _f64(pri["W_prior_prec"], (q, d), "W_prior_prec"),

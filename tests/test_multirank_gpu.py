@@ -1,0 +1,59 @@
+"""Several ranks drive libpyvb_hip.so at once on the ONE GPU of the box: rows (PCA) / replicates (LDS) sharded as on a
+multi-GPU node, every collective of the library executed -- through the host transport of pyvb_*_comm_init_host, because
+RCCL refuses two ranks on one device.  What this pins: the sharded algorithm (row offsets, who owns global row 0, the
+order and contents of the collectives) against the single-rank result.  What it cannot pin: RCCL itself over xGMI."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "multirank_worker.py")
+
+
+def _run(what, world, tmp_path, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    prefix = str(tmp_path / ("%s_w%d" % (what, world)))
+    procs = [subprocess.Popen([sys.executable, WORKER, what, str(r), str(world), prefix], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    return [dict(np.load(prefix + "_%d.npz" % r)) for r in range(world)]
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pca_rows_sharded_over_ranks(world, tmp_path):
+    one = _run("pca", 1, tmp_path, 29610)[0]
+    many = _run("pca", world, tmp_path, 29620 + world)
+    assert [int(m["rows"][0]) for m in many] == sorted(int(m["rows"][0]) for m in many) and int(many[0]["rows"][0]) == 0
+    for m in many:                                            # global quantities: the same on every rank, equal to one rank's
+        for k in ("W_mean", "W_var", "Mu_mean", "Mu_var", "Z_cov", "beta_ab", "elbo"):
+            assert _rel(m[k], one[k]) < 1e-10, (k, _rel(m[k], one[k]))
+    for k in ("X", "Z", "X_rowvar"):                          # row quantities: the shards stack up to the whole
+        assert _rel(np.concatenate([m[k] for m in many]), one[k]) < 1e-10, k
+
+
+def test_lds_replicates_sharded_over_ranks(tmp_path):
+    one = _run("lds", 1, tmp_path, 29640)[0]
+    many = _run("lds", 2, tmp_path, 29650)
+    np.testing.assert_array_equal(np.concatenate([m["X"] for m in many]), one["X"])     # replicates are independent: bitwise
+    total = sum(m["elbo_local"] for m in many)
+    for m in many:
+        assert _rel(m["elbo_total"], total) < 1e-13                                      # the all-reduce, on every rank
+        assert _rel(m["elbo_total"], one["elbo_total"]) < 1e-12
+        assert _rel(m["history"][-1], one["history"][-1]) < 1e-12                       # the side-stream history too
