@@ -1,7 +1,7 @@
 """One rank of the multi-rank rehearsal on ONE GPU (tests/test_multirank_gpu.py): the library's collectives travel through
 the host transport (pyvb_*_comm_init_host over pyvb_amd.dist.SocketComm) because RCCL refuses several ranks on one device.
 
-    python tests/multirank_worker.py {pca|lds} RANK WORLD OUT_PREFIX
+    python tests/multirank_worker.py {pca|lds|pcabig} RANK WORLD OUT_PREFIX [N d q]
 """
 import importlib.util
 import os
@@ -45,6 +45,48 @@ def pca_rank(rank, world, comm):
     return st
 
 
+def big_rows(lo, hi, d, q, seed, block=10000):
+    """Rows lo..hi of a seeded N x d problem, generated block by block so that every rank makes only its own rows."""
+    g = np.random.default_rng(seed)
+    W = g.standard_normal((d, q)); mean = g.standard_normal(d)
+    W0 = g.standard_normal((d, q))
+    X, obs, Z0 = [], [], []
+    for b0 in range(lo // block * block, hi, block):
+        r = np.random.default_rng([seed, b0 // block])
+        Z = r.standard_normal((block, q))
+        x = Z @ W.T + mean + 0.2 * r.standard_normal((block, d))
+        o = r.random((block, d)) > 0.1
+        z0 = r.standard_normal((block, q))
+        a, e = max(lo, b0) - b0, min(hi, b0 + block) - b0
+        X.append(x[a:e]); obs.append(o[a:e]); Z0.append(z0[a:e])
+    return np.concatenate(X), np.concatenate(obs), np.concatenate(Z0), W0
+
+
+def pca_big_rank(rank, world, comm, N, d, q):
+    """BASELINE configs[4]'s shape, rows sharded over the ranks."""
+    from pyvb_amd.pca import PCABatch
+    lo, hi = dist.shard_range(N, rank, world)
+    X, obs, Z0, W0 = big_rows(lo, hi, d, q, 33)
+    pri = {"W_prior_mean": np.zeros((d, q)), "W_prior_prec": np.full((q, d), 1e-3), "Mu_prior_mean": np.zeros(d),
+           "Mu_prior_prec": np.full(d, 1e-3), "beta_a0": 1e-3, "beta_b0": 1e-3}
+    b = PCABatch(hi - lo, d, q, device=0, N_total=N, row_offset=lo)
+    if world > 1:
+        b.comm_init_host(comm, rank, world)
+    b.set_priors(pri)
+    b.set_data(np.where(obs, X, np.nan))
+    b.set_state(X_missing=np.where(obs, X, 0.0), W_mean=W0, Z=Z0, Z_cov=np.eye(q), Mu_mean=np.zeros(d), beta_b=1.0)
+    del X, obs
+    b.iterate(3)
+    st = b.get_state()
+    out = {k: st[k] for k in ("W_mean", "W_var", "Mu_mean", "Mu_var", "Z_cov", "beta_ab")}
+    out["elbo"] = b.elbo()
+    out["Z_head"] = st["Z"][:64]; out["X_head"] = st["X"][:64]       # of this rank's shard
+    out["Z_sum"] = st["Z"].sum(0); out["X_sum"] = st["X"].sum(0)
+    out["rows"] = np.array([lo, hi])
+    b.close()
+    return out
+
+
 def lds_rank(rank, world, comm):
     from pyvb_amd.lds import LDSBatch
     T, D, K, N, seed = LDS_SHAPE
@@ -64,7 +106,10 @@ def lds_rank(rank, world, comm):
 if __name__ == "__main__":
     what, rank, world, prefix = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     comm = dist.SocketComm(world, rank) if world > 1 else dist.LocalComm()
-    res = (pca_rank if what == "pca" else lds_rank)(rank, world, comm)
+    if what == "pcabig":
+        res = pca_big_rank(rank, world, comm, *[int(x) for x in sys.argv[5:8]])
+    else:
+        res = (pca_rank if what == "pca" else lds_rank)(rank, world, comm)
     np.savez(prefix + "_%d.npz" % rank, **res)
     comm.barrier()
     comm.close()

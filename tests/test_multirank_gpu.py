@@ -14,15 +14,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "multirank_worker.py")
 
 
-def _run(what, world, tmp_path, port):
+def _run(what, world, tmp_path, port, extra=()):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     prefix = str(tmp_path / ("%s_w%d" % (what, world)))
-    procs = [subprocess.Popen([sys.executable, WORKER, what, str(r), str(world), prefix], env=env,
+    procs = [subprocess.Popen([sys.executable, WORKER, what, str(r), str(world), prefix] + [str(x) for x in extra], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=300)
+            out, _ = p.communicate(timeout=600)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -57,3 +57,18 @@ def test_lds_replicates_sharded_over_ranks(tmp_path):
         assert _rel(m["elbo_total"], total) < 1e-13                                      # the all-reduce, on every rank
         assert _rel(m["elbo_total"], one["elbo_total"]) < 1e-12
         assert _rel(m["history"][-1], one["history"][-1]) < 1e-12                       # the side-stream history too
+
+
+def test_baseline_config5_rows_sharded_over_four_ranks(tmp_path):
+    """BASELINE configs[4] at full size (10^6 rows x 256, q = 16, 10 % missing), the rows sharded over four ranks as they
+    would be over GPUs -- here four processes on the one GPU -- against the single-rank run of the same data."""
+    shape = (1000000, 256, 16)
+    one = _run("pcabig", 1, tmp_path, 29660, shape)[0]
+    many = _run("pcabig", 4, tmp_path, 29670, shape)
+    assert [tuple(m["rows"]) for m in many] == [(0, 250000), (250000, 500000), (500000, 750000), (750000, 1000000)]
+    for m in many:
+        for k in ("W_mean", "W_var", "Mu_mean", "Mu_var", "Z_cov", "beta_ab", "elbo"):
+            assert _rel(m[k], one[k]) < 1e-9, (k, _rel(m[k], one[k]))
+    assert _rel(many[0]["Z_head"], one["Z_head"]) < 1e-9 and _rel(many[0]["X_head"], one["X_head"]) < 1e-9
+    assert _rel(sum(m["Z_sum"] for m in many), one["Z_sum"]) < 1e-8
+    assert _rel(sum(m["X_sum"] for m in many), one["X_sum"]) < 1e-9
