@@ -17,6 +17,8 @@ from . import nodes as N
 
 
 class LDSPlan(object):
+    resume_left = 3         # how often a graph handed to the generic plan may still come back (GenericPlan._resume_fused)
+
     def __init__(self, Xs, Ys, As, Cs, A, C, Q, R, pri):
         from .lds import LDSBatch
         self.Xs, self.Ys, self.As, self.Cs, self.A, self.C, self.Q, self.R = Xs, Ys, As, Cs, A, C, Q, R
@@ -156,10 +158,12 @@ class LDSPlan(object):
             n._plan = None
         self.batch.close()
         gp = GenericPlan(self.Xs[0])
+        if self.resume_left > 0:        # back to the fused kernels when a forward and a backward sweep follow each other again
+            gp.resume = {"pattern": self.Xs + self.Xs[::-1], "left": self.resume_left}
         for key in rest:
             node = by_id[lookup[key]]
             if not getattr(node, "observed", False):
-                gp.enqueue(node)
+                node._plan.enqueue(node)        # gp -- or the fused plan again, if these requests brought the graph back to it
         return gp
 
     # -- attribute traffic -----------------------------------------------------------------------

@@ -308,6 +308,12 @@ class GenericPlan(object):
         self._executor_factory = executor_factory or DeviceExecutor
         self.ex = None
         self.n_random_nodes = len([n for n in self.nodes if isinstance(n, (N.Gaussian, N.Gamma, N.DiagonalGamma, N.Wishart))])
+        # A graph a fused plan has handed over (a single X_t.update(), say) goes back to it when the standard loop resumes:
+        # resume = {"pattern": the update() requests of one forward and one backward sweep, "left": hand-backs still allowed},
+        # set by LDSPlan._demote.  Requests that follow the pattern wait in _buf; anything else runs them node by node.
+        self.resume = None
+        self._buf = []
+        self.released = False
         if adopt:
             for nd in self.nodes:
                 nd._plan = self
@@ -337,6 +343,8 @@ class GenericPlan(object):
 
     # -- running --------------------------------------------------------------------------------
     def _ensure_executor(self, need):
+        if self.released:
+            raise RuntimeError("this plan has been released: its graph is bound to another plan now")
         if self.ex is None or need > self.ex.size:
             old = self.ex
             size = max(need, self.temp_high) + 4096
@@ -374,15 +382,54 @@ class GenericPlan(object):
 
     # -- plan interface used by pyvb_amd.nodes / network -----------------------------------------
     def enqueue(self, node):
+        if self.resume is not None and self._buffer(node):
+            return
+        self._update_now(node)
+
+    def _update_now(self, node):
         if isinstance(node, N.Gaussian):
             self._run(("update", id(node)), lambda t: self._emit_update_gaussian(t, node))
         else:
             self._run(("update", id(node)), lambda t: self._emit_update_noise(t, node))
 
+    def _buffer(self, node):
+        """True if the request was taken into the buffer (it runs later: fused, or node by node at the next flush)."""
+        pat = self.resume["pattern"]
+        if node is pat[len(self._buf)]:
+            self._buf.append(node)
+            if len(self._buf) == len(pat):
+                self._resume_fused()
+            return True
+        self._flush_buf()
+        if node is pat[0]:
+            self._buf.append(node)
+            return True
+        return False
+
+    def _flush_buf(self):
+        buf, self._buf = self._buf, []
+        for nd in buf:
+            self._update_now(nd)
+
+    def _resume_fused(self):
+        """A forward and a backward sweep have queued up with nothing in between: the standard loop is back.  The state goes
+        to the host attributes, the recogniser binds the graph anew (the fused plan, if it still is that graph) and the two
+        sweeps are its first requests."""
+        from . import _recognise
+        buf, self._buf = self._buf, []
+        left = self.resume["left"] - 1
+        self.resume = None
+        self.release()
+        plan = _recognise.bind(buf[0])
+        plan.resume_left = left
+        for nd in buf:
+            plan.enqueue(nd)
+
     def flush(self):
-        pass
+        self._flush_buf()
 
     def read(self, node, name):
+        self._flush_buf()
         s = self.slot[id(node)]
         if isinstance(node, N.Gaussian):
             if name == "qmu":
@@ -402,6 +449,7 @@ class GenericPlan(object):
         raise AttributeError(name)
 
     def write(self, node, name, value):
+        self._flush_buf()
         s = self.slot[id(node)]
         if name in ("qmu", "qcov", "qb", "qw") and name in s:
             self._ensure_executor(self.temp_high)
@@ -411,6 +459,7 @@ class GenericPlan(object):
 
     def pull(self):
         """Device state back into the nodes' host attributes (before the graph is re-bound)."""
+        self._flush_buf()
         if self.ex is None:
             return
         for nd in self.nodes:
@@ -435,13 +484,16 @@ class GenericPlan(object):
         if self.ex is not None:
             self.ex.close()
             self.ex = None
+        self.released = True
 
     def node_llb(self, node):
+        self._flush_buf()
         res = self._run(("llb", id(node)), lambda t: self._emit_llb(t, node))
         return float(self._read(res)[0, 0])
 
     def llb_sum(self, node_list):
         """sum of log_lower_bound() over the nodes (network.py:49), one launch."""
+        self._flush_buf()
         key = ("llbsum",) + tuple(id(n) for n in node_list)
 
         def build(t):
@@ -453,6 +505,7 @@ class GenericPlan(object):
 
     def update_all(self, node_list):
         """[n.update() for n in node_list] as one launch (Network.learn, network.py:46-48)."""
+        self._flush_buf()
         key = ("updall",) + tuple(id(n) for n in node_list)
 
         def build(t):
@@ -467,10 +520,12 @@ class GenericPlan(object):
 
     def message(self, node, requester):
         """node.pass_up_m1_m2(requester) evaluated on the device; returns numpy arrays."""
+        self._flush_buf()
         res = self._run(("msg", id(node), id(requester)), lambda t: self._pass_up(t, node, requester))
         return tuple(self._read(r) for r in res)
 
     def expectation(self, node, what):
+        self._flush_buf()
         fn = {"Ex": self._ex, "ExxT": self._exxt, "ExTx": self._extx, "lndet": self._lndet}[what]
         return self._read(self._run(("exp", what, id(node)), lambda t: fn(t, node)))
 

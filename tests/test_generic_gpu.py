@@ -23,7 +23,11 @@ def test_generic_scenarios_on_device(name, monkeypatch):
         monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
     named = check_scenario(name)
     plan = next(iter(named.values()))._plan
-    assert isinstance(plan, generic.GenericPlan) and isinstance(plan.ex, generic.DeviceExecutor)
+    if name in GS.NEEDS_DEVICE and not isinstance(plan, generic.GenericPlan):
+        # left to the recogniser: the requests no fused kernel serves ran node by node, then the sweeps took the graph back
+        assert isinstance(plan, _recognise.LDSPlan) and plan.resume_left < _recognise.LDSPlan.resume_left
+    else:
+        assert isinstance(plan, generic.GenericPlan) and isinstance(plan.ex, generic.DeviceExecutor)
 
 
 def test_lds_with_missing_outputs_on_the_fused_plan():

@@ -226,3 +226,61 @@ def test_pca_demo_of_the_reference_tests_file():
     assert isinstance(got[5], _recognise.PCAPlan) and isinstance(ref[5], generic.GenericPlan)
     for a, b, what in zip(got[:5], ref[:5], ("W", "Mu", "Z", "cov of a Z_n", "Beta.qb")):
         assert _rel(a, b) <= 1e-8, what
+
+
+def _small_lds(seed, T=12, q=3, d=4):
+    from pyvb_amd import nodes
+    np.random.seed(seed)                    # the nodes draw their initial posteriors from the global RNG
+    Y = np.random.randn(T, d)
+    As = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q) * 1e-3) for _ in range(q)]
+    Cs = [nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3) for _ in range(q)]
+    A, C = nodes.hstack(As), nodes.hstack(Cs)
+    Q = nodes.DiagonalGamma(q, np.ones(q) * 1e-3, np.ones(q) * 1e-3)
+    R = nodes.DiagonalGamma(d, np.ones(d) * 1e-3, np.ones(d) * 1e-3)
+    Xs = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q))]
+    Ys = [nodes.Gaussian(d, C * Xs[0], R)]
+    for t in range(1, T):
+        Xs.append(nodes.Gaussian(q, A * Xs[-1], Q)); Ys.append(nodes.Gaussian(d, C * Xs[-1], R))
+    for y, row in zip(Ys, Y):
+        y.observe(row.reshape(d, 1))
+
+    def loop():
+        [x.update() for x in Xs]; [x.update() for x in reversed(Xs)]
+        [a.update() for a in As]; [c.update() for c in Cs]; Q.update(); R.update()
+    return Xs, As, Cs, Q, R, loop
+
+
+def test_graph_returns_to_the_fused_plan_when_the_loop_resumes(monkeypatch):
+    """A single X_t.update() hands the graph to the node-by-node plan (the fused kernels serve whole sweeps); when a forward
+    and a backward sweep follow each other again it goes back.  Checked against a twin kept node by node throughout."""
+    from pyvb_amd import generic, _recognise
+    from pyvb_amd._recognise import LDSPlan
+    Xs, As, Cs, Q, R, loop = _small_lds(5)
+    bind = _recognise.bind
+    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+    Xs2, As2, Cs2, Q2, R2, loop2 = _small_lds(5)
+    loop2(); Xs2[3].update(); Xs2[7].update(); As2[1].update(); loop2(); loop2()
+    ref = [x.qmu.copy() for x in Xs2] + [a.qmu.copy() for a in As2] + [np.asarray(Q2.qb).copy(), Xs2[4].qcov.copy()]
+    monkeypatch.setattr(_recognise, "bind", bind)
+
+    loop()
+    assert isinstance(Xs[0]._plan, LDSPlan) and Xs[0]._plan.resume_left == 3
+    Xs[3].update(); Xs[7].update(); As[1].update()
+    Xs[0]._plan.flush()                      # requests are queued until something is read
+    assert isinstance(Xs[0]._plan, generic.GenericPlan) and Xs[0]._plan.resume is not None
+    loop()                                   # forward + backward sweep in a row: back to the fused plan, mid-loop
+    assert isinstance(Xs[0]._plan, LDSPlan) and Xs[0]._plan.resume_left == 2
+    loop()
+    got = [x.qmu.copy() for x in Xs] + [a.qmu.copy() for a in As] + [np.asarray(Q.qb).copy(), Xs[4].qcov.copy()]
+    for g, r in zip(got, ref):
+        assert _rel(g, r) < 1e-9
+    # a broken pattern runs the waiting requests node by node, in order
+    Xs[0].update(); Xs[1].update(); Xs[5].update()
+    Xs[0]._plan.flush()
+    assert isinstance(Xs[0]._plan, generic.GenericPlan)
+    Xs2_plan = Xs2[0]._plan
+    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+    Xs2[0].update(); Xs2[1].update(); Xs2[5].update()
+    assert Xs2[0]._plan is Xs2_plan
+    for t in (0, 1, 5, 6):
+        assert _rel(Xs[t].qmu, Xs2[t].qmu) < 1e-9
