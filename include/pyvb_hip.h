@@ -196,6 +196,15 @@ int pyvb_pca_set_data(pyvb_pca* h, const double* X);
 /* explicit posterior state; X_missing[N][d] supplies the posterior means of the missing entries only */
 int pyvb_pca_set_state(pyvb_pca* h, const double* X_missing, const double* W_mean, const double* Z, const double* Z_cov,
                        const double* Mu_mean, const double* beta_b);
+/* The X_n as Gaussian.__init__ leaves them (gaussian.py:70-72; observe() with NaN changes neither qmu nor qcov, :90-96):
+ * a row that is not fully observed carries the posterior mean X_full[n] at ALL its d entries and the covariance
+ * row_var[n] * I, messages with them, and is conditioned on its observed entries by its first update (:125-134).
+ * Call after pyvb_pca_set_data; rows without missing entries are ignored.  Without this call the observed entries of a
+ * partially observed row count as pinned from the start (what pyvb_pca_set_state describes). */
+int pyvb_pca_set_unpinned_rows(pyvb_pca* h, const double* X_full, const double* row_var);
+/* diagonals of the initial covariances of the W columns [q][d] and of Mu [d] (either may be NULL): read only by updates that
+ * come before the first update of the node itself -- Z or Beta before W, Beta before Mu; the crawl order never does that */
+int pyvb_pca_set_initial_variances(pyvb_pca* h, const double* W_var, const double* Mu_var);
 int pyvb_pca_get_state(pyvb_pca* h, double* X, double* X_rowvar, double* W_mean, double* W_var, double* Z, double* Z_cov,
                        double* Mu_mean, double* Mu_var, double* beta_ab);
 /* [w.update() for w in Ws]; [z.update() for z in Zs]; Xs[lo:hi] updates; Mu.update(); Beta.update() */

@@ -14,7 +14,9 @@ Parity status: PINNED by tests/golden/pca_*.npz (tests/golden/make_golden.py run
 
 All Z_n share one posterior covariance (their precision I + <W^T beta W> does not depend on n), the
 rows' missing entries are imputed by X_n.update() (gaussian.py:125-134 on a diagonal covariance: known
-entries pinned, missing ones <W><z_n> + <Mu> with variance 1/beta) and then message as if observed.
+entries pinned, missing ones <W><z_n> + <Mu> with variance 1/beta) and then message as if observed.  Before
+its first update a partially observed row messages with whatever mean it holds at ALL its entries -- the
+constructor's random draw unless the caller assigned one (fixture pca_default_init_*: init X_full, X_var0).
 Paths are relative to /root/reference/src/pyvb/.
 
 State (float64):  W_mean [d,q], W_var [q,d] (diagonals of the column covariances), Z [N,q], Z_cov [q,q],
@@ -76,7 +78,7 @@ def update_X(st, pri, lo, hi):
     pred = st["Z"][lo:hi] @ st["W_mean"].T + st["Mu_mean"]
     upd = ~obs.all(1)
     X, V = st["X"][lo:hi], st["X_var"][lo:hi]
-    X[upd] = np.where(obs[upd], X[upd], pred[upd])
+    X[upd] = np.where(obs[upd], st["Xdata"][lo:hi][upd], pred[upd])     # until its first update a row may carry other means there
     V[upd] = np.where(obs[upd], 0.0, 1.0 / beta)
     d = X.shape[1]
     if upd.any():
@@ -166,9 +168,16 @@ def iterate(st, pri):
 
 def make_state(init, pri, N, d, q):
     """Copy an explicit initial state (tests/golden/make_golden.py: pca_initial_state) into the layout above."""
-    st = {k: np.array(v, dtype=float, copy=True) for k, v in init.items() if k != "obs"}
+    st = {k: np.array(v, dtype=float, copy=True) for k, v in init.items() if k not in ("obs", "X_full", "X_var0")}
     st["obs"] = np.array(init["obs"], dtype=bool)
     st["X_var"] = np.zeros((N, d))
+    st["Xdata"] = st["X"].copy()            # the observations (where obs)
+    if "X_full" in init:
+        # the X_n as their constructors drew them (gaussian.py:70-72): a row that is not fully observed carries a mean at
+        # ALL its entries and the covariance c_n I until its first update conditions it on the observed ones (:90-96, :125-134)
+        free = ~st["obs"].all(1)
+        st["X"][free] = np.asarray(init["X_full"], dtype=float)[free]
+        st["X_var"][free] = np.asarray(init["X_var0"], dtype=float)[free, None]
     st["W_var"] = np.zeros((q, d))
     st["Mu_var"] = np.zeros(d)
     st["qld_W"] = np.full(q, np.nan)

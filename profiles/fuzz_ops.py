@@ -106,9 +106,9 @@ def main():
             if a is not None:
                 for u, v in zip(a, b):
                     u, v = np.asarray(u, float), np.asarray(v, float)
-                    if not (np.all(np.isfinite(v)) and np.all(np.isfinite(u))):
-                        assert np.array_equal(np.isfinite(u), np.isfinite(v)), (case, n, op[0], u, v)
-                        continue
+                    if not np.all(np.isfinite(v)):      # NaN on the node-by-node path: a term the reference cannot evaluate yet
+                        continue                        # (q_ln_det before the node's first update: AttributeError there)
+                    assert np.all(np.isfinite(u)), (case, n, op[0], u, v)
                     e = float(np.abs(u - v).max() / max(np.abs(v).max(), 1e-12))
                     err = max(err, e)
                     assert e < 1e-7, "case %d op %d %s: rel err %.3e\nops so far: %s" % (case, n, op[0], e, [o[0] for o in ops[:n + 1]])

@@ -83,6 +83,8 @@ SIGNATURES = {
     "pyvb_pca_set_priors": (ctypes.c_int, [_h, _dp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_double]),
     "pyvb_pca_set_data": (ctypes.c_int, [_h, _dp]),
     "pyvb_pca_set_state": (ctypes.c_int, [_h] + [_dp] * 6),
+    "pyvb_pca_set_unpinned_rows": (ctypes.c_int, [_h, _dp, _dp]),
+    "pyvb_pca_set_initial_variances": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_pca_get_state": (ctypes.c_int, [_h] + [_dp] * 9),
     "pyvb_pca_update_W": (ctypes.c_int, [_h]),
     "pyvb_pca_update_Z": (ctypes.c_int, [_h]),

@@ -490,14 +490,23 @@ def describe_pca(start):
     N_ = len(Xs)
     obs = np.ones((N_, d), dtype=bool)
     X = np.empty((N_, d))
+    X_full, X_var0 = np.empty((N_, d)), np.zeros(N_)
     for n, x in enumerate(Xs):
-        X[n] = x.__dict__["_h_qmu"].reshape(-1)
+        X[n] = X_full[n] = x.__dict__["_h_qmu"].reshape(-1)
         if x.partially_observed:
             obs[n] = ~np.isnan(x.obs_value.reshape(-1))
             X[n] = np.where(obs[n], x.obs_value.reshape(-1), X[n])
         elif not x.observed:
             obs[n] = False
-    init = {"obs": obs, "X": X, "W_mean": np.hstack([w.__dict__["_h_qmu"] for w in Ws]),
+        if not x.observed:
+            # until its first update the row is what the constructor (or the caller) made it: a mean at ALL entries and a
+            # covariance, gaussian.py:70-72 / :90-96; the kernels keep one variance per row
+            cov = x.__dict__["_h_qcov"]
+            if np.abs(cov - cov[0, 0] * np.eye(d)).max() != 0.0 or not cov[0, 0] > 0.0:
+                _fail("the initial covariance of a row with missing entries must be a positive multiple of the identity")
+            X_var0[n] = cov[0, 0]
+    init = {"obs": obs, "X": X, "X_full": X_full, "X_var0": X_var0, "W_mean": np.hstack([w.__dict__["_h_qmu"] for w in Ws]),
+            "W_var": np.stack([np.diag(w.__dict__["_h_qcov"]) for w in Ws]).copy(), "Mu_var": np.diag(Mu.__dict__["_h_qcov"]).copy(),
             "Z": np.hstack([z.__dict__["_h_qmu"] for z in Zs]).T.copy(), "Z_cov": zc.copy(),
             "Mu_mean": Mu.__dict__["_h_qmu"].reshape(-1).copy(),
             "beta_b": float(np.asarray(Beta.__dict__["_h_qb"], dtype=float).reshape(-1)[0])}
@@ -510,6 +519,8 @@ class PCAPlan(object):
         self.Ws, self.W, self.Mu, self.Beta, self.Zs, self.Xs = Ws, W, Mu, Beta, Zs, Xs
         self.N, self.d, self.q = len(Xs), W.shape[0], W.shape[1]
         self.obs = init["obs"]
+        nmiss = (~self.obs).sum(1)
+        self.unpinned = (nmiss > 0) & (nmiss < self.d)       # rows not yet conditioned on their observed entries (first update)
         self.batch = PCABatch.from_problem(init, pri)
         self.index = {}
         for i, w in enumerate(Ws):
@@ -553,6 +564,7 @@ class PCAPlan(object):
                 self.z_updated = True
             elif kind == "x":
                 b.update_X(lo, hi)
+                self.unpinned[lo:hi] = False
             elif kind == "mu":
                 b.update_Mu()
             elif kind == "beta":
@@ -581,7 +593,7 @@ class PCAPlan(object):
             if name == "qmu":
                 return st["X"][i].reshape(-1, 1).copy()
             if name == "qcov":
-                return np.diag(np.where(self.obs[i], 0.0, st["X_rowvar"][i]))
+                return np.diag(np.where(self.obs[i] & ~self.unpinned[i], 0.0, st["X_rowvar"][i]))
             return node.__dict__.get("_h_" + name)
         if kind == "mu":
             return st["Mu_mean"].reshape(-1, 1).copy() if name == "qmu" else (np.diag(st["Mu_var"]) if name == "qcov" else node.__dict__.get("_h_" + name))

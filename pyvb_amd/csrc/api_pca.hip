@@ -24,7 +24,7 @@ int pyvb_pca_destroy(pyvb_pca* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) pyvb_comm_free(h->comm);
     void* bufs[] = {h->X, h->M, h->xvar, h->nmiss, h->Z, h->W_mean, h->W_var, h->Mu_mean, h->Mu_var, h->Z_cov, h->qld_W, h->W_pm, h->W_pp,
-                    h->Mu_pm, h->Mu_pp, h->scal, h->Gz, h->g0, h->part, h->stats, h->aux, h->elbo, h->status, h->red2};
+                    h->Mu_pm, h->Mu_pp, h->scal, h->Gz, h->g0, h->part, h->stats, h->aux, h->elbo, h->status, h->red2, h->Xdata, h->pinned};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -178,6 +178,50 @@ int pyvb_pca_set_state(pyvb_pca* h, const double* X_missing, const double* W_mea
     if ((rc = up(h, h->Mu_mean, Mu_mean, d))) return rc;
     if (beta_b) HIPCHK(hipMemcpyAsync(h->scal + PS_BETA_B, beta_b, sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->full_valid = h->lin_valid = false; h->res_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_pca_set_initial_variances(pyvb_pca* h, const double* W_var, const double* Mu_var) {
+    ENTER(h);
+    int rc;
+    if ((rc = up(h, h->W_var, W_var, (size_t)h->q * h->d))) return rc;
+    if ((rc = up(h, h->Mu_var, Mu_var, h->d))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->res_valid = false;
+    return PYVB_OK;
+}
+
+int pyvb_pca_set_unpinned_rows(pyvb_pca* h, const double* X_full, const double* row_var) {
+    ENTER(h);
+    ARGCHK(X_full && row_var, "X_full and row_var are required");
+    const long N = h->N; const int d = h->d, DP = h->DP;
+    std::vector<double> xb((size_t)N * DP), xv(N);
+    std::vector<int> nm(N);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(xb.data(), h->X, xb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(xv.data(), h->xvar, N * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nm.data(), h->nmiss, N * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<double> data(xb);           // the observations (and whatever the missing entries held)
+    std::vector<unsigned char> pin(N, 1);
+    long unpinned = 0;
+    for (long n = 0; n < N; ++n) {
+        if (nm[n] == 0) continue;           // fully observed: qmu is the observation, qcov zero (gaussian.py:97-100)
+        ARGCHK(row_var[n] > 0.0, "row_var must be positive for rows with missing entries");
+        xv[n] = row_var[n];
+        for (int k = 0; k < d; ++k) xb[(size_t)n * DP + k] = X_full[(size_t)n * d + k];
+        if (nm[n] < d) { pin[n] = 0; ++unpinned; }      // some entries observed: they are pinned by the row's first update
+    }
+    if (unpinned > 0) {
+        if (!h->Xdata) {
+            HIPCHK(hipMalloc((void**)&h->Xdata, xb.size() * sizeof(double)));
+            HIPCHK(hipMalloc((void**)&h->pinned, (size_t)N));
+        }
+        HIPCHK(hipMemcpy(h->Xdata, data.data(), data.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->pinned, pin.data(), (size_t)N, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(h->X, xb.data(), xb.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->xvar, xv.data(), N * sizeof(double), hipMemcpyHostToDevice));
     h->full_valid = h->lin_valid = false; h->res_valid = false;
     return PYVB_OK;
 }

@@ -19,6 +19,7 @@
 
 struct PcaArgs {
     double* X; const unsigned char* M; double* xvar; const int* nmiss; double* Z;
+    const double* Xdata; unsigned char* pinned;     // null unless some rows have not been conditioned on their observations yet
     double *W_mean, *W_var, *Mu_mean, *Mu_var, *Z_cov, *qld_W;
     const double *W_pm, *W_pp, *Mu_pm, *Mu_pp;
     double* scal; double* Gz; double* g0;
@@ -187,6 +188,13 @@ __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
 #pragma unroll
             for (int p = 0; p < P2T; ++p)
                 if (rowupd && ((mk[r] >> (8 * p)) & 0xffu) == 0) { v[p] = xn[p][r]; any = true; }
+            if (a.Xdata != nullptr && rowupd && !a.pinned[r0 + row]) {      // first update of a row that still carries its initial
+                const d2 dat = *reinterpret_cast<const d2*>(a.Xdata + (size_t)r0 * DP + xoff[r]);   // mean everywhere: the
+#pragma unroll
+                for (int p = 0; p < P2T; ++p)                                // observed entries take their data (gaussian.py:125-134)
+                    if (((mk[r] >> (8 * p)) & 0xffu) != 0) v[p] = dat[p];
+                any = true;
+            }
             // whole rows go back, known entries with their own bits: full-line writes (a masked 8-byte store is a
             // read-modify-write at the memory side, measured 0.3 ms slower per pass)
 #ifndef P2_GROUP
@@ -268,8 +276,12 @@ __global__ void __launch_bounds__(256) k_pca_rowvar(PcaArgs a) {
     for (long row = r0 + threadIdx.x; row < r1; row += 256) {
         const int nm = a.nmiss[row];
         double v = a.xvar[row];
-        if (nm > 0 && row >= a.lo_upd && row < a.hi_upd) { v = var_new; a.xvar[row] = v; }
-        sxv += nm * v;
+        int cnt = nm;                       // entries of the row that carry this variance
+        if (nm > 0 && row >= a.lo_upd && row < a.hi_upd) {
+            v = var_new; a.xvar[row] = v;
+            if (a.pinned) a.pinned[row] = 1;    // pass 2 (same stream, before this kernel) has conditioned the row just now
+        } else if (a.pinned && !a.pinned[row]) cnt = a.d;       // not updated yet: the initial covariance v I on all entries
+        sxv += cnt * v;
         if (nm > 0 && nm < a.d) slv += nm * log(v);
     }
     double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
@@ -474,13 +486,18 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         if (tid < DP) dsx[tid] = 0.0;
         __syncthreads();
         if (a.row_offset == 0 && a.nmiss[0] > 0) {
+            const bool pin = a.pinned && !a.pinned[0];           // first update of a row still carrying its initial mean everywhere
+            __syncthreads();
             if (tid < d && a.M[tid] == 0) {
                 double pred = a.Mu_mean[tid];
                 for (int i = 0; i < q; ++i) pred += a.W_mean[(size_t)tid * q + i] * a.Z[i];
                 dsx[tid] = pred - a.X[tid];
                 a.X[tid] = pred;
+            } else if (tid < d && pin) {
+                dsx[tid] = a.Xdata[tid] - a.X[tid];
+                a.X[tid] = a.Xdata[tid];
             }
-            if (tid == 0) { a.xvar[0] = 1.0 / beta; a.scal[PS_QLD_X] = 0.5 / (0.5 * d * log(beta)); }
+            if (tid == 0) { a.xvar[0] = 1.0 / beta; a.scal[PS_QLD_X] = 0.5 / (0.5 * d * log(beta)); if (pin) a.pinned[0] = 1; }
         }
     } else if (a.mode == PCA_APPLY) {
         // after the all-reduce of aux: the new sum of z replaces the old one, the sum of x moves by the delta
@@ -558,7 +575,7 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
 // ---------------------------------------------------------------------------------------------------
 static PcaArgs pca_args(pyvb_pca* h) {
     PcaArgs a;
-    a.X = h->X; a.M = h->M; a.xvar = h->xvar; a.nmiss = h->nmiss; a.Z = h->Z;
+    a.X = h->X; a.M = h->M; a.xvar = h->xvar; a.nmiss = h->nmiss; a.Z = h->Z; a.Xdata = h->Xdata; a.pinned = h->pinned;
     a.W_mean = h->W_mean; a.W_var = h->W_var; a.Mu_mean = h->Mu_mean; a.Mu_var = h->Mu_var; a.Z_cov = h->Z_cov; a.qld_W = h->qld_W;
     a.W_pm = h->W_pm; a.W_pp = h->W_pp; a.Mu_pm = h->Mu_pm; a.Mu_pp = h->Mu_pp;
     a.scal = h->scal; a.Gz = h->Gz; a.g0 = h->g0; a.part = h->part; a.stats = h->stats; a.aux = h->aux; a.elbo = h->elbo; a.status = h->status;

@@ -30,6 +30,8 @@ struct pyvb_pca {
     hipStream_t stream;
     double *X; unsigned char* M;         // [N][DP] posterior means of the X_n (data / imputed); 1 = observed
     double *xvar;                        // [N] variance of the missing entries of row n
+    double *Xdata; unsigned char* pinned; // only after pyvb_pca_set_unpinned_rows: the observations [N][DP] of rows that still
+                                         // carry their initial mean at ALL entries (pinned[n] == 0) until their first update
     int *nmiss;                          // [N]
     double *Z;                           // [N][QP]
     double *W_mean, *W_var, *Mu_mean, *Mu_var, *Z_cov, *qld_W;   // [d][q], [q][d], [d], [d], [q][q], [q]

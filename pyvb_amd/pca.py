@@ -66,6 +66,18 @@ class PCABatch(object):
                 None if beta_b is None else np.array([float(beta_b)])]
         C.check(C.lib.pyvb_pca_set_state(self._h, *[C.dptr(x) for x in arrs]))
 
+    def set_unpinned_rows(self, X_full, row_var):
+        """Rows that are not fully observed start as Gaussian.__init__ leaves them: mean X_full[n] at ALL entries, covariance
+        row_var[n] * I, until their first update conditions them on the observed entries (pyvb_pca_set_unpinned_rows)."""
+        C.check(C.lib.pyvb_pca_set_unpinned_rows(self._h, C.dptr(_f64(X_full, (self.N, self.d), "X_full")),
+                                                 C.dptr(_f64(row_var, (self.N,), "row_var"))))
+
+    def set_initial_variances(self, W_var=None, Mu_var=None):
+        """Diagonals of the initial covariances of the W columns [q, d] and of Mu [d] (pyvb_pca_set_initial_variances)."""
+        a = None if W_var is None else _f64(W_var, (self.q, self.d), "W_var")
+        b = None if Mu_var is None else _f64(Mu_var, (self.d,), "Mu_var")
+        C.check(C.lib.pyvb_pca_set_initial_variances(self._h, C.dptr(a), C.dptr(b)))
+
     def get_state(self):
         N, d, q = self.N, self.d, self.q
         out = {"X": np.empty((N, d)), "X_rowvar": np.empty(N), "W_mean": np.empty((d, q)), "W_var": np.empty((q, d)),
@@ -112,4 +124,8 @@ class PCABatch(object):
         b.set_data(np.where(init["obs"], init["X"], np.nan))
         b.set_state(X_missing=init["X"], W_mean=init["W_mean"], Z=init["Z"], Z_cov=init["Z_cov"],
                     Mu_mean=init["Mu_mean"], beta_b=float(init["beta_b"]))
+        if "W_var" in init or "Mu_var" in init:
+            b.set_initial_variances(init.get("W_var"), init.get("Mu_var"))
+        if "X_full" in init:                # the X_n as their constructors drew them (fixture pca_default_init_*)
+            b.set_unpinned_rows(init["X_full"], np.where(np.asarray(init["X_var0"]) > 0, init["X_var0"], 1.0))
         return b

@@ -218,8 +218,11 @@ def pca_problem(N, d, q, seed, p_missing=0.15):
     return init, pri
 
 
-def pca_build_graph(mod, init, pri):
-    """Graph of examples/PCA_missing_data.py:31-42 with explicit initial posteriors; returns the network too."""
+def pca_build_graph(mod, init, pri, explicit_x=True):
+    """Graph of examples/PCA_missing_data.py:31-42 with explicit initial posteriors; returns the network too.
+    explicit_x=False leaves the X_n as their constructors drew them (gaussian.py:70-72), which is what the example does: a
+    partially observed row then carries a random mean at ALL its entries, and the covariance I / rand, until its first
+    update conditions it on the observed ones (gaussian.py:90-96, :125-134); init["X_full"] / init["X_var0"] record the draw."""
     nodes = mod.nodes
     N, d = init["X"].shape
     q = init["Z"].shape[1]
@@ -237,8 +240,11 @@ def pca_build_graph(mod, init, pri):
         z.qmu = init["Z"][n].reshape(q, 1).copy()
         z.qcov = init["Z_cov"].copy()
     for n, x in enumerate(Xs):
-        if not x.observed:
+        if not x.observed and explicit_x:
             x.qmu = init["X"][n].reshape(d, 1).copy()
+    if not explicit_x:
+        init["X_full"] = np.hstack([np.asarray(x.qmu, dtype=float) for x in Xs]).T.copy()
+        init["X_var0"] = np.array([float(x.qcov[0, 0]) for x in Xs])
     Mu.qmu = init["Mu_mean"].reshape(d, 1).copy()
     Beta.qb = float(init["beta_b"])
     net = mod.Network()
@@ -247,9 +253,10 @@ def pca_build_graph(mod, init, pri):
     return dict(Ws=Ws, W=W, Mu=Mu, Beta=Beta, Zs=Zs, Xs=Xs, net=net)
 
 
-def run_pca_case(ref, name, N, d, q, iters, seed):
+def run_pca_case(ref, name, N, d, q, iters, seed, explicit_x=True):
     init, pri = pca_problem(N, d, q, seed)
-    g = pca_build_graph(ref, init, pri)
+    np.random.seed(seed)                    # the constructors draw from the global generator
+    g = pca_build_graph(ref, init, pri, explicit_x)
     net = g["net"]
     net.find_iterable()
     lab = {}
@@ -315,7 +322,8 @@ def run_generic_case(ref, name):
 
 PCA_CASES = [("example_n200_d5_q2", 200, 5, 2, (1, 2, 5), 30100),
              ("n60_d12_q3", 60, 12, 3, (1, 3), 30101),
-             ("n40_d70_q17", 40, 70, 17, (1, 2), 30102)]
+             ("n40_d70_q17", 40, 70, 17, (1, 2), 30102),
+             ("default_init_n50_d6_q2", 50, 6, 2, (1, 2, 4), 30103, False)]
 
 
 def crawl_labels(mod, T=4, D=2, K=3):

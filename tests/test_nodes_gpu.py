@@ -147,7 +147,7 @@ def test_pca_example_through_network_learn():
     import pyvb_amd
     from test_pca_oracle_golden import load_pca
     G = _golden_module()
-    for path in sorted(glob.glob(os.path.join(HERE, "golden", "pca_*.npz")))[:2]:
+    for path in [p for p in sorted(glob.glob(os.path.join(HERE, "golden", "pca_*.npz"))) if "default_init" not in p][:2]:
         N, d, q, init, pri, z = load_pca(path)
         g = G.pca_build_graph(pyvb_amd, init, pri)
         net = g["net"]
@@ -284,3 +284,38 @@ def test_graph_returns_to_the_fused_plan_when_the_loop_resumes(monkeypatch):
     assert Xs2[0]._plan is Xs2_plan
     for t in (0, 1, 5, 6):
         assert _rel(Xs[t].qmu, Xs2[t].qmu) < 1e-9
+
+
+def test_pca_rows_as_their_constructors_drew_them():
+    """The reference's example never assigns the X_n: a partially observed row messages with the constructor's random mean
+    at ALL its entries (and covariance I / rand) until its first update pins the observed ones (gaussian.py:70-72, :90-96,
+    :125-134).  Fixture pca_default_init_* records such a run of the reference; here the same graph through Network.learn."""
+    import pyvb_amd
+    from pyvb_amd._recognise import PCAPlan
+    from test_pca_oracle_golden import load_pca
+    G = _golden_module()
+    N, d, q, init, pri, z = load_pca(os.path.join(HERE, "golden", "pca_default_init_n50_d6_q2.npz"))
+    np.random.seed(30103)                                   # the generator's seed: the constructors draw from the global RNG
+    g = G.pca_build_graph(pyvb_amd, dict(init), pri, explicit_x=False)
+    drawn = np.hstack([x.qmu for x in g["Xs"]]).T
+    free = ~init["obs"].all(1)
+    assert _rel(drawn[free], init["X_full"][free]) < 1e-15     # same draws as the reference's classes made (SURVEY Q11)
+    assert _rel(np.array([x.qcov[0, 0] for x in g["Xs"]])[free], init["X_var0"][free]) < 1e-15
+    net = g["net"]
+    part = free & init["obs"].any(1)
+    n0 = int(np.nonzero(part)[0][0])
+    assert _rel(g["Xs"][n0].qcov, init["X_var0"][n0] * np.eye(d)) < 1e-15      # before any update: the draw, on all entries
+    done = 0
+    for it in [int(i) for i in z["iters"]]:
+        net.learn(it - done, tol=-np.inf, verbose=False)
+        done = it
+        tag = "it%d_" % it
+        assert isinstance(g["Zs"][0]._plan, PCAPlan)
+        assert _rel(np.hstack([w.qmu for w in g["Ws"]]), z[tag + "W_mean"]) <= RTOL
+        assert _rel(np.hstack([zz.qmu for zz in g["Zs"]]).T, z[tag + "Z"]) <= RTOL
+        assert _rel(np.hstack([x.qmu for x in g["Xs"]]).T, z[tag + "X"]) <= RTOL
+        assert _rel(np.stack([np.diag(x.qcov) for x in g["Xs"]]), z[tag + "X_var"]) <= RTOL
+        assert _rel(g["Mu"].qmu.reshape(-1), z[tag + "Mu_mean"]) <= RTOL
+        assert abs(g["Beta"].qb - float(z[tag + "beta_b"])) <= RTOL * abs(float(z[tag + "beta_b"]))
+        ref = z[tag + "elbo_parts"].sum()
+        assert abs(net.llb - ref) <= RTOL * abs(ref)
