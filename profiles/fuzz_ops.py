@@ -24,7 +24,11 @@ def build(seed, T, q, d, noise, Y, knowns):
     As = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q) * 1e-3) for _ in range(q)]
     Cs = [nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3) for _ in range(q)]
     A, C = nodes.hstack(As), nodes.hstack(Cs)
-    if noise == "gamma":
+    if noise == "wishart":
+        Q, R = nodes.Wishart(q, q + 1e-3, np.eye(q) * 1e-3), nodes.Wishart(d, d + 1e-3, np.eye(d) * 1e-3)
+        Q.qw = np.eye(q) * (0.5 + np.random.rand())         # the constructor's rank-one draw has no inverse
+        R.qw = np.eye(d) * (0.5 + np.random.rand())
+    elif noise == "gamma":
         Q, R = nodes.Gamma(q, 1e-3, 1e-3), nodes.Gamma(d, 1e-3, 1e-3)
     else:
         Q = nodes.DiagonalGamma(q, np.ones(q) * 1e-3, np.ones(q) * 1e-3)
@@ -42,8 +46,8 @@ def build(seed, T, q, d, noise, Y, knowns):
 
 
 def ops_for(rng, T, q, d, n_ops, friendly):
-    kinds = ["x", "fwd", "bwd", "a", "c", "As", "Cs", "Q", "R", "read_x", "read_a", "read_q", "llb_x", "llb_y", "llb_a", "exxt", "reobs", "iter"]
-    w = np.array([4, 3, 3, 2, 2, 2, 2, 2, 2, 3, 2, 2, 2, 1, 1, 1, 1, 3], float)
+    kinds = ["x", "fwd", "bwd", "a", "c", "As", "Cs", "Q", "R", "read_x", "read_a", "read_q", "llb_x", "llb_y", "llb_a", "exxt", "reobs", "iter", "Ys", "y", "read_y"]
+    w = np.array([4, 3, 3, 2, 2, 2, 2, 2, 2, 3, 2, 2, 2, 1, 1, 1, 1, 3, 2, 1, 2], float)
     if friendly:        # what the fused plan serves without handing the graph to the generic one: no single-state updates
         w[0] = 0.0
     out = []
@@ -75,7 +79,11 @@ def apply(g, op):
     elif k == "llb_y": return [np.array(Ys[t].log_lower_bound())]
     elif k == "llb_a": return [np.array(As[i].log_lower_bound()), np.array(g["Q"].log_lower_bound())]
     elif k == "exxt": return [Ys[t].mean_parent.pass_down_Ex(), Ys[t].mean_parent.pass_down_ExxT()]
-    elif k == "reobs": Ys[t].observe(vec.reshape(-1, 1))
+    elif k == "reobs":
+        if Ys[t].observed: Ys[t].observe(vec.reshape(-1, 1))
+    elif k == "Ys": [y.update() for y in Ys if not y.observed]
+    elif k == "y": Ys[t].update()
+    elif k == "read_y": return [Ys[t].qmu.copy(), np.diag(Ys[t].qcov).copy()]
     return None
 
 
@@ -87,22 +95,29 @@ def main():
         T = int(rng.integers(3, 40)); q = int(rng.integers(1, 5)); d = int(rng.integers(1, 6))
         if d == 1 and q > 1:
             d = 2       # a one-row product: the reference itself raises there (node.py:198 NameError, nodes_todo.py:40-41), so does the generic path
-        noise = str(rng.choice(["gamma", "diagonal_gamma"])); knowns = bool(rng.random() < 0.3) and q > 1
+        noise = str(rng.choice(["gamma", "diagonal_gamma", "wishart"], p=[0.4, 0.4, 0.2])); knowns = bool(rng.random() < 0.3) and q > 1 and noise != "wishart"
         Y = rng.standard_normal((T, d))
+        if noise != "wishart" and rng.random() < 0.3:      # outputs with missing entries: nodes of their own
+            Y[rng.random((T, d)) < 0.2] = np.nan
+            Y[0] = np.abs(Y[0]); Y[0][~np.isfinite(Y[0])] = 0.5
         seed = int(rng.integers(1 << 30))
         fused = build(seed, T, q, d, noise, Y, knowns)
         with forced_generic():
             slow = build(seed, T, q, d, noise, Y, knowns)
         friendly = bool(rng.random() < 0.7)
         ops = ops_for(rng, T, q, d, 25, friendly)
-        print("case %2d T=%2d q=%d d=%d %-14s knowns=%d: %s" % (case, T, q, d, noise, knowns, " ".join(o[0] for o in ops)), flush=True)
+        print("case %2d T=%2d q=%d d=%d %-14s knowns=%d missing=%d: %s" % (case, T, q, d, noise, knowns, int(np.isnan(Y).sum()), " ".join(o[0] for o in ops)), flush=True)
         if friendly or rng.random() < 0.5:
             ops.insert(0, ("fwd", 0, 0, None))          # else: whatever comes first, e.g. parameters before any state update
         err = 0.0
         for n, op in enumerate(ops):
-            a = apply(fused, op)
-            with forced_generic():
-                b = apply(slow, op)
+            try:
+                a = apply(fused, op)
+                with forced_generic():
+                    b = apply(slow, op)
+            except Exception:
+                print("case %d failed at op %d (%s, t=%d, i=%d); plan %s" % (case, n, op[0], op[1], op[2], type(fused["Xs"][0]._plan).__name__), flush=True)
+                raise
             if a is not None:
                 for u, v in zip(a, b):
                     u, v = np.asarray(u, float), np.asarray(v, float)

@@ -216,10 +216,17 @@ class LDSPlan(object):
         raise AttributeError(name)
 
     def write(self, node, name, value):
-        """A user assignment to a posterior attribute after binding: push it to the device."""
+        """A user assignment to a posterior attribute after binding: push it to the device.  False: not something this plan
+        can patch in place (an observation, a state covariance): the caller releases the plan and the graph is bound anew."""
         self.flush()
+        if node._plan is not self:              # the queue held something only the node-by-node plan serves
+            return node._plan.write(node, name, value)
+        if name not in ("qmu", "qcov", "qb", "qw"):
+            return True                         # q_ln_det, qprec: host-only bookkeeping
         self.cache = None
         kind, i = self.index[id(node)]
+        if not ((kind == "x" and name == "qmu") or kind in ("a", "c") or (kind in ("q", "r") and name in ("qb", "qw"))):
+            return False
         st = self.batch.get_state()
         if kind == "x" and name == "qmu":
             st["X"][0, i] = np.asarray(value).reshape(-1)
@@ -238,7 +245,7 @@ class LDSPlan(object):
             key = "Q_b" if kind == "q" else "R_b"
             st[key][0] = np.broadcast_to(np.asarray(value, dtype=float), st[key][0].shape)
             self.batch.set_state(**{key: st[key]})
-        # other attributes (q_ln_det, observed nodes) are host-only bookkeeping
+        return True
 
     # -- lower bound -----------------------------------------------------------------------------
     def elbo_parts(self):
@@ -602,7 +609,11 @@ class PCAPlan(object):
         raise AttributeError(name)
 
     def write(self, node, name, value):
-        raise NotImplementedError("assigning posteriors after the PCA graph is bound is not supported; set them before the first update()")
+        """Nothing is patched in place: the caller releases the plan and the graph is bound anew with the assignment."""
+        self.flush()
+        if node._plan is not self:
+            return node._plan.write(node, name, value)
+        return name not in ("qmu", "qcov", "qb", "qw")
 
     def elbo_parts(self):
         self.flush()

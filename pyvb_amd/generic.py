@@ -455,7 +455,7 @@ class GenericPlan(object):
             self._ensure_executor(self.temp_high)
             v = np.asarray(value, dtype=float).reshape(-1)
             self.ex.write(s[name].off, np.ascontiguousarray(np.broadcast_to(v, (s[name].size,))))
-        # other attributes (q_ln_det, qprec) are host-only bookkeeping
+        return True     # other attributes (q_ln_det, qprec) are host-only bookkeeping
 
     def pull(self):
         """Device state back into the nodes' host attributes (before the graph is re-bound)."""

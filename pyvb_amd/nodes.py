@@ -219,12 +219,21 @@ class _DeviceAttr(object):
         return obj.__dict__.get("_h_" + self.name)
 
     def __set__(self, obj, value):
-        plan = getattr(obj, "_plan", None)
-        if plan is not None and getattr(plan, "stale", False):
-            plan.release()              # device state back into the nodes first: the assignment below must win
+        # The assignment must win.  A bound plan either patches its device state (write() returns True) or gives the graph
+        # up: its state goes back into the nodes, the value is stored below, and the next use binds the graph anew.  A
+        # release can itself leave the graph with another plan (queued requests that only the node-by-node plan serves;
+        # sweeps among them that bring the fused plan back), bound from the OLD host value: hence the loop.
+        for _ in range(4):
+            plan = getattr(obj, "_plan", None)
+            if plan is None:
+                break
+            if getattr(plan, "stale", False):
+                plan.release()
+                continue
+            if plan.write(obj, self.name, value):
+                break
+            plan.release()
         obj.__dict__["_h_" + self.name] = value
-        if getattr(obj, "_plan", None) is not None:
-            obj._plan.write(obj, self.name, value)
 
 
 class Gaussian(Node):

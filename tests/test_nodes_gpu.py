@@ -319,3 +319,29 @@ def test_pca_rows_as_their_constructors_drew_them():
         assert abs(g["Beta"].qb - float(z[tag + "beta_b"])) <= RTOL * abs(float(z[tag + "beta_b"]))
         ref = z[tag + "elbo_parts"].sum()
         assert abs(net.llb - ref) <= RTOL * abs(ref)
+
+
+def test_assignment_wins_whatever_plan_the_queue_leaves_the_graph_with(monkeypatch):
+    """A re-observation while requests are still queued: flushing them hands the graph to the node-by-node plan (a lone
+    X_t.update()), the sweeps among them bring the fused plan back -- bound from the old observation -- and further lone updates
+    hand it over again.  The new observation must be what every later result is computed from (found by profiles/fuzz_ops.py)."""
+    from pyvb_amd import generic, _recognise
+
+    def run(Xs, As, Cs, Q, R, loop, Ys):
+        Xs[2].update(); [x.update() for x in reversed(Xs)]; loop(); Xs[3].update(); R.update()
+        Ys[5].observe(np.full((4, 1), 0.25))            # everything above is still queued on a fused plan
+        loop()
+        Ys[6].observe(np.full((4, 1), -0.5)); Xs[1].qmu = np.ones((3, 1))
+        loop()
+        return [x.qmu.copy() for x in Xs] + [np.asarray(R.qb).copy(), Ys[5].qmu.copy(), Ys[6].qmu.copy()]
+
+    def graph():
+        Xs, As, Cs, Q, R, loop = _small_lds(11)
+        Ys = [x.children[-1].children[0] if t == len(Xs) - 1 else [c for c in x.children if c.A.shape[0] == 4][0].children[0] for t, x in enumerate(Xs)]
+        return Xs, As, Cs, Q, R, loop, Ys
+    got = run(*graph())
+    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+    ref = run(*graph())
+    for g, r in zip(got, ref):
+        assert _rel(g, r) < 1e-9
+    assert _rel(got[-2], np.full((4, 1), 0.25)) == 0.0 and _rel(got[-1], np.full((4, 1), -0.5)) == 0.0
