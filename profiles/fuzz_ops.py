@@ -46,8 +46,9 @@ def build(seed, T, q, d, noise, Y, knowns):
 
 
 def ops_for(rng, T, q, d, n_ops, friendly):
-    kinds = ["x", "fwd", "bwd", "a", "c", "As", "Cs", "Q", "R", "read_x", "read_a", "read_q", "llb_x", "llb_y", "llb_a", "exxt", "reobs", "iter", "Ys", "y", "read_y"]
-    w = np.array([4, 3, 3, 2, 2, 2, 2, 2, 2, 3, 2, 2, 2, 1, 1, 1, 1, 3, 2, 1, 2], float)
+    kinds = ["x", "fwd", "bwd", "a", "c", "As", "Cs", "Q", "R", "read_x", "read_a", "read_q", "llb_x", "llb_y", "llb_a", "exxt", "reobs", "iter", "Ys", "y", "read_y",
+             "set_x", "set_a", "set_q", "learn"]
+    w = np.array([4, 3, 3, 2, 2, 2, 2, 2, 2, 3, 2, 2, 2, 1, 1, 1, 1, 3, 2, 1, 2, 1, 1, 1, 1], float)
     if friendly:        # what the fused plan serves without handing the graph to the generic one: no single-state updates
         w[0] = 0.0
     out = []
@@ -81,10 +82,37 @@ def apply(g, op):
     elif k == "exxt": return [Ys[t].mean_parent.pass_down_Ex(), Ys[t].mean_parent.pass_down_ExxT()]
     elif k == "reobs":
         if Ys[t].observed: Ys[t].observe(vec.reshape(-1, 1))
+    elif k == "set_x": Xs[t].qmu = np.resize(vec, Xs[t].shape).copy()
+    elif k == "set_a": As[i].qmu = np.resize(vec, As[i].shape).copy()
+    elif k == "set_q":
+        if not isinstance(g["Q"], nodes.Wishart): g["Q"].qb = (float(abs(vec[0])) + 0.5) if np.ndim(g["Q"].qb) == 0 else np.abs(np.resize(vec, np.shape(g["Q"].qb))) + 0.5
+    elif k == "learn":
+        from pyvb_amd import network
+        net = network.Network(); net.addnode(g["A"]); net.fetch_network(verbose=False)
+        net.learn(1 + t % 2, tol=-np.inf, verbose=False)
+        return [np.array(net.llb)]
     elif k == "Ys": [y.update() for y in Ys if not y.observed]
     elif k == "y": Ys[t].update()
     elif k == "read_y": return [Ys[t].qmu.copy(), np.diag(Ys[t].qcov).copy()]
     return None
+
+
+def diagnose(fused, slow):
+    """per-node lower-bound terms and posteriors of the two twins, largest differences first"""
+    rows = []
+    for key in ("Xs", "Ys", "As", "Cs"):
+        for i, (a, b) in enumerate(zip(fused[key], slow[key])):
+            with forced_generic():
+                lb = float(b.log_lower_bound()); mb = b.qmu.copy(); cb = b.qcov.copy()
+            la = float(a.log_lower_bound())
+            rows.append((abs(la - lb), "%s[%d] llb %.10g vs %.10g  dmu %.2e dcov %.2e" % (key, i, la, lb, np.abs(a.qmu - mb).max(), np.abs(a.qcov - cb).max())))
+    for key in ("Q", "R"):
+        with forced_generic():
+            lb = float(slow[key].log_lower_bound())
+        la = float(fused[key].log_lower_bound())
+        rows.append((abs(la - lb), "%s llb %.10g vs %.10g" % (key, la, lb)))
+    for d_, txt in sorted(rows, key=lambda r: -r[0])[:8]:
+        print("  diff %.3e  %s" % (d_, txt), flush=True)
 
 
 def main():
@@ -126,6 +154,8 @@ def main():
                     assert np.all(np.isfinite(u)), (case, n, op[0], u, v)
                     e = float(np.abs(u - v).max() / max(np.abs(v).max(), 1e-12))
                     err = max(err, e)
+                    if e >= 1e-7:
+                        diagnose(fused, slow)
                     assert e < 1e-7, "case %d op %d %s: rel err %.3e\nops so far: %s" % (case, n, op[0], e, [o[0] for o in ops[:n + 1]])
         kinds = (type(fused["Xs"][0]._plan).__name__, type(slow["Xs"][0]._plan).__name__)
         print("case %2d T=%2d q=%d d=%d %-14s knowns=%d plans=%s/%s  worst rel err %.2e" % (case, T, q, d, noise, knowns, kinds[0], kinds[1], err), flush=True)

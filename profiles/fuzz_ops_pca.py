@@ -34,6 +34,11 @@ def apply(g, op):
     elif k == "Xs": [x.update() for x in Xs]
     elif k == "mu": g["Mu"].update()
     elif k == "beta": g["Beta"].update()
+    elif k == "set_w": Ws[i].qmu = np.cos(np.arange(Ws[i].shape[0], dtype=float) + n).reshape(-1, 1)
+    elif k == "set_z": Zs[n].qmu = np.sin(np.arange(Zs[n].shape[0], dtype=float) + i).reshape(-1, 1)
+    elif k == "set_beta": g["Beta"].qb = 0.5 + (n % 7) / 3.0
+    elif k == "reobs":
+        if Xs[n].observed: Xs[n].observe(np.cos(np.arange(Xs[n].shape[0], dtype=float) * (i + 1)).reshape(-1, 1))
     elif k == "read_z": return [Zs[n].qmu.copy(), Zs[n].qcov.copy()]
     elif k == "read_x": return [Xs[n].qmu.copy(), np.diag(Xs[n].qcov).copy()]
     elif k == "read_w": return [Ws[i].qmu.copy(), Ws[i].qcov.copy(), g["Mu"].qmu.copy(), np.array(g["Beta"].qb)]
@@ -45,7 +50,7 @@ def apply(g, op):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    kinds = ["learn", "w", "Ws", "z", "Zs", "x", "Xs", "mu", "beta", "read_z", "read_x", "read_w", "llb"]
+    kinds = ["learn", "w", "Ws", "z", "Zs", "x", "Xs", "mu", "beta", "read_z", "read_x", "read_w", "llb", "set_w", "set_z", "set_beta", "reobs"]
     worst = 0.0
     for case in range(cases):
         N = int(rng.integers(4, 40)); d = int(rng.integers(2, 9)); q = int(rng.integers(1, min(d, 4) + 1))
@@ -57,7 +62,7 @@ def main():
             np.random.seed(seed)
             slow = G.pca_build_graph(pyvb_amd, dict(init), pri, explicit_x=explicit)
         friendly = rng.random() < 0.6
-        w = np.array([6 if friendly else 2, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2], float)
+        w = np.array([6 if friendly else 2, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 0.5, 0.5, 0.5, 0.5], float)
         if friendly:
             w[1:9] = 0.15
         ops = [(str(rng.choice(kinds, p=w / w.sum())), int(rng.integers(0, 1000)), int(rng.integers(0, 1000))) for _ in range(14)]

@@ -208,9 +208,9 @@ class LDSPlan(object):
             if name == "qcov" and self.kind == "wishart":
                 return c["A_cov" if kind == "a" else "C_cov"][i].copy()
             return np.diag(st[V][0, i]) if name == "qcov" else float(c[q][i])
-        if name == "qw":
+        if name == "qw" and self.kind == "wishart":
             return c["w"]["Q_w" if kind == "q" else "R_w"][0].copy()
-        if name == "qb":
+        if name == "qb" and self.kind != "wishart":
             v = st["Q_b" if kind == "q" else "R_b"][0]
             return float(v[0]) if self.kind == "gamma" else v.copy()
         raise AttributeError(name)
@@ -235,9 +235,17 @@ class LDSPlan(object):
             M, V = ("A_mean", "A_colvar") if kind == "a" else ("C_mean", "C_colvar")
             if name == "qmu":
                 st[M][0][:, i] = np.asarray(value).reshape(-1)
+                self.batch.set_state(**{M: st[M]})              # the mean alone: with Wishart noise the covariances are dense
+            elif self.kind == "wishart":
+                covs = list(self.batch.get_column_cov())
+                covs[0 if kind == "a" else 1][0, i] = np.asarray(value, dtype=float)
+                self.batch.set_column_cov(**{"A_cov" if kind == "a" else "C_cov": covs[0 if kind == "a" else 1]})
             else:
-                st[V][0, i] = np.diag(np.asarray(value))
-            self.batch.set_state(**{M: st[M], V: st[V]})
+                cov = np.asarray(value, dtype=float)
+                if np.abs(cov - np.diag(np.diag(cov))).max() != 0.0:
+                    return False                                # the fused kernels keep diagonal column covariances here
+                st[V][0, i] = np.diag(cov)
+                self.batch.set_state(**{V: st[V]})
         elif kind in ("q", "r") and name == "qw":
             v = np.asarray(value, dtype=float).reshape((1,) + node.shape)
             self.batch.set_wishart_state(**{"Q_w" if kind == "q" else "R_w": v})

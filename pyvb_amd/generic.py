@@ -441,10 +441,10 @@ class GenericPlan(object):
                 if np.isnan(v):
                     raise AttributeError("q_ln_det is set by the first update()")
                 return v
-        elif name == "qb":
+        elif name == "qb" and "qb" in s:
             v = self._read(s["qb"]).reshape(-1)
             return float(v[0]) if isinstance(node, N.Gamma) else v.copy()
-        elif name == "qw":
+        elif name == "qw" and "qw" in s:
             return self._read(s["qw"])
         raise AttributeError(name)
 

@@ -345,3 +345,37 @@ def test_assignment_wins_whatever_plan_the_queue_leaves_the_graph_with(monkeypat
     for g, r in zip(got, ref):
         assert _rel(g, r) < 1e-9
     assert _rel(got[-2], np.full((4, 1), 0.25)) == 0.0 and _rel(got[-1], np.full((4, 1), -0.5)) == 0.0
+
+
+def test_assigning_a_column_mean_keeps_the_dense_covariances_with_wishart_noise(monkeypatch):
+    """With Wishart noise the columns of A and C have dense covariances; assigning one column's mean must not touch them
+    (the write-back used to go through the diagonal form; found by profiles/fuzz_ops.py)."""
+    from pyvb_amd import nodes, generic, _recognise
+
+    def run():
+        np.random.seed(3)
+        T, q, d = 10, 3, 2
+        Y = np.random.randn(T, d)
+        As = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q) * 1e-3) for _ in range(q)]
+        Cs = [nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3) for _ in range(q)]
+        A, C = nodes.hstack(As), nodes.hstack(Cs)
+        Q, R = nodes.Wishart(q, q + 1e-3, np.eye(q) * 1e-3), nodes.Wishart(d, d + 1e-3, np.eye(d) * 1e-3)
+        Q.qw, R.qw = np.eye(q) * 0.7, np.eye(d) * 0.9
+        Xs = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q))]
+        Ys = [nodes.Gaussian(d, C * Xs[0], R)]
+        for t in range(1, T):
+            Xs.append(nodes.Gaussian(q, A * Xs[-1], Q)); Ys.append(nodes.Gaussian(d, C * Xs[-1], R))
+        for y, row in zip(Ys, Y):
+            y.observe(row.reshape(d, 1))
+        for _ in range(2):
+            [x.update() for x in Xs]; [x.update() for x in reversed(Xs)]; [a.update() for a in As]; [c.update() for c in Cs]; Q.update(); R.update()
+        As[0].qmu = np.array([[0.3], [-0.2], [0.1]])
+        As[1].update(); Q.update()
+        return [As[2].qcov.copy(), As[1].qmu.copy(), np.asarray(Q.qw).copy()], Xs[0]._plan
+    got, plan = run()
+    assert isinstance(plan, _recognise.LDSPlan)
+    assert np.abs(got[0] - np.diag(np.diag(got[0]))).max() > 0.0           # still dense
+    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+    ref, _ = run()
+    for g, r in zip(got, ref):
+        assert _rel(g, r) < 1e-9
