@@ -288,7 +288,7 @@ def _y_entropy_terms(st):
 # ----------------------------------------------------------------------------
 # hstack columns  (Gaussian.update for As[i] / Cs[i])
 # ----------------------------------------------------------------------------
-def _update_columns(M, Mcov, prior_mean, prior_prec, Lam, G, H, obs=None):
+def _update_columns(M, Mcov, prior_mean, prior_prec, Lam, G, H, obs=None, cols=None):
     """Gauss-Seidel over the columns i = 0..D-1 of an hstack.
     hstack.pass_up_m1_m2 nodes_todo.py:43-62:
       m1 = sum_t Lam <x x^T>[i,i]                          (:56)
@@ -303,7 +303,7 @@ def _update_columns(M, Mcov, prior_mean, prior_prec, Lam, G, H, obs=None):
     N, rows, D = M.shape
     qld = np.full((N, D), np.nan)
     LH = np.einsum("nkl,nli->nki", Lam, H)
-    for i in range(D):
+    for i in (range(D) if cols is None else range(*cols)):          # cols = (first, last + 1): [a.update() for a in As[first:last + 1]]
         known = None if obs is None else ~np.isnan(obs[:, i])
         if known is not None and known.all():
             continue
@@ -338,21 +338,23 @@ def observe_columns(st, which, obs):
             Mcov[:, i] = 0.0
 
 
-def update_A(st, pri, S):
+def update_A(st, pri, S, cols=None):
     """[a.update() for a in As]  (Linear_Dynamic_System.py:74).  Children of the
     hstack A are Mult(A, X_t), t = 0..T-2, whose own children X_{t+1} send
     (<Q>, <Q> qmu_{t+1})."""
     Qb = noise_expect(pri["noise"], st["Q_a"], st["Q_b"], st["A_mean"].shape[1])
-    st["qld_A"] = _update_columns(st["A_mean"], st["A_cov"], pri["A_prior_mean"],
-                                  pri["A_prior_prec"], Qb, S["Sxx_m"], S["Sx1x"], pri.get("A_obs"))
+    qld = _update_columns(st["A_mean"], st["A_cov"], pri["A_prior_mean"],
+                          pri["A_prior_prec"], Qb, S["Sxx_m"], S["Sx1x"], pri.get("A_obs"), cols)
+    st["qld_A"] = qld if cols is None or "qld_A" not in st else np.where(np.isnan(qld), st["qld_A"], qld)
 
 
-def update_C(st, pri, S):
+def update_C(st, pri, S, cols=None):
     """[c.update() for c in Cs]  (:75).  Children Mult(C, X_t), t = 0..T-1; the
     observed Y_t send (<R>, <R> y_t)."""
     Rb = noise_expect(pri["noise"], st["R_a"], st["R_b"], st["C_mean"].shape[1])
-    st["qld_C"] = _update_columns(st["C_mean"], st["C_cov"], pri["C_prior_mean"],
-                                  pri["C_prior_prec"], Rb, S["Sxx"], S["Syx"], pri.get("C_obs"))
+    qld = _update_columns(st["C_mean"], st["C_cov"], pri["C_prior_mean"],
+                          pri["C_prior_prec"], Rb, S["Sxx"], S["Syx"], pri.get("C_obs"), cols)
+    st["qld_C"] = qld if cols is None or "qld_C" not in st else np.where(np.isnan(qld), st["qld_C"], qld)
 
 
 # ----------------------------------------------------------------------------

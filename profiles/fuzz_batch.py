@@ -1,0 +1,76 @@
+"""Random update orders through the C ABI (LDSBatch) against the oracle: sweeps in either direction any number of times, the
+sweep written out as T single pyvb_lds_update_x calls, column updates over random ranges, noise updates, the lower bound --
+in any order after the first sweep.      python profiles/fuzz_batch.py [cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pyvb_amd import synth
+from pyvb_amd.lds import LDSBatch
+from oracle import lds_closed_form as O
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    worst = 0.0
+    for case in range(cases):
+        T = int(rng.choice([2, 3, 5, 17, 40, 130, 600])); D = int(rng.integers(1, 20)); K = int(rng.integers(1, 20)); N = int(rng.integers(1, 4))
+        if rng.random() < 0.15:
+            D, K = int(rng.choice([33, 64])), int(rng.choice([48, 64]))
+        kind = str(rng.choice(["diagonal_gamma", "gamma", "wishart"], p=[0.5, 0.25, 0.25]))
+        Y, st0, pri = synth.make_problem(T, D, K, N, seed=int(rng.integers(1 << 30)))
+        pri["noise"] = kind
+        if kind == "gamma":
+            for k in ("Q_a0", "Q_b0", "R_a0", "R_b0"):
+                pri[k] = np.float64(1e-3)
+        if kind == "wishart":       # proper priors: v0 > (dim - 1) / 2, dense w0
+            W = rng.standard_normal((D, D)); pri["Q_b0"] = 0.05 * (W @ W.T + D * np.eye(D)); pri["Q_a0"] = np.float64(0.5 * D + 1.0)
+            W = rng.standard_normal((K, K)); pri["R_b0"] = 0.05 * (W @ W.T + K * np.eye(K)); pri["R_a0"] = np.float64(0.5 * K + 0.5)
+        b = LDSBatch.from_problem(Y, st0, pri)
+        st = O.expand_state(st0, pri, T)
+        ops = ["fwd" if rng.random() < 0.7 else "bwd"] + [str(rng.choice(["fwd", "bwd", "xs", "A", "C", "Acols", "Ccols", "Q", "R", "elbo"],
+                                                                         p=[.14, .14, .08, .1, .1, .12, .12, .08, .08, .04])) for _ in range(14)]
+        err = 0.0
+        for op in ops:
+            if op in ("fwd", "bwd"):
+                O.sweep(st, pri, Y, "forward" if op == "fwd" else "backward"); b.sweep("forward" if op == "fwd" else "backward")
+            elif op == "xs":
+                for t in range(T):
+                    O.update_x(st, pri, Y, t); b.update_x(t)
+            elif op in ("A", "C", "Acols", "Ccols"):
+                S = O.statistics(st, Y)
+                cols = None
+                if op.endswith("cols"):
+                    c0 = int(rng.integers(0, D)); cols = (c0, int(rng.integers(c0 + 1, D + 1)))
+                (O.update_A if op[0] == "A" else O.update_C)(st, pri, S, cols)
+                b.update_columns(op[0], *(cols or (0, D)))
+            elif op in ("Q", "R"):
+                S = O.statistics(st, Y)
+                (O.update_Q if op == "Q" else O.update_R)(st, pri, S, T); (b.update_Q if op == "Q" else b.update_R)()
+            elif op == "elbo":
+                if "qld_A" not in st or np.isnan(st["qld_A"]).any() or np.isnan(st["qld_C"]).any():
+                    continue                # a column without q_ln_det yet: the reference raises AttributeError
+                parts = O.elbo_parts(st, pri, O.statistics(st, Y), T)
+                got = b.elbo()
+                err = max(err, rel(got.sum(1), parts.sum(1)))
+            g = b.get_state()
+            err = max(err, rel(g["X"], st["X"]), rel(g["A_mean"], st["A_mean"]), rel(g["C_mean"], st["C_mean"]))
+            if kind == "wishart":
+                w = b.get_wishart_state()
+                err = max(err, rel(w["Q_w"], st["Q_b"]), rel(w["R_w"], st["R_b"]))
+            else:
+                err = max(err, rel(g["Q_b"], np.broadcast_to(np.asarray(st["Q_b"]).reshape(N, -1), g["Q_b"].shape)),
+                          rel(g["R_b"], np.broadcast_to(np.asarray(st["R_b"]).reshape(N, -1), g["R_b"].shape)))
+            assert err < 1e-7, "case %d (%s T=%d D=%d K=%d N=%d) after %s of %s: rel err %.3e" % (case, kind, T, D, K, N, op, ops, err)
+        b.close()
+        print("case %2d %-14s T=%3d D=%2d K=%2d N=%d  %s  worst %.2e" % (case, kind, T, D, K, N, " ".join(ops), err), flush=True)
+        worst = max(worst, err)
+    print("worst", worst)
+
+
+if __name__ == "__main__":
+    main()
