@@ -273,6 +273,114 @@ def wishart_precision(nodes, rng):
     return [Mu, Lam], named
 
 
+def random_graph(nodes, rng):
+    """A random composition of the building blocks the scenarios above use one at a time -- vector means with Gamma /
+    DiagonalGamma / Constant precisions, sums of two or three terms, column x scalar products (+ offset), hstack matrix x
+    latent vector (+ offset), DiagonalGaussian scalings, scalar regressions on Constant inputs -- with dimensions, counts,
+    priors, observation patterns (full / partial / none) and the update order drawn from rng; variable nodes are shared between
+    blocks.  Wishart precisions are left out (only their first update is a reference target)."""
+    named, order, pool = {}, [], {}
+
+    def label(prefix):
+        k = "%s%02d" % (prefix, sum(1 for x in named if x.startswith(prefix)))
+        return k
+
+    def gauss(d, prefix="g", share=True):
+        n = nodes.Gaussian(d, rng.standard_normal((d, 1)) * 0.3, np.eye(d) * 10 ** rng.uniform(-3, 0))
+        named[label(prefix)] = n
+        order.append(n)
+        if share:
+            pool.setdefault(d, []).append(n)
+        return n
+
+    def term(d):
+        have = pool.get(d, [])
+        return have[int(rng.integers(len(have)))] if have and rng.random() < 0.5 else gauss(d)
+
+    def precision(d):
+        r = rng.random()
+        if r < 0.3:
+            return np.eye(d) * 10 ** rng.uniform(-0.5, 1.5)
+        if r < 0.65 or d == 1:
+            n = nodes.Gamma(d, 10 ** rng.uniform(-3, -1), 10 ** rng.uniform(-3, -1))
+        else:
+            n = nodes.DiagonalGamma(d, np.full(d, 10 ** rng.uniform(-3, -1)), np.full(d, 10 ** rng.uniform(-3, -1)))
+        named[label("p")] = n
+        order.append(n)
+        return n
+
+    def child(d, mean, prec, value):
+        y = nodes.Gaussian(d, mean, prec)
+        named[label("y")] = y
+        r = rng.random()
+        if r < 0.65:
+            y.observe(value.reshape(d, 1).copy())
+        elif r < 0.85 and d > 1:
+            v = value.reshape(d, 1).copy()
+            miss = rng.random(d) < 0.5
+            miss[int(rng.integers(d))] = True; miss[int((np.nonzero(miss)[0][0] + 1) % d)] = False
+            v[miss] = np.nan
+            y.observe(v)
+            order.append(y)
+        else:
+            order.append(y)          # a latent leaf: its update sees the parents only
+        return y
+
+    for _ in range(int(rng.integers(2, 5))):
+        kind = str(rng.choice(["mean", "sum", "colscalar", "matrix", "diag", "regression"], p=[.25, .2, .2, .15, .1, .1]))
+        d = int(rng.integers(1, 5))
+        if kind == "mean":
+            mu, p = term(d), precision(d)
+            for _i in range(int(rng.integers(2, 8))):
+                child(d, mu, p, rng.standard_normal(d) + 1.0)
+        elif kind == "sum":
+            ts = [term(d) for _i in range(int(rng.integers(2, 4)))]
+            if len(set(id(t) for t in ts)) < len(ts):
+                ts = [gauss(d) for _i in ts]
+            m = ts[0] + ts[1]
+            for t in ts[2:]:
+                m = m + t
+            child(d, m, precision(d), rng.standard_normal(d) * 3)
+        elif kind == "colscalar":
+            w, p = gauss(d, "w", share=False), precision(d)
+            off = term(d) if rng.random() < 0.5 else None
+            for _i in range(int(rng.integers(2, 6))):
+                z = nodes.Gaussian(1, np.zeros((1, 1)), np.eye(1))
+                named[label("z")] = z
+                order.append(z)
+                m = nodes.Multiplication(w, z)
+                child(d, m + off if off is not None else m, p, rng.standard_normal(d))
+        elif kind == "matrix":
+            d = max(d, 2); q = int(rng.integers(2, 4))
+            cols = [gauss(d, "c", share=False) for _i in range(q)]
+            W = nodes.hstack(cols)
+            p = precision(d)
+            off = term(d) if rng.random() < 0.5 else None
+            for _i in range(int(rng.integers(2, 6))):
+                z = nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q))
+                named[label("z")] = z
+                order.append(z)
+                m = W * z
+                child(d, m + off if off is not None else m, p, rng.standard_normal(d))
+        elif kind == "diag":
+            S = nodes.DiagonalGaussian(d, np.ones((d, 1)), np.eye(d) * 4.0)
+            named[label("S")] = S
+            B = gauss(d)
+            y = nodes.Gaussian(d, S * B, np.eye(d) * 10 ** rng.uniform(0, 1.5))
+            named[label("y")] = y
+            y.observe(rng.standard_normal((d, 1)))
+        else:
+            A, B, p = term(1), term(1), precision(1)
+            if A is B:
+                B = gauss(1)
+            for _i in range(int(rng.integers(3, 9))):
+                x = nodes.Constant(rng.standard_normal((1, 1)))
+                child(1, x * A + B, p, rng.standard_normal(1))
+    _init_all(named, rng)
+    order = [order[i] for i in rng.permutation(len(order))]
+    return order, named
+
+
 # name -> (builder, seed, iterations after which the state is recorded, messages to record as (node label, requester label))
 SCENARIOS = {
     "simple_mean_inference": (simple_mean_inference, 101, (1, 2), [("y03", "mu")]),
@@ -290,6 +398,12 @@ SCENARIOS = {
     "diagonal_gaussian_scaling": (diagonal_gaussian_scaling, 113, (1, 2), [("C", "B")]),
     "lds_network_crawl": (lds_network_crawl, 114, (1, 3), []),
 }
+
+# random compositions (random_graph): the seeds the reference itself runs cleanly -- 1027 and 1043 of the first forty-odd make it
+# raise ("setting an array element with a sequence": a sum of messages of different shapes) and are left out
+RANDOM_SEEDS = [s for s in range(1000, 1044) if s not in (1027, 1043)][:30]
+for _s in RANDOM_SEEDS:
+    SCENARIOS["random_%d" % _s] = (random_graph, _s, (1, 2), [])
 
 # scenarios whose graph binds to a fused plan first (needs the GPU even though they end up node by node)
 NEEDS_DEVICE = ("lds_parameters_first", "lds_network_crawl")
