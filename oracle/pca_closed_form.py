@@ -132,7 +132,10 @@ def elbo_parts(st, pri):
     none = nmiss == d
     Vm = np.where(st["obs"], 1.0, st["X_var"])
     LX -= np.sum(0.5 * nmiss[part] * LN2PI - 0.5 * np.log(Vm[part]).sum(1) - 0.5 * nmiss[part])    # gaussian.py:148-150
-    LX += none.sum() * (0.5 * d * LN2PI + 0.5 * st["qld_X"] + 0.5 * d) if none.any() else 0.0       # :145-147
+    if none.any():      # :145-147; each latent row keeps the q_ln_det of ITS last update: qprec = <beta> I then, qcov = I / <beta>
+        with np.errstate(divide="ignore"):
+            qld_rows = 0.5 / (0.5 * d * np.log(1.0 / st["X_var"][none, 0]))
+        LX += none.sum() * (0.5 * d * LN2PI + 0.5 * d) + 0.5 * qld_rows.sum()
     # Z_n against Constant(0), Constant(I)
     m = _moments(st)
     LZ = N * (-0.5 * q * LN2PI) - 0.5 * np.trace(m["Szz"]) + N * (0.5 * q * LN2PI + 0.5 * st["qld_Z"] + 0.5 * q)

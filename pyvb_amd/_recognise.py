@@ -66,6 +66,7 @@ class LDSPlan(object):
         self.cache = None
         self.stale = False              # set when a node of the graph gains a child or an observation after binding
         self.x_updated = False
+        self.ran = False                # anything at all has run on the device (the outputs can update before any sweep)
         self.n_random_nodes = 2 * self.T + 2 * self.D + 2
         for n in _component(Xs[0]):         # the operation nodes and Constants too: their messages go through mirror()
             n._plan = self
@@ -95,12 +96,13 @@ class LDSPlan(object):
                     b.sweep("backward"); i += T
                 else:
                     return self._demote(ops[i:])
-                self.x_updated = True
+                self.x_updated = self.ran = True
             elif kind == "y":           # [y.update() for y in Ys if not y.observed]: all of them, in order, or node by node
                 run = [o[1] for o in ops[i:i + len(self.free_ys)] if o[0] == "y"]
                 if run != self.free_ys:
                     return self._demote(ops[i:])
                 b.update_Y(); i += len(run)
+                self.ran = True
             elif kind in ("a", "c", "q", "r"):
                 if not self.x_updated:
                     return self._demote(ops[i:])
@@ -119,7 +121,7 @@ class LDSPlan(object):
 
     def _sync_host(self):
         """Current device posteriors into the nodes' host attributes."""
-        if not self.x_updated:
+        if not self.ran:
             return              # nothing has run: the host attributes are the state
         self._pull()
         for nd in self.Xs + self.As + self.Cs + [self.Ys[t] for t in self.free_ys]:
@@ -634,11 +636,10 @@ class PCAPlan(object):
         if node._plan is not self:
             return node._plan.node_llb(node)
         kind, _ = self.index[id(node)]
-        parts = self.elbo_parts()
-        if kind == "mu":
-            return float(parts[3])
         if kind == "beta":
-            return float(parts[4])
+            return float(self.elbo_parts()[4])
+        # single Gaussian nodes: the fused kernels form class sums (and keep Mu's q_ln_det only from its last update on THIS
+        # handle: a graph bound anew has it on the host), so the term comes from the generic tape path on a mirror of the state
         return self.mirror().node_llb(node)
 
     def _sync_host(self):

@@ -264,6 +264,7 @@ static int full_stats(pyvb_pca* h, long lo_upd, long hi_upd) {
     if ((rc = pca_launch_reduce(h, 0))) return rc;
     if (h->comm && (rc = pyvb_allreduce_f64(h->comm, h->stats, h->SL.total, h->stream))) return rc;
     h->full_valid = h->lin_valid = true;
+    if (hi_upd > lo_upd) h->res_valid = false;          // rows changed: the cached residual of the last Beta update is stale
     return PYVB_OK;
 }
 static int ensure_full(pyvb_pca* h) { return h->full_valid ? PYVB_OK : full_stats(h, 0, 0); }

@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) k_pca_rowvar(PcaArgs a) {
     const long r0 = (long)blockIdx.x * a.chunk_rows;
     const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
     const double var_new = a.scal[PS_BETA_B] / a.scal[PS_BETA_A];
-    double sxv = 0.0, slv = 0.0;
+    double sxv = 0.0, slv = 0.0, sql = 0.0;
     for (long row = r0 + threadIdx.x; row < r1; row += 256) {
         const int nm = a.nmiss[row];
         double v = a.xvar[row];
@@ -283,10 +283,11 @@ __global__ void __launch_bounds__(256) k_pca_rowvar(PcaArgs a) {
         } else if (a.pinned && !a.pinned[row]) cnt = a.d;       // not updated yet: the initial covariance v I on all entries
         sxv += cnt * v;
         if (nm > 0 && nm < a.d) slv += nm * log(v);
+        if (nm == a.d) sql += 0.5 / (0.5 * a.d * log(1.0 / v));     // a latent row: qprec = I / v (gaussian.py:120, quirk Q1)
     }
     double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
-    sxv = bsum(sxv, red); slv = bsum(slv, red);
-    if (threadIdx.x == 0) { P[a.SL.osxv] = sxv; P[a.SL.oslv] = slv; }
+    sxv = bsum(sxv, red); slv = bsum(slv, red); sql = bsum(sql, red);
+    if (threadIdx.x == 0) { P[a.SL.osxv] = sxv; P[a.SL.oslv] = slv; P[a.SL.osql] = sql; }
 }
 
 // sum the per-chunk partials in two deterministic stages (no atomics: results must not depend on timing)
@@ -535,7 +536,7 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         // X_n (gaussian.py:136-151)
         double LX = N * (-0.5 * d * LN2PI + 0.5 * lnd_beta) - 0.5 * beta * res;
         LX -= 0.5 * (double)a.n_part_missing * LN2PI - 0.5 * S[a.SL.oslv] - 0.5 * (double)a.n_part_missing;
-        if (a.n_none_rows > 0) LX += (double)a.n_none_rows * (0.5 * d * LN2PI + 0.5 * a.scal[PS_QLD_X] + 0.5 * d);
+        if (a.n_none_rows > 0) LX += (double)a.n_none_rows * (0.5 * d * LN2PI + 0.5 * d) + 0.5 * S[a.SL.osql];
         // Z_n against Constant(0), Constant(I)
         double tr = 0.0;
         if (tid < q) tr = S[a.SL.oSzz + (size_t)tid * QP + tid] + N * a.Z_cov[tid * q + tid];

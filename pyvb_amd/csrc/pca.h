@@ -7,15 +7,17 @@
 //   Sxz [DP][QP]  sum x_n z_n^T           sx [DP]  sum x_n           sz [QP]  sum z_n
 //   sxx           sum ||x_n||^2           sxv      sum_n (#missing_n * var_n)
 //   slv           sum over partially observed rows of #missing_n * log(var_n)
+//   sql           sum over rows without any observation of their q_ln_det = 0.5 / (d/2 log(1 / var_n))   (quirk Q1; each row
+//                 keeps the <beta> of ITS last update)
 struct PcaStatsLayout {
     int DP, QP;
-    size_t oSzz, oSxz, osx, osz, osxx, osxv, oslv, total;
+    size_t oSzz, oSxz, osx, osz, osxx, osxv, oslv, osql, total;
 };
 static inline PcaStatsLayout pca_stats_layout(int DP, int QP) {
     PcaStatsLayout L; L.DP = DP; L.QP = QP;
     size_t o = 0;
     L.oSzz = o; o += (size_t)QP * QP; L.oSxz = o; o += (size_t)DP * QP; L.osx = o; o += DP; L.osz = o; o += QP;
-    L.osxx = o++; L.osxv = o++; L.oslv = o++;
+    L.osxx = o++; L.osxv = o++; L.oslv = o++; L.osql = o++;
     L.total = (o + 7) & ~(size_t)7;
     return L;
 }
