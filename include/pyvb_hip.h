@@ -211,6 +211,11 @@ int pyvb_pca_get_state(pyvb_pca* h, double* X, double* X_rowvar, double* W_mean,
 int pyvb_pca_update_W(pyvb_pca* h);
 int pyvb_pca_update_Z(pyvb_pca* h);
 int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi);
+/* Xs[0].update() of the GLOBAL row 0 (the crawl order updates it alone, before Mu).  With a communicator attached every update
+ * call is a collective: all ranks issue the same calls in the same order, pyvb_pca_update_X with their local part of the range
+ * (possibly empty).  This one is the single-row step for every rank: the owner of global row 0 updates it, all ranks exchange
+ * the change of sum x.  (On one rank it is pyvb_pca_update_X(h, 0, 1).) */
+int pyvb_pca_update_X0(pyvb_pca* h);
 int pyvb_pca_update_Mu(pyvb_pca* h);
 int pyvb_pca_update_Beta(pyvb_pca* h);
 /* sum of log_lower_bound() per node class: parts[5] = W columns, Z_n, X_n, Mu, Beta (NULL: leave on the device) */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "pyvb_pca_update_W": (ctypes.c_int, [_h]),
     "pyvb_pca_update_Z": (ctypes.c_int, [_h]),
     "pyvb_pca_update_X": (ctypes.c_int, [_h, ctypes.c_long, ctypes.c_long]),
+    "pyvb_pca_update_X0": (ctypes.c_int, [_h]),
     "pyvb_pca_update_Mu": (ctypes.c_int, [_h]),
     "pyvb_pca_update_Beta": (ctypes.c_int, [_h]),
     "pyvb_pca_elbo": (ctypes.c_int, [_h, _dp]),

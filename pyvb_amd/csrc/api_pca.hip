@@ -327,6 +327,11 @@ int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi) {
     return x_rows(h, lo, hi);
 }
 
+int pyvb_pca_update_X0(pyvb_pca* h) {
+    ENTER(h);
+    return x0_step(h);
+}
+
 int pyvb_pca_update_Mu(pyvb_pca* h) {
     ENTER(h);
     int rc;

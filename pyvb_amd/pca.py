@@ -96,6 +96,10 @@ class PCABatch(object):
     def update_X(self, lo=0, hi=None):
         C.check(C.lib.pyvb_pca_update_X(self._h, int(lo), int(self.N if hi is None else hi)))
 
+    def update_X0(self):
+        """Xs[0].update() of the global row 0; with a communicator the collective single-row step of every rank."""
+        C.check(C.lib.pyvb_pca_update_X0(self._h))
+
     def update_Mu(self):
         C.check(C.lib.pyvb_pca_update_Mu(self._h))
 

@@ -1,7 +1,7 @@
 """One rank of the multi-rank rehearsal on ONE GPU (tests/test_multirank_gpu.py): the library's collectives travel through
 the host transport (pyvb_*_comm_init_host over pyvb_amd.dist.SocketComm) because RCCL refuses several ranks on one device.
 
-    python tests/multirank_worker.py {pca|lds|pcabig} RANK WORLD OUT_PREFIX [N d q]
+    python tests/multirank_worker.py {pca|lds|pcabig|pcafuzz} RANK WORLD OUT_PREFIX [N d q | seed]
 """
 import importlib.util
 import os
@@ -40,6 +40,54 @@ def pca_rank(rank, world, comm):
     b.iterate(ITERS)
     st = b.get_state()
     st["elbo"] = b.elbo()
+    st["rows"] = np.array([lo, hi])
+    b.close()
+    return st
+
+
+def pca_ops(seed, N):
+    """A random sequence of update calls in GLOBAL terms; every rank issues the same calls, row ranges cut to its shard."""
+    rng = np.random.default_rng(seed)
+    ops = []
+    for _ in range(16):
+        k = str(rng.choice(["W", "Z", "X", "Xall", "X0", "Mu", "Beta", "elbo"], p=[.15, .15, .2, .1, .1, .12, .12, .06]))
+        lo = int(rng.integers(0, N)); hi = int(rng.integers(lo, N + 1))
+        ops.append((k, lo, hi))
+    return ops
+
+
+def pca_fuzz_rank(rank, world, comm, seed):
+    from pyvb_amd.pca import PCABatch
+    N, d, q, _ = PCA_SHAPE
+    init, pri = _golden().pca_problem(N, d, q, seed, p_missing=0.2)
+    lo, hi = dist.shard_range(N, rank, world)
+    b = PCABatch(hi - lo, d, q, device=0, N_total=N, row_offset=lo)
+    if world > 1:
+        b.comm_init_host(comm, rank, world)
+    b.set_priors(pri)
+    b.set_data(np.where(init["obs"], init["X"], np.nan)[lo:hi])
+    b.set_state(X_missing=init["X"][lo:hi], W_mean=init["W_mean"], Z=init["Z"][lo:hi], Z_cov=init["Z_cov"],
+                Mu_mean=init["Mu_mean"], beta_b=float(init["beta_b"]))
+    elbos = []
+    b.iterate(1)                                # every node has been updated once: the bound is defined from here on
+    for k, glo, ghi in pca_ops(seed, N):
+        if k == "W": b.update_W()
+        elif k == "Z": b.update_Z()
+        elif k == "X0": b.update_X0()
+        elif k in ("X", "Xall"):
+            if k == "Xall":
+                glo, ghi = 0, N
+            a, e = min(max(glo, lo), hi) - lo, min(max(ghi, lo), hi) - lo
+            if (glo, ghi) == (0, 1):
+                b.update_X0()
+            else:
+                b.update_X(a, max(a, e))
+        elif k == "Mu": b.update_Mu()
+        elif k == "Beta": b.update_Beta()
+        else: elbos.append(b.elbo())
+    st = b.get_state()
+    st["elbo"] = b.elbo()
+    st["elbos"] = np.array(elbos).reshape(-1, 5)
     st["rows"] = np.array([lo, hi])
     b.close()
     return st
@@ -106,7 +154,9 @@ def lds_rank(rank, world, comm):
 if __name__ == "__main__":
     what, rank, world, prefix = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     comm = dist.SocketComm(world, rank) if world > 1 else dist.LocalComm()
-    if what == "pcabig":
+    if what == "pcafuzz":
+        res = pca_fuzz_rank(rank, world, comm, int(sys.argv[5]))
+    elif what == "pcabig":
         res = pca_big_rank(rank, world, comm, *[int(x) for x in sys.argv[5:8]])
     else:
         res = (pca_rank if what == "pca" else lds_rank)(rank, world, comm)

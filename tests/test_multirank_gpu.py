@@ -48,6 +48,19 @@ def test_pca_rows_sharded_over_ranks(world, tmp_path):
         assert _rel(np.concatenate([m[k] for m in many]), one[k]) < 1e-10, k
 
 
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_pca_random_update_orders_over_three_ranks(seed, tmp_path):
+    """Every update call is a collective when a communicator is attached: the same random sequence of calls (row ranges cut
+    to each rank's shard, possibly empty; the single-row step through pyvb_pca_update_X0) on three ranks and on one."""
+    one = _run("pcafuzz", 1, tmp_path, 29700 + seed, (seed,))[0]
+    many = _run("pcafuzz", 3, tmp_path, 29710 + seed, (seed,))
+    for m in many:
+        for k in ("W_mean", "W_var", "Mu_mean", "Mu_var", "Z_cov", "beta_ab", "elbo", "elbos"):
+            assert m[k].shape == one[k].shape and (m[k].size == 0 or _rel(m[k], one[k]) < 1e-9), (k, m[k], one[k])
+    for k in ("X", "Z", "X_rowvar"):
+        assert _rel(np.concatenate([m[k] for m in many]), one[k]) < 1e-9, k
+
+
 def test_lds_replicates_sharded_over_ranks(tmp_path):
     one = _run("lds", 1, tmp_path, 29640)[0]
     many = _run("lds", 2, tmp_path, 29650)
