@@ -276,7 +276,7 @@ def wishart_precision(nodes, rng):
 def random_graph(nodes, rng):
     """A random composition of the building blocks the scenarios above use one at a time -- vector means with Gamma /
     DiagonalGamma / Constant precisions, sums of two or three terms, column x scalar products (+ offset), hstack matrix x
-    latent vector (+ offset), DiagonalGaussian scalings, scalar regressions on Constant inputs -- with dimensions, counts,
+    latent vector (+ offset), DiagonalGaussian scalings, scalar regressions on Constant inputs, short linear dynamical systems -- with dimensions, counts,
     priors, observation patterns (full / partial / none) and the update order drawn from rng; variable nodes are shared between
     blocks.  Wishart precisions are left out (only their first update is a reference target)."""
     named, order, pool = {}, [], {}
@@ -327,7 +327,7 @@ def random_graph(nodes, rng):
         return y
 
     for _ in range(int(rng.integers(2, 5))):
-        kind = str(rng.choice(["mean", "sum", "colscalar", "matrix", "diag", "regression"], p=[.25, .2, .2, .15, .1, .1]))
+        kind = str(rng.choice(["mean", "sum", "colscalar", "matrix", "diag", "regression", "chain"], p=[.22, .17, .17, .14, .08, .08, .14]))
         d = int(rng.integers(1, 5))
         if kind == "mean":
             mu, p = term(d), precision(d)
@@ -369,6 +369,28 @@ def random_graph(nodes, rng):
             y = nodes.Gaussian(d, S * B, np.eye(d) * 10 ** rng.uniform(0, 1.5))
             named[label("y")] = y
             y.observe(rng.standard_normal((d, 1)))
+        elif kind == "chain":           # a short linear dynamical system: hstack transition matrix, outputs through a second one or direct
+            D = max(d, 2); T = int(rng.integers(3, 6))
+            As = [gauss(D, "a", share=False) for _i in range(D)]
+            A = nodes.hstack(As)
+            Q = precision(D)
+            xs = [gauss(D, "x")]
+            for _t in range(1, T):
+                x = nodes.Gaussian(D, A * xs[-1], Q)
+                named[label("x")] = x
+                order.append(x)
+                pool.setdefault(D, []).append(x)
+                xs.append(x)
+            if rng.random() < 0.5:
+                K = int(rng.integers(2, 5))
+                Cs = [gauss(K, "c", share=False) for _i in range(D)]
+                C, R = nodes.hstack(Cs), precision(K)
+                for x in xs:
+                    child(K, C * x, R, rng.standard_normal(K))
+            else:
+                R = precision(D)
+                for x in xs:
+                    child(D, x, R, rng.standard_normal(D))
         else:
             A, B, p = term(1), term(1), precision(1)
             if A is B:
@@ -399,9 +421,10 @@ SCENARIOS = {
     "lds_network_crawl": (lds_network_crawl, 114, (1, 3), []),
 }
 
-# random compositions (random_graph): the seeds the reference itself runs cleanly -- 1027 and 1043 of the first forty-odd make it
-# raise ("setting an array element with a sequence": a sum of messages of different shapes) and are left out
-RANDOM_SEEDS = [s for s in range(1000, 1044) if s not in (1027, 1043)][:30]
+# random compositions (random_graph): the first thirty-six seeds from 1000 on; the reference runs all of them cleanly (of the
+# first seventy, 1063 makes it raise "setting an array element with a sequence": numpy no longer sums messages of different
+# shapes)
+RANDOM_SEEDS = list(range(1000, 1036))
 for _s in RANDOM_SEEDS:
     SCENARIOS["random_%d" % _s] = (random_graph, _s, (1, 2), [])
 
