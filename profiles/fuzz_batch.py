@@ -31,13 +31,27 @@ def main():
         if kind == "wishart":       # proper priors: v0 > (dim - 1) / 2, dense w0
             W = rng.standard_normal((D, D)); pri["Q_b0"] = 0.05 * (W @ W.T + D * np.eye(D)); pri["Q_a0"] = np.float64(0.5 * D + 1.0)
             W = rng.standard_normal((K, K)); pri["R_b0"] = 0.05 * (W @ W.T + K * np.eye(K)); pri["R_a0"] = np.float64(0.5 * K + 0.5)
-        ops = ["fwd" if rng.random() < 0.7 else "bwd"] + [str(rng.choice(["fwd", "bwd", "xs", "A", "C", "Acols", "Ccols", "Q", "R", "elbo"],
-                                                                         p=[.14, .14, .08, .1, .1, .12, .12, .08, .08, .04])) for _ in range(14)]
+        missing = kind != "wishart" and rng.random() < 0.35
+        knowns = kind != "wishart" and rng.random() < 0.3
+        if missing:         # outputs with missing entries are nodes of their own (op "Y": [y.update() for y in Ys if not y.observed])
+            mask = rng.random((N, T, K)) < rng.choice([0.05, 0.3, 0.9])
+            if T > 2:
+                mask[:, 1] = True
+            Y = np.where(mask, np.nan, Y)
+            st0["Yq"] = rng.standard_normal((N, T, K)); st0["Yrowvar"] = 1.0 / rng.uniform(0.5, 1.5, size=(N, T))
+        if knowns:          # known entries of A and C (examples/LDS_knowns_in_A.py:73-74)
+            A_obs = np.where(rng.random((D, D)) < 0.2, rng.standard_normal((D, D)), np.nan)
+            C_obs = np.where(rng.random((K, D)) < 0.2, rng.standard_normal((K, D)), np.nan)
+            if D > 1:
+                C_obs[:, 0] = rng.standard_normal(K)        # a fully known column
+            pri["A_obs"], pri["C_obs"] = A_obs, C_obs
+        ops = ["fwd" if rng.random() < 0.7 else "bwd"] + [str(rng.choice(["fwd", "bwd", "xs", "A", "C", "Acols", "Ccols", "Q", "R", "elbo", "Y"],
+                                                                         p=[.13, .13, .07, .1, .1, .11, .11, .08, .08, .04, .05])) for _ in range(14)]
         ranges = [(lambda c0: (c0, int(rng.integers(c0 + 1, D + 1))))(int(rng.integers(0, D))) for _ in ops]
         if only is not None and case != only:
             continue
         b = LDSBatch.from_problem(Y, st0, pri)
-        st = O.expand_state(st0, pri, T)
+        st = O.expand_state(st0, pri, T, Y)
         err = 0.0
         for k_op, op in enumerate(ops):
             if op in ("fwd", "bwd"):
@@ -55,7 +69,12 @@ def main():
             elif op in ("Q", "R"):
                 S = O.statistics(st, Y)
                 (O.update_Q if op == "Q" else O.update_R)(st, pri, S, T); (b.update_Q if op == "Q" else b.update_R)()
+            elif op == "Y":
+                if missing:
+                    O.update_Y(st, pri); b.update_Y()
             elif op == "elbo":
+                if missing and np.isnan(st["Yqld"][np.isnan(Y).all(2)]).any():
+                    continue                # an output nothing of which is observed has no q_ln_det before its first update
                 if "qld_A" not in st or np.isnan(st["qld_A"]).any() or np.isnan(st["qld_C"]).any():
                     continue                # a column without q_ln_det yet: the reference raises AttributeError
                 parts = O.elbo_parts(st, pri, O.statistics(st, Y), T)
@@ -78,7 +97,7 @@ def main():
             # implementations after a few parameter updates) and the noise residuals cancel
             assert err < (1e-7 if D <= K else 1e-4), "case %d (%s T=%d D=%d K=%d N=%d) after %s of %s: rel err %.3e" % (case, kind, T, D, K, N, op, ops, err)
         b.close()
-        print("case %2d %-14s T=%3d D=%2d K=%2d N=%d  %s  worst %.2e" % (case, kind, T, D, K, N, " ".join(ops), err), flush=True)
+        print("case %2d %-14s T=%3d D=%2d K=%2d N=%d missing=%d knowns=%d  %s  worst %.2e" % (case, kind, T, D, K, N, missing, knowns, " ".join(ops), err), flush=True)
         worst = max(worst, err)
     print("worst", worst)
 
