@@ -294,6 +294,62 @@ def run_pca_case(ref, name, N, d, q, iters, seed, explicit_x=True):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def example_script_graph(nodes, Y, q):
+    """The graph exactly as examples/Linear_Dynamic_System.py:46-66 writes it: default constructors, every initial posterior
+    drawn by them from numpy's global generator (seed it before calling)."""
+    T, d = Y.shape
+    As = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q) * 1e-3) for i in range(q)]
+    A = nodes.hstack(As)
+    Cs = [nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3) for i in range(q)]
+    C = nodes.hstack(Cs)
+    Q = nodes.DiagonalGamma(q, np.ones(q) * 1e-3, np.ones(q) * 1e-3)
+    R = nodes.DiagonalGamma(d, np.ones(d) * 1e-3, np.ones(d) * 1e-3)
+    X0 = nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q))
+    Y0 = nodes.Gaussian(d, C * X0, R)
+    Y0.observe(Y[0].reshape(d, 1).copy())
+    Xs, Ys = [X0], [Y0]
+    for t in range(1, T):
+        Xs.append(nodes.Gaussian(q, A * Xs[-1], Q))
+        Ys.append(nodes.Gaussian(d, C * Xs[-1], R))
+        Ys[-1].observe(Y[t].reshape(d, 1).copy())
+    return dict(As=As, Cs=Cs, A=A, C=C, Q=Q, R=R, Xs=Xs, Ys=Ys)
+
+
+def example_script_loop(g):
+    """One pass of the example's loop body (Linear_Dynamic_System.py:69-77)."""
+    Xs = g["Xs"]
+    [x.update() for x in Xs]
+    Xs.reverse()
+    [x.update() for x in Xs]
+    Xs.reverse()
+    [a.update() for a in g["As"]]
+    [c.update() for c in g["Cs"]]
+    g["Q"].update()
+    g["R"].update()
+
+
+def run_example_script(ref, name="example_script_q2d5_t40", T=40, q=2, d=5, iters=(1, 2, 5), seed=4242):
+    """The reference's example as written -- nothing assigned, everything drawn -- under a fixed seed of the global generator."""
+    Y = np.random.default_rng(seed).standard_normal((T, d))
+    np.random.seed(seed)
+    g = example_script_graph(ref.nodes, Y, q)
+    out = {"Y": Y, "q": q, "seed": seed, "iters": np.array(sorted(iters)),
+           "init_X": np.hstack([x.qmu for x in g["Xs"]]).T.copy(), "init_A": np.hstack([a.qmu for a in g["As"]]),
+           "init_Qb": np.array(g["Q"].qb, dtype=float)}
+    for it in range(1, max(iters) + 1):
+        example_script_loop(g)
+        if it in iters:
+            tag = "it%d_" % it
+            out[tag + "X"] = np.hstack([x.qmu for x in g["Xs"]]).T.copy()
+            out[tag + "A"], out[tag + "C"] = g["A"].pass_down_Ex(), g["C"].pass_down_Ex()
+            out[tag + "Qb"], out[tag + "Rb"] = np.array(g["Q"].qb, dtype=float), np.array(g["R"].qb, dtype=float)
+            out[tag + "Sigma1"] = g["Xs"][1].qcov.copy()
+            out[tag + "llb"] = np.float64(sum(float(n.log_lower_bound()) for n in g["Xs"] + g["Ys"] + g["As"] + g["Cs"] + [g["Q"], g["R"]]))
+    path = os.path.join(HERE, "script_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def run_generic_case(ref, name):
     """Small graphs of src/tests.py through the reference's classes (tests/golden/generic_scenarios.py): posteriors of
     every random node after the listed iterations, every node's log_lower_bound(), a few pass_up_m1_m2 messages."""
@@ -379,6 +435,8 @@ if __name__ == "__main__":
     for c in PCA_CASES:
         if not sel or sel == ["small"] or "pca" in sel or c[0] in sel:
             run_pca_case(ref, *c)
+    if not sel or sel == ["small"] or "script" in sel:
+        run_example_script(ref)
     sys.path.insert(0, HERE)
     import generic_scenarios
     for name in generic_scenarios.SCENARIOS:
