@@ -294,7 +294,7 @@ def run_pca_case(ref, name, N, d, q, iters, seed, explicit_x=True):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
-def example_script_graph(nodes, Y, q):
+def example_script_graph(nodes, Y, q, knowns=False):
     """The graph exactly as examples/Linear_Dynamic_System.py:46-66 writes it: default constructors, every initial posterior
     drawn by them from numpy's global generator (seed it before calling)."""
     T, d = Y.shape
@@ -312,6 +312,9 @@ def example_script_graph(nodes, Y, q):
         Xs.append(nodes.Gaussian(q, A * Xs[-1], Q))
         Ys.append(nodes.Gaussian(d, C * Xs[-1], R))
         Ys[-1].observe(Y[t].reshape(d, 1).copy())
+    if knowns:      # examples/LDS_knowns_in_A.py:73-74: the first row of A is known
+        As[0].observe(np.array([[1.0]] + [[np.nan]] * (q - 1)))
+        As[1].observe(np.array([[1e-4]] + [[np.nan]] * (q - 1)))
     return dict(As=As, Cs=Cs, A=A, C=C, Q=Q, R=R, Xs=Xs, Ys=Ys)
 
 
@@ -328,12 +331,12 @@ def example_script_loop(g):
     g["R"].update()
 
 
-def run_example_script(ref, name="example_script_q2d5_t40", T=40, q=2, d=5, iters=(1, 2, 5), seed=4242):
+def run_example_script(ref, name="example_script_q2d5_t40", T=40, q=2, d=5, iters=(1, 2, 5), seed=4242, knowns=False):
     """The reference's example as written -- nothing assigned, everything drawn -- under a fixed seed of the global generator."""
     Y = np.random.default_rng(seed).standard_normal((T, d))
     np.random.seed(seed)
-    g = example_script_graph(ref.nodes, Y, q)
-    out = {"Y": Y, "q": q, "seed": seed, "iters": np.array(sorted(iters)),
+    g = example_script_graph(ref.nodes, Y, q, knowns)
+    out = {"Y": Y, "q": q, "seed": seed, "knowns": knowns, "iters": np.array(sorted(iters)),
            "init_X": np.hstack([x.qmu for x in g["Xs"]]).T.copy(), "init_A": np.hstack([a.qmu for a in g["As"]]),
            "init_Qb": np.array(g["Q"].qb, dtype=float)}
     for it in range(1, max(iters) + 1):
@@ -437,6 +440,7 @@ if __name__ == "__main__":
             run_pca_case(ref, *c)
     if not sel or sel == ["small"] or "script" in sel:
         run_example_script(ref)
+        run_example_script(ref, name="knowns_script_q2d5_t40", seed=4243, knowns=True)
     sys.path.insert(0, HERE)
     import generic_scenarios
     for name in generic_scenarios.SCENARIOS:

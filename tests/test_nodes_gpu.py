@@ -381,16 +381,17 @@ def test_assigning_a_column_mean_keeps_the_dense_covariances_with_wishart_noise(
         assert _rel(g, r) < 1e-9
 
 
-def test_the_example_exactly_as_the_reference_writes_it():
+@pytest.mark.parametrize("name", ["example_script_q2d5_t40", "knowns_script_q2d5_t40"])
+def test_the_example_exactly_as_the_reference_writes_it(name):
     """examples/Linear_Dynamic_System.py:46-77 with nothing assigned: every initial posterior is what the constructors draw
     from numpy's global generator.  Under the same seed pyvb_amd's classes make the same draws, and the fused plan
     reproduces the reference's run (fixture script_example_script_*: recorded from the reference's classes)."""
     import pyvb_amd
     from pyvb_amd._recognise import LDSPlan
     G = _golden_module()
-    z = dict(np.load(os.path.join(HERE, "golden", "script_example_script_q2d5_t40.npz"), allow_pickle=False))
+    z = dict(np.load(os.path.join(HERE, "golden", "script_%s.npz" % name), allow_pickle=False))
     np.random.seed(int(z["seed"]))
-    g = G.example_script_graph(pyvb_amd.nodes, z["Y"], int(z["q"]))
+    g = G.example_script_graph(pyvb_amd.nodes, z["Y"], int(z["q"]), bool(z["knowns"]))
     assert _rel(np.hstack([x.qmu for x in g["Xs"]]).T, z["init_X"]) < 1e-15
     assert _rel(np.hstack([a.qmu for a in g["As"]]), z["init_A"]) < 1e-15 and _rel(g["Q"].qb, z["init_Qb"]) < 1e-15
     done = 0
