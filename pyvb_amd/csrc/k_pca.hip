@@ -123,9 +123,6 @@ __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
         for (int s = 0; s < QS; ++s) { const int i = 4 * s + qk; wb[p][s] = (dim < d && i < q) ? a.W_mean[(size_t)dim * q + i] : 0.0; }
         mu[p] = dim < d ? a.Mu_mean[dim] : 0.0;
     }
-    const double var_new = a.scal[PS_BETA_B] / a.scal[PS_BETA_A];          // 1 / <beta>
-    if (blockIdx.x == 0 && wave == 0 && lane == 0 && a.hi_upd > a.lo_upd)    // q_ln_det of rows without any observation
-        a.scal[PS_QLD_X] = 0.5 / (0.5 * d * log(1.0 / var_new));
     d4 sxz[P2T][QT], szz[QT][QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -498,7 +495,7 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
                 dsx[tid] = a.Xdata[tid] - a.X[tid];
                 a.X[tid] = a.Xdata[tid];
             }
-            if (tid == 0) { a.xvar[0] = 1.0 / beta; a.scal[PS_QLD_X] = 0.5 / (0.5 * d * log(beta)); if (pin) a.pinned[0] = 1; }
+            if (tid == 0) { a.xvar[0] = 1.0 / beta; if (pin) a.pinned[0] = 1; }
         }
     } else if (a.mode == PCA_APPLY) {
         // after the all-reduce of aux: the new sum of z replaces the old one, the sum of x moves by the delta

@@ -25,7 +25,7 @@ static inline PcaStatsLayout pca_stats_layout(int DP, int QP) {
 #define PCA_RED 128     // slices of the chunk partials summed in parallel (stage 0 of k_pca_reduce)
 
 // device scalars
-enum { PS_BETA_A = 0, PS_BETA_B, PS_QLD_Z, PS_QLD_X, PS_QLD_MU, PS_BETA_A0, PS_BETA_B0, PS_RES, PS_COUNT = 16 };   // PS_RES: the residual of the last Beta update (see res_valid)
+enum { PS_BETA_A = 0, PS_BETA_B, PS_QLD_Z, PS_QLD_X /* unused: latent rows keep their own, statistics slot sql */, PS_QLD_MU, PS_BETA_A0, PS_BETA_B0, PS_RES, PS_COUNT = 16 };   // PS_RES: the residual of the last Beta update (see res_valid)
 
 struct pyvb_pca {
     int device; long N, N_total, row_offset; int d, q, DP, QP, DT, QT;
