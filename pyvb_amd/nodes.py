@@ -223,7 +223,7 @@ class _DeviceAttr(object):
         # up: its state goes back into the nodes, the value is stored below, and the next use binds the graph anew.  A
         # release can itself leave the graph with another plan (queued requests that only the node-by-node plan serves;
         # sweeps among them that bring the fused plan back), bound from the OLD host value: hence the loop.
-        for _ in range(4):
+        for _ in range(8):
             plan = getattr(obj, "_plan", None)
             if plan is None:
                 break
@@ -233,6 +233,8 @@ class _DeviceAttr(object):
             if plan.write(obj, self.name, value):
                 break
             plan.release()
+        else:
+            raise RuntimeError("the graph kept changing plans while %s was assigned" % self.name)
         obj.__dict__["_h_" + self.name] = value
 
 
