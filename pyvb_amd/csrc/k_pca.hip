@@ -105,7 +105,9 @@ __global__ void __launch_bounds__(256) k_pca_pass1(PcaArgs a) {
 #ifndef P2_OCC
 #define P2_OCC (QT == 1 ? 4 : 2)        // workgroups per CU the register budget is set for
 #endif
-template <int QT>
+// PIN: some rows still carry their initial mean at all entries and take their observations at their first update
+// (pyvb_pca_set_unpinned_rows); its own instantiation, so that the usual one keeps its register budget
+template <int QT, bool PIN>
 __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
     const int lane = threadIdx.x & 63, wave = 4 * blockIdx.y + (threadIdx.x >> 6), c = lane & 15, qk = lane >> 4;
     const int DP = a.DP, QP = a.QP, d = a.d, q = a.q;
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
 #pragma unroll
             for (int p = 0; p < P2T; ++p)
                 if (rowupd && ((mk[r] >> (8 * p)) & 0xffu) == 0) { v[p] = xn[p][r]; any = true; }
-            if (a.Xdata != nullptr && rowupd && !a.pinned[r0 + row]) {      // first update of a row that still carries its initial
+            if (PIN && rowupd && !a.pinned[r0 + row]) {                     // first update of a row that still carries its initial
                 const d2 dat = *reinterpret_cast<const d2*>(a.Xdata + (size_t)r0 * DP + xoff[r]);   // mean everywhere: the
 #pragma unroll
                 for (int p = 0; p < P2T; ++p)                                // observed entries take their data (gaussian.py:125-134)
@@ -605,8 +607,9 @@ int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
     PcaArgs a = pca_args(h); a.lo_upd = lo_upd; a.hi_upd = hi_upd;
     const unsigned nw = (h->DT + P2T - 1) / P2T;          // wavefronts per row chunk: 32 columns each, four to a workgroup
     const dim3 grid(h->nchunk, (nw + 3) / 4), block(64 * (nw < 4 ? nw : 4));
-    if (h->QT == 1) hipLaunchKernelGGL(k_pca_pass2<1>, grid, block, 0, h->stream, a);
-    else hipLaunchKernelGGL(k_pca_pass2<2>, grid, block, 0, h->stream, a);
+    const bool pin = h->Xdata != nullptr;
+    if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass2<1, true>), grid, block, 0, h->stream, a); else hipLaunchKernelGGL((k_pca_pass2<1, false>), grid, block, 0, h->stream, a); }
+    else { if (pin) hipLaunchKernelGGL((k_pca_pass2<2, true>), grid, block, 0, h->stream, a); else hipLaunchKernelGGL((k_pca_pass2<2, false>), grid, block, 0, h->stream, a); }
     hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
