@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) k_pca_pass1(PcaArgs a) {
 // ---------------------------------------------------------------------------------------------------
 #define P2T 2           // tiles per wavefront
 #ifndef P2_OCC
-#define P2_OCC (QT == 1 ? 4 : 2)        // workgroups per CU the register budget is set for
+#define P2_OCC (QT == 1 ? (PIN ? 3 : 4) : 2)     // workgroups per CU the register budget is set for
 #endif
 // PIN: some rows still carry their initial mean at all entries and take their observations at their first update
 // (pyvb_pca_set_unpinned_rows); its own instantiation, so that the usual one keeps its register budget
