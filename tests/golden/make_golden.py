@@ -353,6 +353,52 @@ def run_example_script(ref, name="example_script_q2d5_t40", T=40, q=2, d=5, iter
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def pca_script_graph(mod, Xdata, q):
+    """The graph and network exactly as examples/PCA_missing_data.py:31-42 writes them: default constructors, every initial
+    posterior drawn from numpy's global generator (seed it before calling)."""
+    nodes = mod.nodes
+    N, d = Xdata.shape
+    Ws = [nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3) for i in range(q)]
+    W = nodes.hstack(Ws)
+    Mu = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3)
+    Beta = nodes.Gamma(d, 1e-3, 1e-3)
+    Zs = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q)) for i in range(N)]
+    Xs = [nodes.Gaussian(d, W * z + Mu, Beta) for z in Zs]
+    [xnode.observe(xval.reshape(d, 1).copy()) for xnode, xval in zip(Xs, Xdata)]
+    net = mod.Network()
+    net.addnode(W)
+    net.fetch_network()
+    return dict(Ws=Ws, W=W, Mu=Mu, Beta=Beta, Zs=Zs, Xs=Xs, net=net)
+
+
+def run_pca_script(ref, name="pca_script_n40_d5_q2", N=40, d=5, q=2, iters=(1, 2, 4), seed=5151):
+    """The reference's PCA example as written -- nothing assigned -- under a fixed seed of the global generator."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, q)) @ rng.standard_normal((q, d)) + rng.standard_normal(d) + 0.2 * rng.standard_normal((N, d))
+    X[rng.random((N, d)) < 0.15] = np.nan
+    X[3] = np.nan                           # a row without any observation
+    np.random.seed(seed)
+    g = pca_script_graph(ref, X, q)
+    net = g["net"]
+    net.find_iterable()
+    out = {"X": X, "q": q, "seed": seed, "iters": np.array(sorted(iters)),
+           "init_Z": np.hstack([z.qmu for z in g["Zs"]]).T.copy(), "init_Zc": np.array([z.qcov[0, 0] for z in g["Zs"]])}
+    for it in range(1, max(iters) + 1):
+        for n in net.iterable_nodes:
+            n.update()
+        if it in iters:
+            tag = "it%d_" % it
+            out[tag + "W"] = np.hstack([w.qmu for w in g["Ws"]])
+            out[tag + "Z"] = np.hstack([z.qmu for z in g["Zs"]]).T.copy()
+            out[tag + "Xm"] = np.hstack([x.qmu for x in g["Xs"]]).T.copy()
+            out[tag + "Mu"] = g["Mu"].qmu.reshape(-1).copy()
+            out[tag + "beta_b"] = np.float64(g["Beta"].qb)
+            out[tag + "llb"] = np.float64(sum(float(n.log_lower_bound()) for n in net.iterable_nodes))
+    path = os.path.join(HERE, "script_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def run_generic_case(ref, name):
     """Small graphs of src/tests.py through the reference's classes (tests/golden/generic_scenarios.py): posteriors of
     every random node after the listed iterations, every node's log_lower_bound(), a few pass_up_m1_m2 messages."""
@@ -441,6 +487,7 @@ if __name__ == "__main__":
     if not sel or sel == ["small"] or "script" in sel:
         run_example_script(ref)
         run_example_script(ref, name="knowns_script_q2d5_t40", seed=4243, knowns=True)
+        run_pca_script(ref)
     sys.path.insert(0, HERE)
     import generic_scenarios
     for name in generic_scenarios.SCENARIOS:

@@ -427,3 +427,29 @@ def test_shapes_beyond_the_fused_kernels_run_node_by_node():
     assert _rel(np.hstack([x.qmu for x in g["Xs"]]).T, st["X"][0]) < 1e-7
     assert _rel(np.hstack([a.qmu for a in g["As"]]), st["A_mean"][0]) < 1e-7
     assert _rel(g["R"].qb, st["R_b"][0]) < 1e-7
+
+
+def test_the_pca_example_exactly_as_the_reference_writes_it():
+    """examples/PCA_missing_data.py:31-45 with nothing assigned: W, Mu, every Z_n and X_n as their constructors draw them (each Z_n
+    its own covariance I / rand -- the fused plan keeps their mean, which serves exactly because everything that reads them
+    before their first update is linear in them), Network.fetch_network + learn.  Fixture recorded from the reference's classes."""
+    import pyvb_amd
+    from pyvb_amd._recognise import PCAPlan
+    G = _golden_module()
+    z = dict(np.load(os.path.join(HERE, "golden", "script_pca_script_n40_d5_q2.npz"), allow_pickle=False))
+    np.random.seed(int(z["seed"]))
+    g = G.pca_script_graph(pyvb_amd, z["X"], int(z["q"]))
+    assert _rel(np.hstack([zz.qmu for zz in g["Zs"]]).T, z["init_Z"]) < 1e-15
+    assert _rel(np.array([zz.qcov[0, 0] for zz in g["Zs"]]), z["init_Zc"]) < 1e-15
+    net, done = g["net"], 0
+    for it in [int(i) for i in z["iters"]]:
+        net.learn(it - done, tol=-np.inf, verbose=False)
+        done = it
+        tag = "it%d_" % it
+        assert isinstance(g["Zs"][0]._plan, PCAPlan)
+        assert _rel(np.hstack([w.qmu for w in g["Ws"]]), z[tag + "W"]) <= RTOL
+        assert _rel(np.hstack([zz.qmu for zz in g["Zs"]]).T, z[tag + "Z"]) <= RTOL
+        assert _rel(np.hstack([x.qmu for x in g["Xs"]]).T, z[tag + "Xm"]) <= RTOL
+        assert _rel(g["Mu"].qmu.reshape(-1), z[tag + "Mu"]) <= RTOL
+        assert abs(g["Beta"].qb - float(z[tag + "beta_b"])) <= RTOL * abs(float(z[tag + "beta_b"]))
+        assert abs(net.llb - float(z[tag + "llb"])) <= 1e-7 * abs(float(z[tag + "llb"]))
