@@ -124,7 +124,7 @@ def main():
     only = int(sys.argv[3]) if len(sys.argv) > 3 else None      # run this case alone, comparing EVERYTHING after every operation
     worst = 0.0
     for case in range(cases):
-        T = int(rng.integers(3, 40)); q = int(rng.integers(1, 5)); d = int(rng.integers(1, 6))
+        T = int(rng.integers(3, int(os.environ.get("FUZZ_TMAX", "40")))); q = int(rng.integers(1, int(os.environ.get("FUZZ_QMAX", "5")))); d = int(rng.integers(1, int(os.environ.get("FUZZ_QMAX", "5")) + 1))
         if d == 1 and q > 1:
             d = 2       # a one-row product: the reference itself raises there (node.py:198 NameError, nodes_todo.py:40-41), so does the generic path
         noise = str(rng.choice(["gamma", "diagonal_gamma", "wishart"], p=[0.4, 0.4, 0.2])); knowns = bool(rng.random() < 0.3) and q > 1 and noise != "wishart"
