@@ -46,3 +46,20 @@ for i in range(int(os.environ.get("SOAK_GRAPHS", "60"))):
     v = mu.qmu
     mu._plan.release()
 print("generic plan: free memory drift after %s graphs: %d bytes" % (os.environ.get("SOAK_GRAPHS", "60"), base - free_bytes()))
+
+# the VB-PCA handle, with the extra buffers of constructor-drawn rows
+import importlib.util
+from pyvb_amd.pca import PCABatch
+spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "make_golden.py"))
+G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+init, ppri = G.pca_problem(3000, 40, 6, seed=3)
+init["X_full"] = np.where(init["obs"].all(1)[:, None], init["X"], np.random.default_rng(0).standard_normal(init["X"].shape))
+init["X_var0"] = np.where(init["obs"].all(1), 0.0, 1.3)
+b = PCABatch.from_problem(init, ppri); b.iterate(2); b.close()
+base = free_bytes()
+for i in range(int(os.environ.get("SOAK_CYCLES", "40"))):
+    b = PCABatch.from_problem(init, ppri)
+    b.iterate(3)
+    e = b.elbo().sum()
+    b.close()
+print("VB-PCA: free memory drift after the create/destroy cycles: %d bytes" % (base - free_bytes()))
