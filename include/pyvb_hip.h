@@ -244,6 +244,12 @@ int pyvb_graph_destroy(pyvb_graph* g);
 int pyvb_graph_write(pyvb_graph* g, size_t offset, const double* src, size_t n);
 int pyvb_graph_read(pyvb_graph* g, size_t offset, double* dst, size_t n);
 int pyvb_graph_tape_create(pyvb_graph* g, const int* ops, int nops, int* tape_id);
+/* Optional: how pyvb_graph_tape_run issues the tape -- launches[nl][2] = (first block, number of blocks), in order, and
+ * blocks[nb][2] = (first record, number of records); the blocks of one launch run side by side, one workgroup each (the
+ * updates of nodes none of which reads what another writes: [z.update() for z in Zs] of a PCA-like graph).  The caller
+ * guarantees that independence; blocks and launches must tile the tape in order (checked).  Without a program one workgroup
+ * interprets the whole tape. */
+int pyvb_graph_tape_set_program(pyvb_graph* g, int tape_id, const int* blocks, int nblocks, const int* launches, int nlaunches);
 int pyvb_graph_tape_run(pyvb_graph* g, int tape_id);
 int pyvb_graph_tape_destroy(pyvb_graph* g, int tape_id);
 int pyvb_graph_sync(pyvb_graph* g);

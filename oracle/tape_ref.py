@@ -105,6 +105,7 @@ class NumpyExecutor(object):
         self.size = int(arena_doubles)
         self.arena = np.zeros(self.size)
         self.tapes = []
+        self.programs = []
         self.bad = False
 
     def write(self, off, arr):
@@ -115,13 +116,24 @@ class NumpyExecutor(object):
         self.sync()
         return self.arena[off:off + n].copy()
 
-    def tape(self, ops):
+    def tape(self, ops, program=None):
         self.tapes.append(np.array(ops, dtype=np.int64).reshape(-1, 8))
+        self.programs.append(program)
         return len(self.tapes) - 1
 
     def run(self, tid):
+        """With a program (pyvb_graph_tape_set_program: record ranges the device runs side by side) the blocks of a launch are
+        interpreted LAST FIRST: if the independence the program claims did not hold, the results would depend on that order and
+        the comparisons with the reference's fixtures would fail."""
         try:
-            run(self.arena, self.tapes[tid])
+            ops, prog = self.tapes[tid], self.programs[tid]
+            if prog is None:
+                run(self.arena, ops)
+            else:
+                blocks, launches = [np.asarray(a).reshape(-1, 2) for a in prog]
+                for first, count in launches:
+                    for a, n in reversed(blocks[first:first + count].tolist()):
+                        run(self.arena, ops[a:a + n])
         except LinAlgStatus:
             self.bad = True
 

@@ -75,6 +75,7 @@ SIGNATURES = {
     "pyvb_graph_write": (ctypes.c_int, [_h, ctypes.c_size_t, _dp, ctypes.c_size_t]),
     "pyvb_graph_read": (ctypes.c_int, [_h, ctypes.c_size_t, _dp, ctypes.c_size_t]),
     "pyvb_graph_tape_create": (ctypes.c_int, [_h, _ip, ctypes.c_int, _ip]),
+    "pyvb_graph_tape_set_program": (ctypes.c_int, [_h, ctypes.c_int, _ip, ctypes.c_int, _ip, ctypes.c_int]),
     "pyvb_graph_tape_run": (ctypes.c_int, [_h, ctypes.c_int]),
     "pyvb_graph_tape_destroy": (ctypes.c_int, [_h, ctypes.c_int]),
     "pyvb_graph_sync": (ctypes.c_int, [_h]),

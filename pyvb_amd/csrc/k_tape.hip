@@ -40,11 +40,11 @@ __device__ static double tape_digamma(double x) {
     return r + log(x) - 0.5 / x - ser;
 }
 
-__global__ void __launch_bounds__(TAPE_THREADS) k_tape(TapeArgs t) {
-    __shared__ double red[TAPE_THREADS];
+// records [first, first + count) of the tape, interpreted by the calling workgroup
+__device__ static void tape_exec(const TapeArgs& t, int first, int count, double* red) {
     double* A = t.arena;
     const int tid = threadIdx.x;
-    for (int pc = 0; pc < t.nops; ++pc) {
+    for (int pc = first; pc < first + count; ++pc) {
         const int* o = t.ops + 8 * pc;
         const int op = o[0], m = o[4], n = o[5], flags = o[7];
         double* dst = A + o[1];
@@ -177,12 +177,27 @@ __global__ void __launch_bounds__(TAPE_THREADS) k_tape(TapeArgs t) {
     }
 }
 
+__global__ void __launch_bounds__(TAPE_THREADS) k_tape(TapeArgs t) {
+    __shared__ double red[TAPE_THREADS];
+    tape_exec(t, 0, t.nops, red);
+}
+
+// A PROGRAM over a tape: launches in order, each of them a set of record ranges ("blocks") that touch disjoint state and so
+// run side by side, one workgroup per block (the updates of nodes none of which reads what another writes: the Z_n of a
+// PCA-like graph, its X_n).  blocks: [first record, count] per workgroup of this launch.
+__global__ void __launch_bounds__(TAPE_THREADS) k_tape_blocks(TapeArgs t, const int* blocks) {
+    __shared__ double red[TAPE_THREADS];
+    tape_exec(t, blocks[2 * blockIdx.x], blocks[2 * blockIdx.x + 1], red);
+}
+
 struct pyvb_graph {
     int device;
     hipStream_t stream;
     double* arena; size_t arena_n;
     int* status;
     std::vector<int*> tapes; std::vector<int> tape_len;
+    std::vector<int*> prog_blocks;                   // per tape: device table [nblocks][2], or null
+    std::vector<std::vector<int>> prog_launches;     // per tape: (first block, number of blocks) per launch
 };
 
 #define ARGCHK(cond, msg) do { if (!(cond)) { pyvb_set_error("%s", msg); return PYVB_E_ARG; } } while (0)
@@ -212,6 +227,7 @@ int pyvb_graph_destroy(pyvb_graph* g) {
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     for (int* t : g->tapes) if (t) (void)hipFree(t);
+    for (int* t : g->prog_blocks) if (t) (void)hipFree(t);
     if (g->arena) (void)hipFree(g->arena);
     if (g->status) (void)hipFree(g->status);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -294,7 +310,38 @@ int pyvb_graph_tape_create(pyvb_graph* g, const int* ops, int nops, int* tape_id
     HIPCHK(hipMemcpyAsync(d, ops, (size_t)nops * 8 * sizeof(int), hipMemcpyHostToDevice, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
     g->tapes.push_back(d); g->tape_len.push_back(nops);
+    g->prog_blocks.push_back(nullptr); g->prog_launches.emplace_back();
     *tape_id = (int)g->tapes.size() - 1;
+    return PYVB_OK;
+}
+
+/* How pyvb_graph_tape_run issues the tape: launches[nl][2] = (first block, number of blocks), in order; blocks[nb][2] =
+ * (first record, number of records).  The blocks of one launch run side by side: the caller guarantees that none of them
+ * reads or writes what another writes.  Every record must belong to exactly one block and the launches must cover the
+ * blocks in order (checked). */
+int pyvb_graph_tape_set_program(pyvb_graph* g, int tape_id, const int* blocks, int nblocks, const int* launches, int nlaunches) {
+    ARGCHK(g && tape_id >= 0 && tape_id < (int)g->tapes.size() && g->tapes[tape_id], "no such tape");
+    ARGCHK(blocks && launches && nblocks > 0 && nlaunches > 0, "bad arguments");
+    HIPCHK(hipSetDevice(g->device));
+    int rec = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        ARGCHK(blocks[2 * b] == rec && blocks[2 * b + 1] > 0, "the blocks of a program must tile the tape in order");
+        rec += blocks[2 * b + 1];
+    }
+    ARGCHK(rec == g->tape_len[tape_id], "the blocks of a program must cover every record of the tape");
+    int blk = 0;
+    for (int l = 0; l < nlaunches; ++l) {
+        ARGCHK(launches[2 * l] == blk && launches[2 * l + 1] > 0, "the launches of a program must tile the blocks in order");
+        blk += launches[2 * l + 1];
+    }
+    ARGCHK(blk == nblocks, "the launches of a program must cover every block");
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (g->prog_blocks[tape_id]) { (void)hipFree(g->prog_blocks[tape_id]); g->prog_blocks[tape_id] = nullptr; }
+    int* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)nblocks * 2 * sizeof(int)));
+    HIPCHK(hipMemcpy(d, blocks, (size_t)nblocks * 2 * sizeof(int), hipMemcpyHostToDevice));
+    g->prog_blocks[tape_id] = d;
+    g->prog_launches[tape_id].assign(launches, launches + 2 * nlaunches);
     return PYVB_OK;
 }
 
@@ -302,7 +349,12 @@ int pyvb_graph_tape_run(pyvb_graph* g, int tape_id) {
     ARGCHK(g && tape_id >= 0 && tape_id < (int)g->tapes.size() && g->tapes[tape_id], "no such tape");
     HIPCHK(hipSetDevice(g->device));
     TapeArgs t; t.arena = g->arena; t.arena_n = g->arena_n; t.ops = g->tapes[tape_id]; t.nops = g->tape_len[tape_id]; t.status = g->status;
-    hipLaunchKernelGGL(k_tape, dim3(1), dim3(TAPE_THREADS), 0, g->stream, t);
+    if (g->prog_blocks[tape_id]) {
+        const std::vector<int>& L = g->prog_launches[tape_id];
+        for (size_t l = 0; l + 1 < L.size(); l += 2)
+            hipLaunchKernelGGL(k_tape_blocks, dim3(L[l + 1]), dim3(TAPE_THREADS), 0, g->stream, t, g->prog_blocks[tape_id] + 2 * L[l]);
+    } else
+        hipLaunchKernelGGL(k_tape, dim3(1), dim3(TAPE_THREADS), 0, g->stream, t);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
@@ -312,6 +364,7 @@ int pyvb_graph_tape_destroy(pyvb_graph* g, int tape_id) {
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(hipStreamSynchronize(g->stream));
     if (g->tapes[tape_id]) { (void)hipFree(g->tapes[tape_id]); g->tapes[tape_id] = nullptr; }
+    if (g->prog_blocks[tape_id]) { (void)hipFree(g->prog_blocks[tape_id]); g->prog_blocks[tape_id] = nullptr; }
     return PYVB_OK;
 }
 

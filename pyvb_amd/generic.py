@@ -24,6 +24,8 @@ Deviations from the reference, all where it is broken: a
 Constant matrix or a row vector returns a proper (m1, m2) pair (Q3; node.py:209,212 return a bare matrix, which
 Gaussian.update then mis-indexes) and its pass_down_ExxT uses A <BB^T> A^T (node.py:258 has a typo and no transpose, Q6).
 """
+import bisect
+
 import numpy as np
 
 from . import nodes as N
@@ -58,12 +60,16 @@ class Tape(object):
         self.plan = plan
         self.ops = []
         self.top = plan.temp_base
+        self.marks = []                 # record indices where a new node's records begin (many-node tapes)
 
     def tmp(self, m, n=1):
         r = Ref(self.top, m, n)
         self.top += max(1, m * n)
         self.plan.temp_high = max(self.plan.temp_high, self.top)
         return r
+
+    def mark(self):
+        self.marks.append(len(self.ops))
 
     def emit(self, op, dst, a=0, b=0, m=0, n=0, p=0, flags=0):
         self.ops.append((op, int(dst), int(a), int(b), int(m), int(n), int(p), int(flags)))
@@ -209,10 +215,15 @@ class DeviceExecutor(object):
             self.C.check(self.C.lib.pyvb_graph_read(self._h, int(off), self.C.dptr(out), int(n)))
         return out
 
-    def tape(self, ops):
+    def tape(self, ops, program=None):
+        """program: (blocks [nb, 2], launches [nl, 2]) -- record ranges that may run side by side (pyvb_graph_tape_set_program)."""
         ops = np.ascontiguousarray(ops, dtype=np.int32)
         tid = self.C.ctypes.c_int()
         self.C.check(self.C.lib.pyvb_graph_tape_create(self._h, ops.ctypes.data_as(self.C._ip), int(ops.shape[0]), self.C.ctypes.byref(tid)))
+        if program is not None:
+            blocks, launches = [np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 2) for a in program]
+            self.C.check(self.C.lib.pyvb_graph_tape_set_program(self._h, tid.value, blocks.ctypes.data_as(self.C._ip), int(blocks.shape[0]),
+                                                                launches.ctypes.data_as(self.C._ip), int(launches.shape[0])))
         return tid.value
 
     def run(self, tid):
@@ -303,6 +314,9 @@ class GenericPlan(object):
         self.temp_high = off
         self._init = init
         self._tapes = {}                  # key -> (tape id or None while not uploaded, records, result refs)
+        self._programs = {}               # key -> (blocks, launches) for tapes whose nodes can run side by side
+        starts = sorted((ref.off, id_) for id_, sl in self.slot.items() for ref in sl.values())
+        self._slot_start, self._slot_owner = [a for a, _ in starts], [b for _, b in starts]
         # what the tapes run on: the device.  (executor_factory exists for tests/test_generic_cpu.py, which checks the emitters
         # without a GPU by handing in the numpy restatement of the interpreter; nothing in the package passes it.)
         self._executor_factory = executor_factory or DeviceExecutor
@@ -365,16 +379,76 @@ class GenericPlan(object):
             t = Tape(self)
             res = build(t)
             self._tapes[key] = (None, t.array(), res)
+            if t.marks:
+                self._programs[key] = self._program(t)
         tid, ops, res = self._tapes[key]
         self._ensure_executor(self.temp_high)
         if self._const_dirty:
             self.ex.write(0, np.array(self._const_vals, dtype=float))
             self._const_dirty = False
         if tid is None:
-            tid = self.ex.tape(ops)
+            tid = self.ex.tape(ops, self._programs.get(key))
             self._tapes[key] = (tid, ops, res)
         self.ex.run(tid)
         return res
+
+    # Many-node tapes (update_all, llb_sum) mark where each node's records begin.  Nodes whose records neither read nor write a
+    # posterior another one writes can run side by side: one workgroup per node instead of one workgroup for all of them.
+    PAR_MIN = 8         # shorter independent runs stay in the sequential block: a launch costs more than they gain
+
+    def _owner(self, off):
+        """The node whose state slot holds arena offset `off` (None: constants, temporaries)."""
+        if off < CONST_CAP or off >= self.temp_base:
+            return None
+        return self._slot_owner[bisect.bisect_right(self._slot_start, off) - 1]
+
+    def _program(self, t):
+        ops = t.ops
+        cuts = [m for m in t.marks if m < len(ops)] + [len(ops)]
+        segs = []                                   # (first record, count, nodes read, nodes written)
+        prologue = cuts[0] > 0                      # records before the first node (the result vector of llb_sum): they set up
+        if prologue:                                # temporaries the nodes write into, so they run first and alone
+            cuts = [0] + cuts
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b == a:
+                continue
+            reads, writes = set(), set()
+            for o in ops[a:b]:
+                for v in (o[1], o[2], o[3], o[6], o[7]):          # any field may be an offset; small values are dimensions
+                    w = self._owner(v)
+                    if w is not None:
+                        reads.add(w)
+                for v in ((o[1], o[3]) if o[0] == T_CHOLINV else (o[1],)):
+                    w = self._owner(v)
+                    if w is not None:
+                        writes.add(w)
+            segs.append((a, b - a, reads, writes))
+        blocks, launches = [], []
+
+        def sequential(run):
+            for a, n, _, _ in run:
+                if launches and launches[-1][1] == 1 and blocks[-1][2] and blocks[-1][0] + blocks[-1][1] == a:
+                    blocks[-1][1] += n              # extend the sequential block before it
+                else:
+                    blocks.append([a, n, True]); launches.append([len(blocks) - 1, 1])
+
+        def flush(run):
+            if len(run) >= self.PAR_MIN:
+                launches.append([len(blocks), len(run)])
+                blocks.extend([a, n, False] for a, n, _, _ in run)
+            else:
+                sequential(run)
+        run, rr, rw = [], set(), set()
+        for k, seg in enumerate(segs):
+            _, _, reads, writes = seg
+            if writes & (rr | rw) or reads & rw or (prologue and k == 1):
+                flush(run)
+                run, rr, rw = [], set(), set()
+            run.append(seg); rr |= reads; rw |= writes
+        flush(run)
+        if len(launches) == 1 and launches[0][1] == 1:
+            return None                              # nothing to run side by side: the plain single-workgroup tape
+        return (np.array([[a, n] for a, n, _ in blocks], dtype=np.int32), np.array(launches, dtype=np.int32))
 
     def _read(self, ref):
         self._ensure_executor(self.temp_high)
@@ -499,6 +573,7 @@ class GenericPlan(object):
         def build(t):
             parts = t.zeros(len(node_list), 1)
             for i, n in enumerate(node_list):
+                t.mark()
                 t.copy(self._emit_llb(t, n), dst=parts.elem(i))
             return parts
         return self._read(self._run(key, build)).reshape(-1)
@@ -510,6 +585,7 @@ class GenericPlan(object):
 
         def build(t):
             for n in node_list:
+                t.mark()
                 if isinstance(n, N.Gaussian):
                     if not n.observed:
                         self._emit_update_gaussian(t, n)

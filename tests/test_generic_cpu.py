@@ -174,3 +174,49 @@ def test_emitters_refuse_what_the_reference_cannot_do(numpy_executor):
     h = nodes.hstack([mu, nodes.Gaussian(2, np.zeros((2, 1)), np.eye(2))])
     with pytest.raises(NotImplementedError):
         h.pass_down_ExTx()              # nodes_todo.py:40-41 raises too
+
+
+PROGRAM_CASES = ["simple_PCA", "partial_observations", "lds_missing_outputs", "simple_regression"] + ["random_%d" % s for s in GS.RANDOM_SEEDS[:12]]
+
+
+def check_programs(name, plan_of):
+    """update_all / llb_sum tapes carry a PROGRAM: nodes whose records touch disjoint posteriors run side by side (device) or
+    last-first (numpy executor).  Either must equal the one-node-at-a-time loop."""
+    from pyvb_amd import nodes
+    build, seed, _, _ = GS.SCENARIOS[name]
+    order, named = build(nodes, np.random.default_rng(seed))
+    order2, named2 = build(nodes, np.random.default_rng(seed))
+    for _ in range(2):
+        for n in order:
+            n.update()
+    plans = []                              # a random graph may fall into several unconnected components: one plan each
+    for n in order2:
+        p = plan_of(n)
+        if p not in plans:
+            plans.append(p)
+    plan = plans[0]
+    for _ in range(2):
+        for p in plans:                     # components do not see each other: their order does not matter (Network groups by plan too)
+            p.update_all([n for n in order2 if n._plan is p])
+    for k, v in GS.snapshot(named).items():
+        w = GS.snapshot(named2)[k]
+        assert np.abs(np.asarray(v) - np.asarray(w)).max() <= 1e-12 * max(np.abs(np.asarray(v)).max(), 1.0), (name, k)
+    for p in plans:
+        keys = [k for k in named2 if named2[k]._plan is p and not getattr(named2[k], "observed", False)]
+        try:
+            want = np.array([float(np.asarray(named[k].log_lower_bound()).reshape(-1)[0]) for k in keys])
+        except (AttributeError, NotImplementedError):
+            continue
+        got = p.llb_sum([named2[k] for k in keys])
+        ok = np.isfinite(want)
+        assert np.all(np.abs(got[ok] - want[ok]) <= 1e-10 * np.maximum(np.abs(want[ok]), 1.0)), (name, got, want)
+    return plan
+
+
+@pytest.mark.parametrize("name", PROGRAM_CASES)
+def test_programs_of_many_node_tapes(name, numpy_executor):
+    from pyvb_amd import nodes
+    plan = check_programs(name, lambda n: nodes._plan_of(n))
+    if name == "simple_PCA":        # 25 independent latent scalars: they must have ended up side by side
+        progs = [p for p in plan._programs.values() if p is not None]
+        assert progs and max(int(l[1]) for p in progs for l in p[1]) >= 25

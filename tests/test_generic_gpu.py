@@ -260,3 +260,14 @@ def test_single_terms_of_the_fused_pca_plan():
         assert abs(v - r) <= 1e-8 * scale, (got, ref)
     m1, m2 = g["Xs"][5].pass_up_m1_m2(g["Xs"][5].mean_parent)
     _close(m1, g["Beta"].pass_down_Ex(), "m1 of an output row", 1e-9)
+
+
+@pytest.mark.parametrize("name", ["simple_PCA", "partial_observations", "lds_missing_outputs"] + ["random_%d" % s for s in GS.RANDOM_SEEDS[:12]])
+def test_programs_of_many_node_tapes_on_device(name, monkeypatch):
+    """Network.learn's tapes (all updates of an iteration; all lower-bound terms) issue nodes that touch disjoint posteriors side
+    by side, one workgroup each (pyvb_graph_tape_set_program): same results as the one-node-at-a-time loop."""
+    from pyvb_amd import generic, _recognise, nodes
+    from test_generic_cpu import check_programs
+    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+    plan = check_programs(name, lambda n: nodes._plan_of(n))
+    assert isinstance(plan.ex, generic.DeviceExecutor)
