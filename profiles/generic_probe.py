@@ -57,3 +57,4 @@ def pca(N, d, q, iters):
 lds(200, 2, 5, 5)
 lds(1000, 4, 8, 3)
 pca(200, 10, 3, 5)
+pca(2000, 10, 3, 3)

@@ -60,7 +60,8 @@ class Tape(object):
         self.plan = plan
         self.ops = []
         self.top = plan.temp_base
-        self.marks = []                 # record indices where a new node's records begin (many-node tapes)
+        self.marks = []                 # record indices where a block begins: a node of a many-node tape, one child's message
+        self.barriers = set()           # marks before which everything emitted so far must have finished (temporaries are read)
 
     def tmp(self, m, n=1):
         r = Ref(self.top, m, n)
@@ -68,8 +69,10 @@ class Tape(object):
         self.plan.temp_high = max(self.plan.temp_high, self.top)
         return r
 
-    def mark(self):
+    def mark(self, barrier=False):
         self.marks.append(len(self.ops))
+        if barrier:
+            self.barriers.add(len(self.ops))
 
     def emit(self, op, dst, a=0, b=0, m=0, n=0, p=0, flags=0):
         self.ops.append((op, int(dst), int(a), int(b), int(m), int(n), int(p), int(flags)))
@@ -404,7 +407,7 @@ class GenericPlan(object):
 
     def _program(self, t):
         ops = t.ops
-        cuts = [m for m in t.marks if m < len(ops)] + [len(ops)]
+        cuts = sorted(set(m for m in t.marks if m < len(ops))) + [len(ops)]
         segs = []                                   # (first record, count, nodes read, nodes written)
         prologue = cuts[0] > 0                      # records before the first node (the result vector of llb_sum): they set up
         if prologue:                                # temporaries the nodes write into, so they run first and alone
@@ -441,7 +444,7 @@ class GenericPlan(object):
         run, rr, rw = [], set(), set()
         for k, seg in enumerate(segs):
             _, _, reads, writes = seg
-            if writes & (rr | rw) or reads & rw or (prologue and k == 1):
+            if writes & (rr | rw) or reads & rw or (prologue and k == 1) or seg[0] in t.barriers:
                 flush(run)
                 run, rr, rw = [], set(), set()
             run.append(seg); rr |= reads; rw |= writes
@@ -706,13 +709,65 @@ class GenericPlan(object):
             return t.axpby(float(nd.shape[0]), t.unary(s["qv"], U_LOG), -2.0, o2.elem(1))
         raise NotImplementedError("pass_down_lndet of %s" % type(nd).__name__)
 
+    def _ordered_sums(self, t, inits, count, item):
+        """K sums at once: inits[k] + the terms item(0)[k], item(1)[k], ... (lists of Refs shaped like inits[k], or (factor, Ref)
+        pairs, the factor a python float or a 1 x 1 Ref; inits[k] may be None: the sum then starts with the first term), added in
+        that order.  From PAR_MIN items on,
+        each item is emitted as a block of its own and its terms land in rows of one matrix per sum, which a single product
+        with a row of ones adds up -- in the same order, so the result is bitwise the chain of additions -- after a barrier:
+        the items (the messages of a node's children) are then issued side by side (see _program)."""
+        K = len(inits)
+        if count < self.PAR_MIN:
+            accs = [None if a is None else t.copy(a) for a in inits]
+            for i in range(count):
+                for k, terms in enumerate(item(i)):
+                    for term in terms:
+                        f, term = term if isinstance(term, tuple) else (1.0, term)
+                        if accs[k] is None:
+                            accs[k] = t.copy(term) if (not isinstance(f, Ref) and f == 1.0) else t.axpby(f, term)
+                        else:
+                            t.axpby(1.0, accs[k], f, term, dst=accs[k])
+            return accs
+        rows, per, shape = [None] * K, [0] * K, [None] * K
+        for i in range(count):
+            t.mark()
+            for k, terms in enumerate(item(i)):
+                terms = [term if isinstance(term, tuple) else (1.0, term) for term in terms]
+                if rows[k] is None:
+                    per[k] = len(terms)
+                    shape[k] = (terms[0][1].m, terms[0][1].n) if inits[k] is None else (inits[k].m, inits[k].n)
+                    rows[k] = t.tmp((0 if inits[k] is None else 1) + count * per[k], shape[k][0] * shape[k][1])
+                size, base = rows[k].n, 0 if inits[k] is None else 1
+                assert len(terms) == per[k]
+                for j, (f, term) in enumerate(terms):
+                    assert term.size == size, "terms of different shapes cannot be summed (the reference raises there too)"
+                    dst = Ref(rows[k].off + (base + i * per[k] + j) * size, 1, size)
+                    if not isinstance(f, Ref) and f == 1.0:
+                        t.copy(Ref(term.off, 1, size), dst=dst)
+                    else:
+                        t.axpby(f, Ref(term.off, 1, size), dst=dst)
+        t.mark(barrier=True)
+        out = []
+        for k in range(K):
+            size = rows[k].n
+            if inits[k] is not None:
+                t.copy(Ref(inits[k].off, 1, size), dst=Ref(rows[k].off, 1, size))
+            ones = t.unary(t.zeros(1, rows[k].m), 5)           # exp(0): a row of ones of any length without the constant pool
+            r = t.gemm(ones, rows[k])
+            out.append(Ref(r.off, shape[k][0], shape[k][1]))
+        return out
+
     def _sum_child_messages(self, t, nd):
-        msgs = [self._pass_up(t, c, nd) for c in nd.children]
-        if not msgs:
+        kids = nd.children
+        if not kids:
             raise NotImplementedError("a %s without children was asked for a message" % type(nd).__name__)
-        m1, m2 = msgs[0][0], msgs[0][1]
-        for m in msgs[1:]:
-            m1, m2 = t.add(m1, m[0]), t.add(m2, m[1])
+        msgs = []
+
+        def item(i):
+            m = self._pass_up(t, kids[i], nd)
+            msgs.append(m)
+            return [m[0]], [m[1]]
+        m1, m2 = self._ordered_sums(t, [None, None], len(kids), item)
         return m1, m2, msgs
 
     def _pass_up(self, t, nd, requester):
@@ -759,23 +814,23 @@ class GenericPlan(object):
             if nd.shape[1] == 1:
                 m1, m2, _ = self._sum_child_messages(t, nd)
                 return m1, m2
-            msgs = [self._pass_up(t, c, nd) for c in nd.children]
+            kids = nd.children
             i = nd.parents.index(requester)
             rows = nd.shape[0]
-            m1 = t.zeros(rows, rows)
-            m2 = t.zeros(rows, 1)
-            for m in msgs:
+
+            def item(c):
+                m = self._pass_up(t, kids[c], nd)
                 if len(m) != 4:
                     raise NotImplementedError("an hstack matrix must be the left operand of its Multiplication children")
                 cm1, cm2, bex, bbt = m
                 if cm1.size == 1:
                     cm1 = t.scale(t.eye(rows), cm1)
-                t.axpby(1.0, m1, bbt.elem(i, i), cm1, dst=m1)                  # (:56)
-                t.axpby(1.0, m2, bex.elem(i), cm2, dst=m2)                      # (:60)
+                t2 = [(bex.elem(i), cm2)]                                       # (:60)
                 for j, pj in enumerate(nd.parents):                             # (:61)
                     if j != i:
-                        w = t.gemm(cm1, self._ex(t, pj))
-                        t.axpby(1.0, m2, t.scale(bbt.elem(i, j), -1.0), w, dst=m2)
+                        t2.append((t.scale(bbt.elem(i, j), -1.0), t.gemm(cm1, self._ex(t, pj))))
+                return [(bbt.elem(i, i), cm1)], t2                              # (:56)
+            m1, m2 = self._ordered_sums(t, [t.zeros(rows, rows), t.zeros(rows, 1)], len(kids), item)
             return m1, m2
         raise NotImplementedError("pass_up_m1_m2 of %s" % type(nd).__name__)
 
@@ -786,15 +841,15 @@ class GenericPlan(object):
         d = s["qmu"].m
         pmu = self._ex(t, nd.mean_parent)
         pprec = self._ex(t, nd.precision_parent)
-        qprec = t.copy(pprec)
-        wex = t.gemm(pprec, pmu)
-        for c in nd.children:
-            m = self._pass_up(t, c, nd)
+        kids = nd.children
+
+        def item(i):
+            m = self._pass_up(t, kids[i], nd)
             m1, m2 = m[0], m[1]
             if m1.size == 1 and d > 1:
                 m1 = t.scale(t.eye(d), m1)
-            t.axpby(1.0, qprec, 1.0, m1, dst=qprec)                              # (:117)
-            t.axpby(1.0, wex, 1.0, m2, dst=wex)                                  # (:122)
+            return [m1], [m2]
+        qprec, wex = self._ordered_sums(t, [pprec, t.gemm(pprec, pmu)], len(kids), item)    # (:117, :122)
         t.cholinv(qprec, dst=s["qcov"], out2=s["qld"])                           # (:118-120)
         t.gemm(s["qcov"], wex, dst=s["qmu"])                                     # (:123)
         if nd.partially_observed:                                                # (:125-134)
@@ -807,33 +862,30 @@ class GenericPlan(object):
             t.gemm(gain, delta, dst=s["qmu"], acc=True)
             t.gemm(gain, cov_obs_all, tb=True, dst=s["qcov"], acc=True, neg=True)
 
-    def _children_residual(self, t, nd):
-        """per child: <x x^T>, <mu mu^T>, <x><mu>^T (nodes_todo.py:138, :190, :231)"""
-        for c in nd.children:
-            yield self._exxt(t, c), self._exxt(t, c.mean_parent), t.gemm(self._ex(t, c), self._ex(t, c.mean_parent), tb=True)
-
     def _emit_update_noise(self, t, nd):
         s = self.slot[id(nd)]
+        kids = nd.children
+
+        def residual(i):                        # per child: <x x^T>, <mu mu^T>, <x><mu>^T (nodes_todo.py:138, :190, :231)
+            c = kids[i]
+            return self._exxt(t, c), self._exxt(t, c.mean_parent), t.gemm(self._ex(t, c), self._ex(t, c.mean_parent), tb=True)
         if isinstance(nd, N.Gamma):                              # nodes_todo.py:130-138
-            acc = t.copy(t.const(float(nd.b0)))
-            for xx, mm, xm in self._children_residual(t, nd):
-                t.axpby(1.0, acc, 0.5, t.trace(xx), dst=acc)
-                t.axpby(1.0, acc, 0.5, t.trace(mm), dst=acc)
-                t.axpby(1.0, acc, -1.0, t.trace(xm), dst=acc)
+            def item(i):
+                xx, mm, xm = residual(i)
+                return [[(0.5, t.trace(xx)), (0.5, t.trace(mm)), (-1.0, t.trace(xm))]]
+            acc, = self._ordered_sums(t, [t.const(float(nd.b0))], len(kids), item)
             t.copy(acc, dst=s["qb"])
         elif isinstance(nd, N.DiagonalGamma):                    # nodes_todo.py:187-190
-            acc = t.copy(s["b0"])
-            for xx, mm, xm in self._children_residual(t, nd):
-                t.axpby(1.0, acc, 0.5, t.diag_of(xx), dst=acc)
-                t.axpby(1.0, acc, 0.5, t.diag_of(mm), dst=acc)
-                t.axpby(1.0, acc, -1.0, t.diag_of(xm), dst=acc)
+            def item(i):
+                xx, mm, xm = residual(i)
+                return [[(0.5, t.diag_of(xx)), (0.5, t.diag_of(mm)), (-1.0, t.diag_of(xm))]]
+            acc, = self._ordered_sums(t, [s["b0"]], len(kids), item)
             t.copy(acc, dst=s["qb"])
         elif isinstance(nd, N.Wishart):                          # nodes_todo.py:228-231 (w0 is not mutated: SURVEY Q7)
-            acc = t.copy(s["w0"])
-            for xx, mm, xm in self._children_residual(t, nd):
-                t.axpby(1.0, acc, 0.5, xx, dst=acc)
-                t.axpby(1.0, acc, 0.5, mm, dst=acc)
-                t.axpby(1.0, acc, -1.0, xm, dst=acc)
+            def item(i):
+                xx, mm, xm = residual(i)
+                return [[(0.5, xx), (0.5, mm), (-1.0, xm)]]
+            acc, = self._ordered_sums(t, [s["w0"]], len(kids), item)
             t.copy(acc, dst=s["qw"])
         else:
             raise NotImplementedError("update of %s" % type(nd).__name__)
