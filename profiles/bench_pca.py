@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""A bench line in bench.py's format for the SECOND workload, BASELINE configs[4]: VB-PCA with missing data, N = 10^6 rows x
+d = 256, q = 16, 10 % missing, on one GPU.  bench.py itself stays on the headline metric; this script measures the same way
+(inputs resident before the timed region, K steps after W warm-up steps, a parity check on the timed problem's head, the
+oracle timed on a bounded sample as CPU baseline) and adds the HBM roofline of an iteration.
+
+    python profiles/bench_pca.py [--rows 1000000] [--steps 20] [--warmup 3]
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def rows(lo, hi, d, q, seed, block=10000):
+    g = np.random.default_rng(seed)
+    W = g.standard_normal((d, q)); mean = g.standard_normal(d); W0 = g.standard_normal((d, q))
+    X, obs, Z0 = [], [], []
+    for b0 in range(lo // block * block, hi, block):
+        r = np.random.default_rng([seed, b0 // block])
+        x = r.standard_normal((block, q)) @ W.T + mean + 0.2 * r.standard_normal((block, d))
+        o = r.random((block, d)) > 0.1
+        z0 = r.standard_normal((block, q))
+        a, e = max(lo, b0) - b0, min(hi, b0 + block) - b0
+        X.append(x[a:e]); obs.append(o[a:e]); Z0.append(z0[a:e])
+    return np.concatenate(X), np.concatenate(obs), np.concatenate(Z0), W0
+
+
+def problem(N, d, q, seed):
+    X, obs, Z0, W0 = rows(0, N, d, q, seed)
+    init = {"obs": obs, "X": np.where(obs, X, 0.0), "W_mean": W0, "Z": Z0, "Z_cov": np.eye(q), "Mu_mean": np.zeros(d), "beta_b": 1.0}
+    pri = {"W_prior_mean": np.zeros((d, q)), "W_prior_prec": np.full((q, d), 1e-3), "Mu_prior_mean": np.zeros(d),
+           "Mu_prior_prec": np.full(d, 1e-3), "beta_a0": 1e-3, "beta_b0": 1e-3}
+    return init, pri
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1000000); ap.add_argument("--d", type=int, default=256); ap.add_argument("--q", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    from pyvb_amd.pca import PCABatch                  # raises without libpyvb_hip.so: no fallback
+    N, d, q = a.rows, a.d, a.q
+    init, pri = problem(N, d, q, 33)
+    b = PCABatch.from_problem(init, pri)
+    b.iterate(a.warmup); b.sync()
+    t0 = time.perf_counter()
+    b.iterate(a.steps); b.sync()
+    dt = time.perf_counter() - t0
+    elbo = b.elbo()
+    st = b.get_state()
+    b.close()
+    # parity: the same model on the first rows only is a different problem; instead the oracle runs the WHOLE iteration count on a
+    # small copy of the problem and the device on that copy too (same code path, same kernels, fewer chunks)
+    from oracle import pca_closed_form as P        # checker and CPU baseline only
+    n_s = 20000
+    sinit, _ = problem(n_s, d, q, 33)
+    sb = PCABatch.from_problem(sinit, pri); sb.iterate(a.warmup + a.steps); got = sb.get_state(); ge = sb.elbo(); sb.close()
+    sst = P.make_state(sinit, pri, n_s, d, q)
+    t1 = time.perf_counter()
+    for _ in range(a.warmup + a.steps):
+        ref = P.iterate(sst, pri)
+    cpu_dt = time.perf_counter() - t1
+    rel = lambda x, y: float(np.abs(x - y).max() / np.abs(y).max())
+    parity = max(rel(got["W_mean"], sst["W_mean"]), rel(got["Z"], sst["Z"]), rel(got["X"], sst["X"]), float(np.abs(ge - ref).max() / np.abs(ref).sum()))
+    nmiss = float((~init["obs"]).sum())
+    # algorithmic bytes of an iteration: X is read by both passes, the byte mask by the second, Z written by the first and read by
+    # the second, the missing entries written back
+    alg = 2.0 * N * d * 8 + N * d + 2.0 * N * q * 8 + nmiss * 8
+    step_s = dt / a.steps
+    out = {"metric": "VB-PCA iterations/sec (N=1e6 rows x 256, q=16, 10% missing); rel-err vs NumPy", "value": a.steps / dt, "unit": "VB iterations/s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic low-rank rows + noise, Bernoulli(0.1) missing entries",
+           "config": {"workload": "VB-PCA N=%d d=%d q=%d (BASELINE configs[4] on one GPU)" % (N, d, q),
+                      "rel_err_vs_numpy": parity, "parity_checked_on": "a %d-row copy of the problem, %d iterations, same kernels" % (n_s, a.warmup + a.steps),
+                      "elbo_total": float(elbo.sum()), "beta": float(st["beta_a"] / st["beta_b"])},
+           "roofline": {"bound": "hbm", "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "traffic_source": "profiles/r02/traffic_pca_pmc.json holds the PMC bytes of the two passes (not measured in this run)",
+                        "kernel": "whole iteration (k_pca_pass1 + k_pca_pass2 + small kernels)", "algorithmic_bytes_per_iteration": alg},
+           "cpu_baseline": None if a.no_cpu_baseline else {"value": (a.warmup + a.steps) / cpu_dt * n_s / N, "unit": "VB iterations/s at N=%d (scaled from the sample)" % N,
+                                                           "cores": os.cpu_count(), "kind": "port",
+                                                           "sample": "%d rows, %d iterations of oracle/pca_closed_form.py in %.1f s" % (n_s, a.warmup + a.steps, cpu_dt)}}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
