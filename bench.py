@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- VB update iterations/sec of the LDS path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one variational iteration of every replicate resident on the rank's GPU:
@@ -87,6 +87,61 @@ def cpu_baseline_and_parity(sample, pri, iters, got_elbo, got_X):
     return base, rel, rel_x
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: this process -- which has not touched the GPU (pyvb_amd is imported
+    only further down, in the ranks) -- starts N fresh child processes of this script, one per GPU, with the environment a
+    launcher would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relays rank 0's JSON line and
+    returns non-zero if any rank fails or the line does not say n_gpus == N.  Children are started with subprocess, never
+    by replacing this process."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYVB_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), text=True))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()))
+    reader.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+                for o in live:
+                    procs[o].terminate()        # exactly the children started above
+        time.sleep(0.05)
+    reader.join()
+    lines = [l for l in out0 if l.startswith("{")]
+    for l in out0:
+        if not l.startswith("{"):
+            sys.stderr.write(l)
+    if rc:
+        return rc
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
+        return 1
+    d = json.loads(lines[0])
+    if d.get("n_gpus") != n:
+        sys.stderr.write("bench.py: asked for %d GPUs, the line reports n_gpus = %r\n" % (n, d.get("n_gpus")))
+        return 1
+    sys.stdout.write(lines[0])
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,11 +161,17 @@ def main():
                          "sockets (line marked degraded) instead of failing")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks ourselves (nothing has touched the GPU in this process yet)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        # one rank asked to stand for N GPUs (or the reverse) would put a wrong n_gpus beside a real number: refuse
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (python bench.py --gpus N does so itself)" % (args.gpus, world))
 
     from pyvb_amd.lds import LDSBatch      # raises if libpyvb_hip.so is missing: no fallback
     from pyvb_amd import dist as pdist

@@ -13,8 +13,10 @@ Two implementations of the same small interface:
               profiles/r02/README.md).
   GlooComm    torch.distributed's gloo backend, for the CPU tests of the sharding logic (tests/test_dist_gloo.py).
 """
+import hashlib
+import hmac
+import json
 import os
-import pickle
 import socket
 import struct
 import time
@@ -102,36 +104,111 @@ class GlooComm(object):
             self._dist.destroy_process_group()
 
 
+# ---- wire format of the TCP rendezvous.  Nothing received from a socket is ever unpickled or evaluated: a frame is
+#   1 byte tag | u32 little-endian length | payload,   length <= MAX_FRAME
+# with tags  N none | I int64 | F float64 | B bytes | A float64 array (payload = u32 ndim, ndim x u64 shape, raw doubles) |
+# J a JSON object (the hello only).  Anything else closes the connection.
+MAX_FRAME = 64 << 20
+
+
+def _pack(obj):
+    if obj is None:
+        return b"N", b""
+    if isinstance(obj, (bool, int, np.integer)):
+        return b"I", struct.pack("<q", int(obj))
+    if isinstance(obj, (float, np.floating)):
+        return b"F", struct.pack("<d", float(obj))
+    if isinstance(obj, (bytes, bytearray, memoryview)):
+        return b"B", bytes(obj)
+    if isinstance(obj, np.ndarray):
+        a = np.ascontiguousarray(obj, dtype=np.float64)
+        return b"A", struct.pack("<I", a.ndim) + struct.pack("<%dQ" % a.ndim, *a.shape) + a.tobytes()
+    if isinstance(obj, dict):
+        return b"J", json.dumps(obj, sort_keys=True).encode("utf-8")
+    raise TypeError("the rendezvous carries None, int, float, bytes, float64 arrays and the hello object, not %r" % (type(obj),))
+
+
+def _unpack(tag, data):
+    if tag == b"N" and not data:
+        return None
+    if tag == b"I" and len(data) == 8:
+        return struct.unpack("<q", data)[0]
+    if tag == b"F" and len(data) == 8:
+        return struct.unpack("<d", data)[0]
+    if tag == b"B":
+        return data
+    if tag == b"A" and len(data) >= 4:
+        (nd,) = struct.unpack_from("<I", data)
+        if nd <= 8 and len(data) >= 4 + 8 * nd:
+            shape = struct.unpack_from("<%dQ" % nd, data, 4)
+            count = 1
+            for s in shape:
+                count *= s
+            if 4 + 8 * nd + 8 * count == len(data):
+                return np.frombuffer(data, dtype=np.float64, offset=4 + 8 * nd).reshape(shape).copy()
+    if tag == b"J":
+        obj = json.loads(data.decode("utf-8"))
+        if isinstance(obj, dict):
+            return obj
+    raise ConnectionError("malformed rendezvous frame (tag %r, %d bytes)" % (tag, len(data)))
+
+
 def _send(sock, obj):
-    data = pickle.dumps(obj, protocol=4)
-    sock.sendall(struct.pack("<Q", len(data)) + data)
+    tag, data = _pack(obj)
+    if len(data) > MAX_FRAME:
+        raise ValueError("rendezvous frame of %d bytes exceeds the cap of %d" % (len(data), MAX_FRAME))
+    sock.sendall(tag + struct.pack("<I", len(data)) + data)
 
 
 def _recv(sock):
     def exact(n):
-        buf = b""
+        buf = bytearray()
         while len(buf) < n:
-            chunk = sock.recv(n - len(buf))
+            chunk = sock.recv(min(n - len(buf), 1 << 20))
             if not chunk:
                 raise ConnectionError("peer closed the rendezvous connection")
             buf += chunk
-        return buf
-    (n,) = struct.unpack("<Q", exact(8))
-    return pickle.loads(exact(n))
+        return bytes(buf)
+    head = exact(5)
+    (n,) = struct.unpack("<I", head[1:])
+    if n > MAX_FRAME:
+        raise ConnectionError("rendezvous frame of %d bytes exceeds the cap of %d" % (n, MAX_FRAME))
+    return _unpack(head[:1], exact(n))
+
+
+def _is_loopback(addr):
+    return addr in ("localhost", "::1") or addr.startswith("127.")
 
 
 class SocketComm(object):
     """Rank 0 listens, the others connect (MASTER_ADDR; a port derived from MASTER_PORT, which the launcher's own store
-    occupies); every collective is a gather to rank 0 and a broadcast back.  A few bytes per call, a few calls per run."""
-    TOKEN = "pyvb-rendezvous-1"
+    occupies); every collective is a gather to rank 0 and a broadcast back.  A few bytes per call, a few calls per run.
+
+    Admission: rank 0 sends a random challenge; the peer answers with a hello object (protocol token, run id, base port,
+    world size, its rank) and an HMAC-SHA256 of challenge + hello under a shared secret.  On the loopback interface the
+    secret defaults to a fixed string (any local process could read the environment anyway); for any other MASTER_ADDR it
+    must come from PYVB_RENDEZVOUS_SECRET, identical on every rank, or the constructor refuses to run."""
+    TOKEN = "pyvb-rendezvous-2"
+    HELLO_TIMEOUT = 5.0          # per connection attempt, until the peer has been admitted
 
     def __init__(self, world, rank, timeout=180.0):
         self.world, self.rank = int(world), int(rank)
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         base = int(os.environ.get("MASTER_PORT", "29500"))
         run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+        secret = os.environ.get("PYVB_RENDEZVOUS_SECRET", "")
+        if not secret:
+            if not _is_loopback(addr):
+                raise RuntimeError("rendezvous on %s (not the loopback interface) needs PYVB_RENDEZVOUS_SECRET set to the same "
+                                   "value on every rank" % addr)
+            secret = "pyvb-loopback"
+        key = secret.encode("utf-8")
         ports = [20000 + (base * 31 + 97 * i) % 30000 for i in range(8)]
-        hello = (self.TOKEN, run, base, self.world)
+        hello = {"token": self.TOKEN, "run": run, "base": base, "world": self.world}
+
+        def mac(challenge, obj):
+            return hmac.new(key, challenge + json.dumps(obj, sort_keys=True).encode("utf-8"), hashlib.sha256).digest()
+
         deadline = time.time() + timeout
         if self.rank == 0:
             srv = None
@@ -156,35 +233,48 @@ class SocketComm(object):
                     c, _ = srv.accept()
                 except socket.timeout:
                     continue
-                c.settimeout(timeout)
                 try:
-                    msg = _recv(c)
-                except Exception:
+                    c.settimeout(self.HELLO_TIMEOUT)
+                    challenge = os.urandom(32)
+                    _send(c, challenge)
+                    msg, tag = _recv(c), _recv(c)
+                    r = msg.get("rank") if isinstance(msg, dict) else None
+                    good = (isinstance(r, int) and 0 < r < self.world and r not in self.peers
+                            and {k: msg.get(k) for k in hello} == hello
+                            and isinstance(tag, bytes) and hmac.compare_digest(tag, mac(challenge, msg)))
+                    _send(c, 1 if good else 0)
+                    if not good:
+                        c.close()
+                        continue
+                    c.settimeout(timeout)
+                    self.peers[r] = c
+                except Exception:               # a stranger, a garbled frame, a stalled peer: drop it, keep listening
                     c.close()
-                    continue
-                if msg[:4] != hello or not (0 < msg[4] < self.world) or msg[4] in self.peers:
-                    _send(c, "no")
-                    c.close()
-                    continue
-                _send(c, "ok")
-                self.peers[msg[4]] = c
             srv.close()
         else:
             self.sock = None
+            mine = dict(hello, rank=self.rank)
             while self.sock is None:
                 if time.time() > deadline:
                     raise TimeoutError("rendezvous: rank %d found no rank 0 at %s ports %r" % (self.rank, addr, ports))
                 for p in ports:
+                    c = None
                     try:
                         c = socket.create_connection((addr, p), timeout=2.0)
-                        c.settimeout(timeout)
-                        _send(c, hello + (self.rank,))
-                        if _recv(c) == "ok":
+                        c.settimeout(self.HELLO_TIMEOUT)
+                        challenge = _recv(c)
+                        if not isinstance(challenge, bytes) or len(challenge) != 32:
+                            raise ConnectionError("not a pyvb rendezvous")
+                        _send(c, mine)
+                        _send(c, mac(challenge, mine))
+                        if _recv(c) == 1:
+                            c.settimeout(timeout)
                             self.sock = c
                             break
                         c.close()
-                    except OSError:
-                        pass
+                    except Exception:           # another service on that port, a garbled reply, a time-out: next port
+                        if c is not None:
+                            c.close()
                 else:
                     time.sleep(0.2)
 

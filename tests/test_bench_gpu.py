@@ -70,3 +70,35 @@ def test_two_ranks_on_one_gpu_fail_loudly_or_run_over_rccl():
         d = _line(r2.stdout)
         assert d["n_gpus"] == 2 and d["config"]["degraded"] is True and "DEGRADED" in d["config"]["collective"]
         assert d["config"]["replicates_total"] == 12
+
+
+def test_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent starts two fresh ranks itself and relays
+    rank 0's line; the line must say n_gpus == 2 (round 2 ran ONE rank and said n_gpus 1).  On this one-GPU box RCCL
+    refuses the second rank on the same device: without --allow-host-fallback the run fails naming the reason, with it the
+    line is marked degraded."""
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "NCCL_DEBUG": "WARN"}
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env_clean.update(env)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL, cwd=REPO, env=env_clean,
+                       capture_output=True, text=True, timeout=600)
+    if r.returncode == 0:
+        d = _line(r.stdout)
+        assert d["n_gpus"] == 2 and d["config"]["collective"].startswith("rccl") and d["config"]["degraded"] is False
+        return
+    both = r.stderr + r.stdout
+    assert "Duplicate GPU" in both, both[-3000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no line from a failed run
+    r2 = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--allow-host-fallback"] + SMALL, cwd=REPO, env=env_clean,
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    d = _line(r2.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["replicates_total"] == 2 * 6
+    assert d["config"]["degraded"] is True and "DEGRADED" in d["config"]["collective"]
+    assert d["config"]["elbo_rel_err_vs_numpy"] < 1e-8
+
+
+def test_one_rank_cannot_stand_for_several_gpus():
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL, {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

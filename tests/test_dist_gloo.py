@@ -86,3 +86,92 @@ def test_five_ranks_over_sockets(tmp_path):
     res = [np.load(tmp_path / ("rank%d.npy" % r)) for r in range(5)]
     assert all(np.array_equal(r[:6], res[0][:6]) for r in res) and all(r[6] == 5.0 for r in res)
     assert [(int(r[8]), int(r[9])) for r in res] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)]
+
+
+def test_wire_format_round_trips_and_never_unpickles():
+    """The rendezvous frames are typed raw bytes (pyvb_amd/dist.py): every value the collectives carry survives a round trip,
+    an oversized or malformed frame raises instead of being interpreted, and nothing on the wire is a pickle."""
+    import socket
+    import struct
+    from pyvb_amd import dist
+    a, b = socket.socketpair()
+    try:
+        vals = [None, 0, -7, 2.5, b"\x00\x01" * 64, np.arange(6.0), np.arange(12.0).reshape(3, 4), {"token": "t", "rank": 1}]
+        for v in vals:
+            dist._send(a, v)
+            got = dist._recv(b)
+            if isinstance(v, np.ndarray):
+                assert got.dtype == np.float64 and np.array_equal(got, v)
+            else:
+                assert got == v and type(got) is type(v)
+        with pytest.raises(TypeError):
+            dist._send(a, [1, 2])                                  # lists, tuples, objects: not carried
+        import pickle
+        blob = pickle.dumps(("x",), protocol=4)                    # what round 2's wire looked like: an 8-byte length + pickle
+        a.sendall(struct.pack("<Q", len(blob)) + blob)
+        with pytest.raises((ConnectionError, ValueError)):
+            dist._recv(b)
+    finally:
+        a.close()
+        b.close()
+    a, b = socket.socketpair()
+    try:
+        a.sendall(b"B" + struct.pack("<I", dist.MAX_FRAME + 1))    # a length beyond the cap is refused before any allocation
+        with pytest.raises(ConnectionError):
+            dist._recv(b)
+        a.sendall(b"A" + struct.pack("<I", 12) + struct.pack("<I", 1) + struct.pack("<Q", 1 << 40))   # shape disagrees with size
+        with pytest.raises(ConnectionError):
+            dist._recv(b)
+    finally:
+        a.close()
+        b.close()
+    assert "pickle" not in open(dist.__file__).read().replace("unpickled", "").replace("a pickle", "")
+
+
+def test_rendezvous_refuses_strangers_and_non_loopback_without_secret(monkeypatch):
+    """Rank 0 keeps listening after a peer that sends garbage or a wrong MAC; a non-loopback MASTER_ADDR without
+    PYVB_RENDEZVOUS_SECRET is refused outright."""
+    import socket
+    import threading
+    from pyvb_amd import dist
+    monkeypatch.setenv("MASTER_ADDR", "10.1.2.3")
+    monkeypatch.delenv("PYVB_RENDEZVOUS_SECRET", raising=False)
+    with pytest.raises(RuntimeError, match="PYVB_RENDEZVOUS_SECRET"):
+        dist.SocketComm(2, 1, timeout=1.0)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29549")
+    box = {}
+
+    def rank0():
+        box["c"] = dist.SocketComm(2, 0, timeout=60.0)
+    th = threading.Thread(target=rank0)
+    th.start()
+    base = 29549
+    port = 20000 + (base * 31) % 30000
+    import time
+    for attempt in range(100):
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.1)
+    ch = dist._recv(s)
+    assert isinstance(ch, bytes) and len(ch) == 32
+    s.sendall(b"\x80\x04garbage-that-is-not-a-frame" * 3)          # a stranger
+    s.close()
+    s = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+    ch = dist._recv(s)
+    dist._send(s, {"token": dist.SocketComm.TOKEN, "run": "none", "base": base, "world": 2, "rank": 1})
+    dist._send(s, b"\x00" * 32)                                     # right hello, wrong MAC
+    assert dist._recv(s) == 0
+    s.close()
+    peer = dist.SocketComm(2, 1, timeout=30.0)                      # the real rank 1 still gets in
+    th.join(60)
+    assert not th.is_alive()
+    t = threading.Thread(target=lambda: box.__setitem__("m", box["c"].max_float(1.0)))
+    t.start()
+    assert peer.max_float(3.0) == 3.0
+    t.join(30)
+    assert box["m"] == 3.0
+    peer.close()
+    box["c"].close()
