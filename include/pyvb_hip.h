@@ -59,6 +59,9 @@ enum { PYVB_K_PREP = 0, PYVB_K_SWEEP_FWD = 1, PYVB_K_STATS = 2, PYVB_K_PARAMS = 
 
 const char* pyvb_last_error(void);
 int pyvb_version(void);
+/* first 32 hex digits of the sha256 over the library's source files (pyvb_amd/csrc/Makefile: BUILD_ID): lets a caller check
+ * that a prebuilt libpyvb_hip.so is the build of the sources beside it */
+const char* pyvb_build_id(void);
 int pyvb_device_count(int* count);
 
 /* Graph construction: Linear_Dynamic_System.py:46-66 for N replicates
@@ -214,7 +217,9 @@ int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi);
 /* Xs[0].update() of the GLOBAL row 0 (the crawl order updates it alone, before Mu).  With a communicator attached every update
  * call is a collective: all ranks issue the same calls in the same order, pyvb_pca_update_X with their local part of the range
  * (possibly empty).  This one is the single-row step for every rank: the owner of global row 0 updates it, all ranks exchange
- * the change of sum x.  (On one rank it is pyvb_pca_update_X(h, 0, 1).) */
+ * the change of sum x.  (Without a communicator pyvb_pca_update_X(h, 0, 1) takes this shortcut by itself; with one it does not
+ * -- the two are different collectives -- and runs the general row-range update, which every rank matches by calling
+ * pyvb_pca_update_X with its own, possibly empty, part.) */
 int pyvb_pca_update_X0(pyvb_pca* h);
 int pyvb_pca_update_Mu(pyvb_pca* h);
 int pyvb_pca_update_Beta(pyvb_pca* h);

@@ -27,6 +27,7 @@ HOST_ALLREDUCE = ctypes.CFUNCTYPE(ctypes.c_int, _dp, ctypes.c_size_t, ctypes.c_v
 SIGNATURES = {
     "pyvb_last_error": (ctypes.c_char_p, []),
     "pyvb_version": (ctypes.c_int, []),
+    "pyvb_build_id": (ctypes.c_char_p, []),
     "pyvb_device_count": (ctypes.c_int, [_ip]),
     "pyvb_lds_create": (ctypes.c_int, [ctypes.POINTER(_h)] + [ctypes.c_int] * 6),
     "pyvb_lds_destroy": (ctypes.c_int, [_h]),
@@ -121,6 +122,23 @@ def load():
 
 
 lib = load()
+
+
+def source_id():
+    """What pyvb_build_id() must return for a library built from the sources in this tree (pyvb_amd/csrc/Makefile: BUILD_ID),
+    or None when the sources are not beside the package."""
+    import hashlib
+    import re
+    src = os.path.join(_HERE, "csrc")
+    try:
+        mk = open(os.path.join(src, "Makefile")).read()
+        names = re.search(r"^SRCS\s*=\s*(.*)$", mk, re.M).group(1).split() + re.search(r"^HDRS\s*=\s*(.*)$", mk, re.M).group(1).split()
+        h = hashlib.sha256()
+        for n in names + ["Makefile"]:
+            h.update(open(os.path.join(src, n), "rb").read())
+        return h.hexdigest()[:32]
+    except (OSError, AttributeError):
+        return None
 
 
 def check(rc):

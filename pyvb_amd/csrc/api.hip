@@ -441,12 +441,14 @@ int pyvb_lds_set_output_state(pyvb_lds* h, const double* Yq, const double* Yrowv
     if ((size_t)h->K > (size_t)h->L.DP) { HIPCHK(hipMalloc((void**)&tmp, n * sizeof(double))); dq = tmp; }
     double* dv = h->X[1 - h->cur];      // [N][T][DP] >= [N][T]
     int rc;
-    if ((rc = h2d(h, dq, Yq, n))) return rc;
-    if ((rc = h2d(h, dv, Yrowvar, (size_t)h->N * h->T))) return rc;
-    if ((rc = launch_missing_init(h, dq, dv))) return rc;
-    if ((rc = launch_syy_missing(h))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = h2d(h, dq, Yq, n)) || (rc = h2d(h, dv, Yrowvar, (size_t)h->N * h->T)) ||
+        (rc = launch_missing_init(h, dq, dv)) || (rc = launch_syy_missing(h))) {
+        if (tmp) { (void)hipStreamSynchronize(h->stream); (void)hipFree(tmp); }
+        return rc;
+    }
+    const hipError_t se = hipStreamSynchronize(h->stream);
     if (tmp) (void)hipFree(tmp);
+    HIPCHK(se);
     h->u_valid = false;
     states_changed(h);
     return PYVB_OK;

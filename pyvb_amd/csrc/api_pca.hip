@@ -323,7 +323,10 @@ static int x_rows(pyvb_pca* h, long lo, long hi) {
 int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi) {
     ENTER(h);
     ARGCHK(lo >= 0 && lo <= hi && hi <= h->N, "bad row range");
-    if (lo == 0 && hi == 1 && h->row_offset == 0) return x0_step(h);        // this rank owns global row 0
+    // the single-row step of global row 0 is a different collective (x0_step all-reduces QP + DP doubles, x_rows the whole
+    // statistics vector): with a communicator attached every rank must make the same call, so the shortcut is taken only
+    // without one -- sharded callers reach it through pyvb_pca_update_X0 on every rank
+    if (lo == 0 && hi == 1 && h->row_offset == 0 && !h->comm) return x0_step(h);
     return x_rows(h, lo, hi);
 }
 

@@ -33,7 +33,11 @@ struct TapeArgs { double* arena; size_t arena_n; const int* ops; int nops; int* 
 #define TAPE_THREADS 256
 
 __device__ static double tape_digamma(double x) {
+    // the recurrence below takes 10 - x steps: bounded here, so that no argument (a degenerate qv, -inf, a NaN from bad
+    // state) can keep a workgroup spinning.  Not finite: NaN (+inf: +inf); below -64: the reflection formula.
+    if (!(x - x == 0.0)) return x > 0 ? x : __builtin_nan("");
     double r = 0.0;
+    if (x < -64.0) { r = -M_PI / tan(M_PI * x); x = 1.0 - x; }
     while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
     const double f = 1.0 / (x * x);
     const double ser = f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))));
@@ -236,7 +240,7 @@ int pyvb_graph_destroy(pyvb_graph* g) {
 }
 
 int pyvb_graph_write(pyvb_graph* g, size_t offset, const double* src, size_t n) {
-    ARGCHK(g && src && offset + n <= g->arena_n, "write outside the arena");
+    ARGCHK(g && src && n <= g->arena_n && offset <= g->arena_n - n, "write outside the arena");
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(hipMemcpyAsync(g->arena + offset, src, n * sizeof(double), hipMemcpyHostToDevice, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));        // src is the caller's buffer
@@ -259,7 +263,7 @@ int pyvb_graph_sync(pyvb_graph* g) {
 }
 
 int pyvb_graph_read(pyvb_graph* g, size_t offset, double* dst, size_t n) {
-    ARGCHK(g && dst && offset + n <= g->arena_n, "read outside the arena");
+    ARGCHK(g && dst && n <= g->arena_n && offset <= g->arena_n - n, "read outside the arena");
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(hipMemcpyAsync(dst, g->arena + offset, n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
     return pyvb_graph_sync(g);

@@ -43,3 +43,12 @@ def test_library_has_no_unresolved_symbols_of_its_own():
     out = subprocess.run(["nm", "-D", "--undefined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
     bad = [l for l in out.splitlines() if "pyvb" in l or "launch_" in l]
     assert not bad, bad
+
+
+def test_shipped_library_is_the_build_of_the_sources_beside_it():
+    """The .so is not in git (it travels with the push): its embedded source hash must equal the hash of pyvb_amd/csrc as
+    it stands, so a stale library cannot pass for the sources."""
+    from pyvb_amd import _capi
+    want = _capi.source_id()
+    assert want is not None and len(want) == 32
+    assert _capi.lib.pyvb_build_id().decode() == want, "rebuild: make -C pyvb_amd/csrc"
