@@ -210,6 +210,11 @@ int pyvb_pca_set_unpinned_rows(pyvb_pca* h, const double* X_full, const double* 
 int pyvb_pca_set_initial_variances(pyvb_pca* h, const double* W_var, const double* Mu_var);
 int pyvb_pca_get_state(pyvb_pca* h, double* X, double* X_rowvar, double* W_mean, double* W_var, double* Z, double* Z_cov,
                        double* Mu_mean, double* Mu_var, double* beta_ab);
+/* q_ln_det of the nodes (gaussian.py:120, the quantity of quirk Q1 that log_lower_bound reads, gaussian.py:147), as their
+ * updates on THIS handle left it; NaN for a node that has not been updated on it (the reference, too, sets it only in
+ * update()).  qld_W [q]; qld_Z, qld_Mu one double each (all Z_n share one); qld_X [N]: rows without any observed entry,
+ * NaN for the others.  Any pointer may be NULL. */
+int pyvb_pca_get_qld(pyvb_pca* h, double* qld_W, double* qld_Z, double* qld_Mu, double* qld_X);
 /* [w.update() for w in Ws]; [z.update() for z in Zs]; Xs[lo:hi] updates; Mu.update(); Beta.update() */
 int pyvb_pca_update_W(pyvb_pca* h);
 int pyvb_pca_update_Z(pyvb_pca* h);

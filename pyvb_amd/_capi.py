@@ -88,6 +88,7 @@ SIGNATURES = {
     "pyvb_pca_set_unpinned_rows": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_pca_set_initial_variances": (ctypes.c_int, [_h, _dp, _dp]),
     "pyvb_pca_get_state": (ctypes.c_int, [_h] + [_dp] * 9),
+    "pyvb_pca_get_qld": (ctypes.c_int, [_h, _dp, _dp, _dp, _dp]),
     "pyvb_pca_update_W": (ctypes.c_int, [_h]),
     "pyvb_pca_update_Z": (ctypes.c_int, [_h]),
     "pyvb_pca_update_X": (ctypes.c_int, [_h, ctypes.c_long, ctypes.c_long]),

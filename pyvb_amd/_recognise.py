@@ -648,18 +648,19 @@ class PCAPlan(object):
             for name in ("qmu", "qcov"):
                 nd.__dict__["_h_" + name] = self.read(nd, name)
         self.Beta.__dict__["_h_qb"] = self.read(self.Beta, "qb")
-        # q_ln_det (gaussian.py:120, quirk Q1) follows from the covariances the device holds: 0.5 / sum log diag chol(qprec)
-        qld = lambda cov: 0.5 / np.sum(np.log(np.diag(np.linalg.cholesky(np.linalg.inv(cov)))))
-        with np.errstate(all="ignore"):
-            for nd in self.Ws + [self.Mu]:
-                nd.__dict__["_h_q_ln_det"] = float(qld(nd.__dict__["_h_qcov"]))
-            if self.z_updated:
-                qz = float(qld(st["Z_cov"]))
-                for z in self.Zs:
-                    z.__dict__["_h_q_ln_det"] = qz
-            for n, x in enumerate(self.Xs):
-                if not self.obs[n].any():           # a row without any observation is a latent node: qprec = <beta> I, with the
-                    x.__dict__["_h_q_ln_det"] = 0.5 / (0.5 * self.d * np.log(1.0 / st["X_rowvar"][n]))    # <beta> of its last update
+        # q_ln_det (gaussian.py:120, quirk Q1): what the updates on this handle left on the device (pyvb_pca_get_qld).  A node
+        # that has not been updated on it keeps the value it came with -- the reference sets q_ln_det only in update() too
+        qld = self.batch.get_qld()
+        for i, nd in enumerate(self.Ws):
+            if np.isfinite(qld["W"][i]):
+                nd.__dict__["_h_q_ln_det"] = float(qld["W"][i])
+        if np.isfinite(qld["Mu"]):
+            self.Mu.__dict__["_h_q_ln_det"] = qld["Mu"]
+        if self.z_updated and np.isfinite(qld["Z"]):
+            for z in self.Zs:
+                z.__dict__["_h_q_ln_det"] = qld["Z"]
+        for n in np.nonzero(np.isfinite(qld["X"]))[0]:
+            self.Xs[n].__dict__["_h_q_ln_det"] = float(qld["X"][n])
 
     def release(self):
         """See LDSPlan.release."""

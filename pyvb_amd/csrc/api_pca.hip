@@ -107,6 +107,8 @@ int pyvb_pca_set_priors(pyvb_pca* h, const double* W_pm, const double* W_pp, con
     sc[PS_BETA_A] = beta_a0 + 0.5 * (double)h->d * (double)h->N_total;      // Gamma.update_a, nodes_todo.py:125-128
     sc[PS_QLD_Z] = sc[PS_QLD_X] = sc[PS_QLD_MU] = NAN;
     HIPCHK(hipMemcpy(h->scal, sc, sizeof(sc), hipMemcpyHostToDevice));
+    std::vector<double> nanq((size_t)h->q, (double)NAN);        // no column has been updated on this handle yet
+    HIPCHK(hipMemcpy(h->qld_W, nanq.data(), nanq.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipStreamSynchronize(h->stream));
     return PYVB_OK;
 }
@@ -255,6 +257,29 @@ int pyvb_pca_get_state(pyvb_pca* h, double* X, double* X_rowvar, double* W_mean,
     if ((rc = down(h, Mu_var, h->Mu_var, d))) return rc;
     if ((rc = down(h, beta_ab, h->scal + PS_BETA_A, 2))) return rc;
     return pyvb_pca_sync(h);
+}
+
+int pyvb_pca_get_qld(pyvb_pca* h, double* qld_W, double* qld_Z, double* qld_Mu, double* qld_X) {
+    ENTER(h);
+    int rc;
+    double sc[PS_COUNT];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = down(h, qld_W, h->qld_W, (size_t)h->q))) return rc;
+    HIPCHK(hipMemcpyAsync(sc, h->scal, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+    double* tmp = nullptr;
+    if (qld_X) {
+        HIPCHK(hipMalloc((void**)&tmp, (size_t)h->N * sizeof(double)));
+        if ((rc = pca_launch_rowqld(h, tmp)) || (rc = down(h, qld_X, tmp, (size_t)h->N))) {
+            (void)hipStreamSynchronize(h->stream); (void)hipFree(tmp);
+            return rc;
+        }
+    }
+    const hipError_t se = hipStreamSynchronize(h->stream);
+    if (tmp) (void)hipFree(tmp);
+    HIPCHK(se);
+    if (qld_Z) *qld_Z = sc[PS_QLD_Z];
+    if (qld_Mu) *qld_Mu = sc[PS_QLD_MU];
+    return PYVB_OK;
 }
 
 // ---- dependency tracking: "full" = every sum current, "lin" = at least sum x and sum z ----

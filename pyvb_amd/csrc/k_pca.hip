@@ -572,6 +572,14 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
     }
 }
 
+// q_ln_det (gaussian.py:120, quirk Q1) of every X_n that has no observed entry -- a latent node with qprec = I / var_n --
+// and NaN for the rows that have one (observed and partially observed nodes never set it)
+__global__ void __launch_bounds__(256) k_pca_rowqld(PcaArgs a, double* out) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.N) return;
+    out[row] = (a.nmiss[row] == a.d) ? 0.5 / (0.5 * a.d * log(1.0 / a.xvar[row])) : __builtin_nan("");
+}
+
 // ---------------------------------------------------------------------------------------------------
 static PcaArgs pca_args(pyvb_pca* h) {
     PcaArgs a;
@@ -611,6 +619,13 @@ int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
     if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass2<1, true>), grid, block, 0, h->stream, a); else hipLaunchKernelGGL((k_pca_pass2<1, false>), grid, block, 0, h->stream, a); }
     else { if (pin) hipLaunchKernelGGL((k_pca_pass2<2, true>), grid, block, 0, h->stream, a); else hipLaunchKernelGGL((k_pca_pass2<2, false>), grid, block, 0, h->stream, a); }
     hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+int pca_launch_rowqld(pyvb_pca* h, double* out) {
+    PcaArgs a = pca_args(h);
+    hipLaunchKernelGGL(k_pca_rowqld, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, a, out);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

@@ -35,7 +35,7 @@ struct TapeArgs { double* arena; size_t arena_n; const int* ops; int nops; int* 
 __device__ static double tape_digamma(double x) {
     // the recurrence below takes 10 - x steps: bounded here, so that no argument (a degenerate qv, -inf, a NaN from bad
     // state) can keep a workgroup spinning.  Not finite: NaN (+inf: +inf); below -64: the reflection formula.
-    if (!(x - x == 0.0)) return x > 0 ? x : __builtin_nan("");
+    if (!(x - x == 0.0) || x < -4.5e15) return x > 0 ? x : __builtin_nan("");      // below -2^52 every double is an integer: a pole
     double r = 0.0;
     if (x < -64.0) { r = -M_PI / tan(M_PI * x); x = 1.0 - x; }
     while (x < 10.0) { r -= 1.0 / x; x += 1.0; }

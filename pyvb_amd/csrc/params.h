@@ -49,7 +49,7 @@ __device__ __forceinline__ double bcast(double v, int j) {
 
 // digamma for positive and for negative non-integer arguments (recurrence up to x >= 10, then the asymptotic series)
 __device__ static inline double digamma_pos(double x) {
-    if (!(x - x == 0.0)) return x > 0 ? x : __builtin_nan("");      // bounded recurrence: see tape_digamma (k_tape.hip)
+    if (!(x - x == 0.0) || x < -4.5e15) return x > 0 ? x : __builtin_nan("");      // below -2^52 every double is an integer: a pole      // bounded recurrence: see tape_digamma (k_tape.hip)
     double r = 0.0;
     if (x < -64.0) { r = -M_PI / tan(M_PI * x); x = 1.0 - x; }
     while (x < 10.0) { r -= 1.0 / x; x += 1.0; }

@@ -57,4 +57,5 @@ int pca_launch_small(pyvb_pca* h, int mode);
 int pca_launch_pass1(pyvb_pca* h);
 int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd);
 int pca_launch_reduce(pyvb_pca* h, int what);
+int pca_launch_rowqld(pyvb_pca* h, double* out);      // out: device [N]
 enum { PCA_W = 0, PCA_PREPZ = 1, PCA_MU = 2, PCA_BETA = 3, PCA_ELBO = 4, PCA_X0 = 5, PCA_APPLY = 6 };

@@ -28,64 +28,51 @@ class Network(object):
     def find_iterable(self):            # network.py:35-37
         self.iterable_nodes = [e for e in self.nodes if isinstance(e, (N.Gaussian, N.Gamma, N.DiagonalGamma, N.Wishart))]
 
+    def _groups(self):
+        """The iterable nodes grouped by the device plan their graph is bound to, plans in order of first appearance, nodes
+        in list order inside a group.  Unconnected graphs do not exchange messages, so running the groups one after the
+        other gives what the reference's single pass over the list gives (network.py:46-49)."""
+        plans, groups = [], {}
+        for n in self.iterable_nodes:
+            p = N._plan_of(n)
+            if id(p) not in groups:
+                plans.append(p)
+                groups[id(p)] = []
+            groups[id(p)].append(n)
+        return [(p, groups[id(p)]) for p in plans]
+
     def learn(self, niters, tol=1e-3, verbose=True):
+        """network.py:40-56.  The node list may span any number of unconnected graphs, each on its own plan: a fused LDS
+        or VB-PCA plan takes its group's update() calls as queued requests (whole sweeps become single launches) and gives
+        the lower bound as the sum of its class parts; a graph that runs node by node gets one launch for all its updates
+        and one for the sum of its log_lower_bound() terms.  The grouping is redone around every step because an update
+        order the fused kernels do not serve moves a graph to the node-by-node plan (and sweeps bring it back)."""
         self.find_iterable()
         if verbose:
             print('Found' + str(len(self.iterable_nodes)) + ' iterable nodes\n')
         if not self.iterable_nodes:
             return
-        plan = N._plan_of(self.iterable_nodes[0])
-        if getattr(plan, "generic", False):
-            return self._learn_generic(niters, tol, verbose)
-        missing = [n for n in self.iterable_nodes if n._plan is not plan]
-        if missing:
-            raise NotImplementedError("the network spans nodes outside one recognised LDS graph; no HIP plan")
-        needed = plan.n_random_nodes
-        if len(set(id(n) for n in self.iterable_nodes)) != needed:
-            raise NotImplementedError("Network.learn needs every random-variable node of the graph (the lower bound is a "
-                                      "sum over all of them): call fetch_network() first")
         old_llb = -np.inf
         for i in range(niters):
-            for n in self.iterable_nodes:
-                n.update()
-            plan.flush()
-            if self.iterable_nodes[0]._plan is not plan:        # an update order the fused kernels do not serve: the graph
-                self.llb = float(sum(n.log_lower_bound() for n in self.iterable_nodes))     # runs node by node from here on
-                if verbose:
-                    print(niters - i, self.llb)
-                if self.llb - old_llb < tol:
-                    if verbose:
-                        print("Convergence!")
-                    return
-                return self._learn_generic(niters - i - 1, tol, verbose, old_llb=self.llb)
-            self.llb = float(np.sum(plan.elbo_parts()))        # network.py:49
+            for p, group in self._groups():
+                if getattr(p, "generic", False):
+                    p.update_all(group)
+                else:
+                    for n in group:
+                        n.update()
+                    p.flush()
+            llb = 0.0
+            for p, group in self._groups():
+                if getattr(p, "generic", False):
+                    llb += float(p.llb_sum(group).sum())
+                elif len(set(id(n) for n in group)) == p.n_random_nodes:
+                    llb += float(np.sum(p.elbo_parts()))        # every random node of the graph is listed: the class sums
+                else:
+                    llb += float(sum(n.log_lower_bound() for n in group))     # a part of a fused graph: its terms one by one
+            self.llb = llb                                      # network.py:49
             if verbose:
                 print(niters - i, self.llb)
             if self.llb - old_llb < tol:                        # also fires when the bound decreases (SURVEY.md Q9)
-                if verbose:
-                    print("Convergence!")
-                break
-            old_llb = self.llb
-
-    def _learn_generic(self, niters, tol, verbose, old_llb=-np.inf):
-        """network.py:40-56 for a graph that runs node by node: per iteration one launch for all update() calls in
-        list order and one for the sum of the log_lower_bound() terms; nodes of several unconnected graphs are grouped
-        by plan."""
-        plans = []
-        for n in self.iterable_nodes:
-            p = N._plan_of(n)
-            if not getattr(p, "generic", False):
-                raise NotImplementedError("a Network that mixes a fused (LDS / PCA) graph with other graphs")
-            if p not in plans:
-                plans.append(p)
-        groups = [(p, [n for n in self.iterable_nodes if n._plan is p]) for p in plans]
-        for i in range(niters):
-            for p, group in groups:
-                p.update_all(group)
-            self.llb = float(sum(p.llb_sum(group).sum() for p, group in groups))        # network.py:49
-            if verbose:
-                print(niters - i, self.llb)
-            if self.llb - old_llb < tol:                        # SURVEY.md Q9
                 if verbose:
                     print("Convergence!")
                 break

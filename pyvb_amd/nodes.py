@@ -14,9 +14,12 @@ moves to the GPU (pyvb_amd.lds.LDSBatch, one replicate) and from then on
     launch each (Linear_Dynamic_System.py:69-77); anything else falls back to per-node launches;
   * `qmu`, `qcov`, `qa`, `qb` ... read back from the device.
 
-Graphs the recogniser does not know have no HIP path and raise NotImplementedError: there is
-no CPU execution of updates in this package.  The `pass_down_*` accessors, which the reference's
-examples use for plotting, combine posteriors already fetched from the device on the host.
+Every other graph runs the reference's own schedule, one node at a time, on the device as well: its
+methods are restated as emitters of a small tape language (pyvb_amd/generic.py) that a HIP interpreter
+executes (pyvb_amd/csrc/k_tape.hip).  There is no CPU execution of updates, messages or expectations in
+this package: the `pass_down_*` accessors of the operation nodes (Addition, Multiplication, hstack),
+which the reference's examples use for plotting, are evaluated by the same emitters -- on the graph's
+own plan if it runs node by node, on a mirror of the fused plan's state otherwise.
 """
 import numpy as np
 
@@ -90,12 +93,11 @@ class Addition(Node):
         self.A.addChild(self)
         self.B.addChild(self)
 
-    def pass_down_Ex(self):
-        return self.A.pass_down_Ex() + self.B.pass_down_Ex()
+    def pass_down_Ex(self):                     # node.py:112-119
+        return _expectation_of(self, "Ex")
 
-    def pass_down_ExxT(self):
-        outer = np.dot(self.A.pass_down_Ex(), self.B.pass_down_Ex().T)
-        return self.A.pass_down_ExxT() + self.B.pass_down_ExxT() + outer + outer.T
+    def pass_down_ExxT(self):                   # node.py:121-129
+        return _expectation_of(self, "ExxT")
 
 
 class Multiplication(Node):
@@ -112,20 +114,15 @@ class Multiplication(Node):
         self.B.addChild(self)
 
     def pass_down_Ex(self):                     # node.py:235-242
-        return np.dot(self.A.pass_down_Ex(), self.B.pass_down_Ex())
+        return _expectation_of(self, "Ex")
 
-    def pass_down_ExxT(self):                   # node.py:244-276, hstack and Constant branches
-        BBT = self.B.pass_down_ExxT()
-        if isinstance(self.A, Constant):
-            Am = self.A.pass_down_Ex()
-            return np.dot(Am, np.dot(BBT, Am.T))
-        if hasattr(self.A, "parents"):
-            Am = self.A.pass_down_Ex()
-            ret = np.dot(Am, np.dot(BBT, Am.T))
-            for i, p in enumerate(self.A.parents):
-                ret += p.qcov * float(BBT[i, i])
-            return ret
-        raise NotImplementedError("pass_down_ExxT for this left operand")
+    def pass_down_ExxT(self):
+        """node.py:244-276, all five branches -- column x scalar, row vector, Constant matrix (with the transpose the
+        reference's line lacks), hstack, DiagonalGaussian -- through the emitter GenericPlan._exxt."""
+        r = _expectation_of(self, "ExxT")
+        if self.A.shape[0] == 1 and self.A.shape[1] != 1:
+            return float(r.reshape(-1)[0])      # the row-vector branch is a trace: the reference returns a scalar
+        return r
 
 
 class Constant(Node):
@@ -164,11 +161,11 @@ class hstack(Node):
         self.parents = parents
         [e.addChild(self) for e in self.parents]
 
-    def pass_down_Ex(self):
-        return np.hstack([e.pass_down_Ex() for e in self.parents])
+    def pass_down_Ex(self):                     # nodes_todo.py:33-34
+        return _expectation_of(self, "Ex")
 
-    def pass_down_ExxT(self):
-        return np.sum([p.pass_down_ExxT() for p in self.parents], 0)
+    def pass_down_ExxT(self):                   # nodes_todo.py:36-38
+        return _expectation_of(self, "ExxT")
 
     def pass_down_ExTx(self):
         raise NotImplementedError
@@ -203,6 +200,11 @@ def _generic_view(node):
 
 def _messages_of(node, requester):
     return _generic_view(node).message(node, requester)
+
+
+def _expectation_of(node, what):
+    """node.pass_down_<what>() of an operation node, evaluated on the device (GenericPlan.expectation)."""
+    return _generic_view(node).expectation(node, what)
 
 
 class _DeviceAttr(object):

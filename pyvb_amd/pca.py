@@ -87,6 +87,14 @@ class PCABatch(object):
         out["beta_a"], out["beta_b"] = out["beta_ab"]
         return out
 
+    def get_qld(self, rows=True):
+        """q_ln_det values as the updates on this handle left them (NaN: not updated here yet): W columns [q], the Z_n's
+        shared one, Mu's, and per row for the X_n without any observed entry (NaN for the others)."""
+        w, z, m = np.empty(self.q), np.empty(1), np.empty(1)
+        x = np.empty(self.N) if rows else None
+        C.check(C.lib.pyvb_pca_get_qld(self._h, C.dptr(w), C.dptr(z), C.dptr(m), C.dptr(x)))
+        return {"W": w, "Z": float(z[0]), "Mu": float(m[0]), "X": x}
+
     def update_W(self):
         C.check(C.lib.pyvb_pca_update_W(self._h))
 

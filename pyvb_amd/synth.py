@@ -82,3 +82,29 @@ def make_problem(T, D, K, N=1, seed=20240):
     sim = simulate_lds(T, D, K, N, seed)
     st = initial_state(T, D, K, N, seed + 7919)
     return sim["Y"], st, default_priors(D, K)
+
+
+def pca_rows(lo, hi, d, q, seed, block=10000):
+    """Rows [lo, hi) of the synthetic VB-PCA problem (BASELINE configs[4]: low-rank rows + noise, Bernoulli(0.1) missing
+    entries), generated block by block from (seed, block index) so that any row range of any total size is reproducible --
+    ranks generate only their own shard.  Returns X, the observation mask, initial latent means, the initial W mean."""
+    g = np.random.default_rng(seed)
+    W = g.standard_normal((d, q)); mean = g.standard_normal(d); W0 = g.standard_normal((d, q))
+    X, obs, Z0 = [], [], []
+    for b0 in range(lo // block * block, hi, block):
+        r = np.random.default_rng([seed, b0 // block])
+        x = r.standard_normal((block, q)) @ W.T + mean + 0.2 * r.standard_normal((block, d))
+        o = r.random((block, d)) > 0.1
+        z0 = r.standard_normal((block, q))
+        a, e = max(lo, b0) - b0, min(hi, b0 + block) - b0
+        X.append(x[a:e]); obs.append(o[a:e]); Z0.append(z0[a:e])
+    return np.concatenate(X), np.concatenate(obs), np.concatenate(Z0), W0
+
+
+def pca_problem(N, d, q, seed):
+    """(init, pri) for pyvb_amd.pca.PCABatch.from_problem / oracle.pca_closed_form.make_state."""
+    X, obs, Z0, W0 = pca_rows(0, N, d, q, seed)
+    init = {"obs": obs, "X": np.where(obs, X, 0.0), "W_mean": W0, "Z": Z0, "Z_cov": np.eye(q), "Mu_mean": np.zeros(d), "beta_b": 1.0}
+    pri = {"W_prior_mean": np.zeros((d, q)), "W_prior_prec": np.full((q, d), 1e-3), "Mu_prior_mean": np.zeros(d),
+           "Mu_prior_prec": np.full(d, 1e-3), "beta_a0": 1e-3, "beta_b0": 1e-3}
+    return init, pri

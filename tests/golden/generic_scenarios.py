@@ -403,6 +403,54 @@ def random_graph(nodes, rng):
     return order, named
 
 
+def multiplication_expectations(nodes, rng):
+    """Every branch of Multiplication.pass_down_Ex / pass_down_ExxT (node.py:235-276) the reference can execute: column x scalar
+    (:251-252), row vector x vector (:253-254, a Constant row: its pass_down_ExTx is the only one defined for a row), hstack
+    matrix x vector (:260-271), DiagonalGaussian x vector (:273-276); and Addition.pass_down_ExxT (:121-129) on top of one.
+    (The Constant-matrix branch :257-258 calls a method that does not exist)  Returns the usual
+    (update order, random nodes) plus the operation nodes whose expectations are recorded."""
+    d, q = 3, 2
+    w = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 0.1)
+    z = nodes.Gaussian(1, np.zeros((1, 1)), np.eye(1))
+    col_scalar = nodes.Multiplication(w, z)
+    off = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d))
+    y1 = nodes.Gaussian(d, col_scalar + off, np.eye(d) * 5.0)
+    y1.observe(rng.standard_normal((d, 1)))
+    row = nodes.Constant(rng.standard_normal((1, d)))
+    b = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 0.5)
+    row_vec = nodes.Multiplication(row, b)
+    y2 = nodes.Gaussian(1, row_vec, np.eye(1) * 3.0)
+    y2.observe(rng.standard_normal((1, 1)))
+    cols = [nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 0.3) for _ in range(q)]
+    H = nodes.hstack(cols)
+    v = nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q))
+    mat_vec = nodes.Multiplication(H, v)
+    y3 = nodes.Gaussian(d, mat_vec, np.eye(d) * 2.0)
+    y3.observe(rng.standard_normal((d, 1)))
+    S = nodes.DiagonalGaussian(d, np.ones((d, 1)), np.eye(d) * 4.0)
+    u = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d))
+    diag_vec = nodes.Multiplication(S, u)
+    y4 = nodes.Gaussian(d, diag_vec, np.eye(d) * 7.0)
+    y4.observe(rng.standard_normal((d, 1)))
+    named = {"w": w, "z": z, "off": off, "b": b, "v": v, "S": S, "u": u, "y1": y1, "y2": y2, "y3": y3, "y4": y4}
+    named.update({"c%d" % i: c for i, c in enumerate(cols)})
+    _init_all(named, rng)
+    ops = {"col_scalar": col_scalar, "sum": y1.mean_parent, "row_vec": row_vec, "mat_vec": mat_vec, "diag_vec": diag_vec}
+    return [w, z, off, v, u] + cols, named, ops
+
+
+def expectations(ops):
+    """pass_down_Ex() / pass_down_ExxT() of the operation nodes, as flat arrays."""
+    out = {}
+    for k in sorted(ops):
+        out["op.%s.Ex" % k] = np.array(ops[k].pass_down_Ex(), dtype=float)
+        out["op.%s.ExxT" % k] = np.atleast_2d(np.array(ops[k].pass_down_ExxT(), dtype=float))
+    return out
+
+
+EXPECTATION_SEED, EXPECTATION_ITERS = 115, (0, 1, 2)
+
+
 # name -> (builder, seed, iterations after which the state is recorded, messages to record as (node label, requester label))
 SCENARIOS = {
     "simple_mean_inference": (simple_mean_inference, 101, (1, 2), [("y03", "mu")]),

@@ -425,6 +425,26 @@ def run_generic_case(ref, name):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def run_expectation_case(ref):
+    """pass_down_Ex / pass_down_ExxT of Multiplication (every executable branch of node.py:235-276) and Addition nodes, before
+    any update and after one and two rounds of updates (tests/golden/generic_scenarios.py: multiplication_expectations)."""
+    import generic_scenarios as GS
+    order, named, ops = GS.multiplication_expectations(ref.nodes, np.random.default_rng(GS.EXPECTATION_SEED))
+    out = {}
+    for it in range(max(GS.EXPECTATION_ITERS) + 1):
+        if it:
+            for n in order:
+                n.update()
+        if it in GS.EXPECTATION_ITERS:
+            for k, v in GS.expectations(ops).items():
+                out["it%d.%s" % (it, k)] = v
+            for k, v in GS.snapshot(named).items():
+                out["it%d.%s" % (it, k)] = v
+    path = os.path.join(HERE, "expect_multiplication.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 PCA_CASES = [("example_n200_d5_q2", 200, 5, 2, (1, 2, 5), 30100),
              ("n60_d12_q3", 60, 12, 3, (1, 3), 30101),
              ("n40_d70_q17", 40, 70, 17, (1, 2), 30102),
@@ -493,6 +513,8 @@ if __name__ == "__main__":
     for name in generic_scenarios.SCENARIOS:
         if not sel or sel == ["small"] or "generic" in sel or name in sel:
             run_generic_case(ref, name)
+    if not sel or sel == ["small"] or "generic" in sel or "expect" in sel:
+        run_expectation_case(ref)
     for c in CASES:
         if sel and sel != ["small"] and c[0] not in sel:
             continue

@@ -66,6 +66,33 @@ def check_scenario(name, rtol=RTOL, llb_rtol=1e-8):
     return named
 
 
+def check_expectations(rtol=RTOL):
+    """Shared with the GPU test: pass_down_Ex / pass_down_ExxT of the operation nodes of GS.multiplication_expectations
+    against tests/golden/expect_multiplication.npz (generated from the reference's classes)."""
+    from pyvb_amd import nodes
+    z = dict(np.load(os.path.join(HERE, "golden", "expect_multiplication.npz"), allow_pickle=False))
+    order, named, ops = GS.multiplication_expectations(nodes, np.random.default_rng(GS.EXPECTATION_SEED))
+    seen = 0
+    for it in range(max(GS.EXPECTATION_ITERS) + 1):
+        if it:
+            for n in order:
+                n.update()
+        if it not in GS.EXPECTATION_ITERS:
+            continue
+        for k, v in GS.expectations(ops).items():
+            _close(v, z["it%d.%s" % (it, k)], "iteration %d %s" % (it, k), rtol)
+            seen += 1
+        for k, v in GS.snapshot(named).items():
+            if np.abs(z["it%d.%s" % (it, k)]).max() > 0:
+                _close(v, z["it%d.%s" % (it, k)], "iteration %d %s" % (it, k), rtol)
+    assert seen == 3 * 2 * len(ops)
+    assert isinstance(ops["row_vec"].pass_down_ExxT(), float)           # np.trace in the reference: a scalar, not a 1 x 1 array
+
+
+def test_multiplication_expectations_against_the_reference(numpy_executor):
+    check_expectations()
+
+
 @pytest.mark.parametrize("name", sorted(n for n in GS.SCENARIOS if n not in GS.NEEDS_DEVICE))
 def test_generic_scenarios_against_reference(name, numpy_executor):
     check_scenario(name)

@@ -98,6 +98,42 @@ def test_every_opcode_against_the_numpy_interpreter():
     _close(got[inv.off:inv.off + 81].reshape(9, 9), np.linalg.inv(S), "inverse", 1e-11)
 
 
+def test_digamma_of_degenerate_arguments_terminates():
+    """U_DIGAMMA walks x up to 10 by the recurrence: -inf, NaN or a huge negative argument (a degenerate qv in the Wishart
+    bound, bad state) must end in NaN, not in a workgroup that never finishes; large negative non-integers go through the
+    reflection formula and agree with scipy."""
+    from scipy.special import digamma
+    from pyvb_amd import generic as G
+    x = np.array([-np.inf, -1e300, np.nan, np.inf, -1e16, -70.5, -1000.25, -63.5, 0.3, 12.0])
+    ex = G.DeviceExecutor(64)
+    ex.write(0, x)
+    ex.run(ex.tape([[G.T_UNARY, 16, 0, 0, len(x), 1, 0, G.U_DIGAMMA]]))
+    got = ex.read(16, len(x))
+    ex.close()
+    assert np.all(np.isnan(got[[0, 1, 2, 4]])) and got[3] == np.inf
+    np.testing.assert_allclose(got[5:], digamma(x[5:]), rtol=1e-11)
+
+
+def test_arena_ranges_do_not_wrap():
+    """pyvb_graph_write / _read with an offset near SIZE_MAX: offset + n wraps around in size_t; the call must be refused."""
+    import ctypes
+    from pyvb_amd import _capi, generic
+    ex = generic.DeviceExecutor(64)
+    buf = np.zeros(4)
+    huge = ctypes.c_size_t(-2).value                 # SIZE_MAX - 1
+    for fn in (_capi.lib.pyvb_graph_write, _capi.lib.pyvb_graph_read):
+        assert fn(ex._h if hasattr(ex, "_h") else ex.h, huge, _capi.dptr(buf), 4) == _capi.E_ARG
+    ex.close()
+
+
+def test_multiplication_expectations_against_the_reference(monkeypatch):
+    """Every executable branch of Multiplication.pass_down_Ex / pass_down_ExxT (node.py:235-276: column x scalar, row vector,
+    hstack, DiagonalGaussian) and Addition.pass_down_ExxT, as user-callable accessors, against values the reference's classes
+    produced (tests/golden/expect_multiplication.npz) -- before any update and after one and two rounds."""
+    from test_generic_cpu import check_expectations
+    check_expectations()
+
+
 def test_malformed_tapes_are_refused_and_bad_indices_skipped():
     """pyvb_graph_tape_create checks every extent a record touches against the arena; gather indices are data and are
     checked by the kernel (error reported at the next sync, nothing read or written outside)."""
@@ -173,8 +209,42 @@ def test_single_messages_and_terms_of_the_fused_lds_plan(golden):
     _close(m2, Rbar @ Ys[1].qmu, "m2 of an observed output", 1e-9)
     T = len(Xs)
     if T > 2:
-        m1, m2 = Xs[1].children[0].pass_up_m1_m2(Xs[1])         # Mult(., X_1), hstack branch node.py:213-227
-        assert m1.shape == (meta["D"], meta["D"]) and np.all(np.isfinite(m1)) and np.all(np.isfinite(m2))
+        # Mult(., X_1) asked by X_1: the hstack branch with the D^4 tensor, node.py:213-227.  The fused plan answers from a
+        # mirror of its state; the same graph forced node by node (its posteriors assigned from the fused run) must agree,
+        # and so must the closed form <A^T L A> = Abar^T L Abar + diag_i tr(S_i L) that k_prep uses
+        mults = [m for m in Xs[1].children]
+        fused = [m.pass_up_m1_m2(Xs[1]) for m in mults]
+        from pyvb_amd import generic, _recognise
+        state = {"X": [x.qmu.copy() for x in Xs], "Xc": [x.qcov.copy() for x in Xs],
+                 "A": [(a.qmu.copy(), a.qcov.copy()) for a in As], "C": [(c.qmu.copy(), c.qcov.copy()) for c in Cs],
+                 "Q": (Q.qw.copy() if meta["noise"] == "wishart" else np.copy(Q.qb)), "R": (R.qw.copy() if meta["noise"] == "wishart" else np.copy(R.qb)),
+                 "Y": [(y.qmu.copy(), y.qcov.copy()) for y in Ys]}
+        import pytest as _pt
+        mp = _pt.MonkeyPatch()
+        try:
+            mp.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+            g2 = MG.build_graph(nodes, Y[0], pri, {k: v for k, v in st0.items()})
+            for x, m, c in zip(g2["Xs"], state["X"], state["Xc"]):
+                x.qmu, x.qcov = m, c
+            for cols, key in ((g2["As"], "A"), (g2["Cs"], "C")):
+                for n, (m, c) in zip(cols, state[key]):
+                    n.qmu, n.qcov = m, c
+            for y, (m, c) in zip(g2["Ys"], state["Y"]):
+                if not y.observed:
+                    y.qmu, y.qcov = m, c
+            g2["Q"].qb, g2["R"].qb = state["Q"], state["R"]
+            slow = [m.pass_up_m1_m2(g2["Xs"][1]) for m in g2["Xs"][1].children]
+            assert isinstance(g2["Xs"][1]._plan, generic.GenericPlan)
+        finally:
+            mp.undo()
+        for (f1, f2), (s1, s2) in zip(fused, slow):
+            _close(f1, s1, "hstack-branch m1: fused mirror vs node by node", 1e-10)
+            _close(f2, s2, "hstack-branch m2: fused mirror vs node by node", 1e-10)
+        Qbar = Q.pass_down_Ex()
+        Abar = np.hstack([a.qmu for a in As])
+        closed = Abar.T @ Qbar @ Abar + np.diag([np.trace(a.qcov @ Qbar) for a in As])
+        which = [i for i, m in enumerate(mults) if m.A is g["A"]][0]
+        _close(fused[which][0], closed, "hstack-branch m1 vs Abar^T Q Abar + diag tr(S_i Q)", 1e-10)
 
 
 def test_fused_plan_follows_a_late_observation(monkeypatch):

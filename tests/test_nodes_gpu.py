@@ -453,3 +453,93 @@ def test_the_pca_example_exactly_as_the_reference_writes_it():
         assert _rel(g["Mu"].qmu.reshape(-1), z[tag + "Mu"]) <= RTOL
         assert abs(g["Beta"].qb - float(z[tag + "beta_b"])) <= RTOL * abs(float(z[tag + "beta_b"]))
         assert abs(net.llb - float(z[tag + "llb"])) <= 1e-7 * abs(float(z[tag + "llb"]))
+
+
+def test_network_learn_over_several_unconnected_graphs():
+    """Network.learn (network.py:40-56) iterates any node list.  One list holding an LDS graph (fused kernels), a VB-PCA
+    graph (fused kernels) and a small graph without a fused plan (node by node): every posterior and the summed bound equal
+    what three separate networks give, and the plans stay what the recogniser chose."""
+    import glob
+    import pyvb_amd
+    from pyvb_amd import nodes, synth, _recognise, generic
+    from pyvb_amd.network import Network
+    from test_pca_oracle_golden import load_pca
+    G = _golden_module()
+    T, D, K = 40, 3, 4
+    Y, st0, pri = synth.make_problem(T, D, K, 1, 91)
+    path = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "pca_*.npz")) if "default_init" not in p)[0]
+    _, _, _, init, ppri, _ = load_pca(path)
+
+    def small(rng):
+        y = rng.standard_normal(12) * 0.3 + 2.0
+        mu = nodes.Gaussian(1, np.array([[0.0]]), np.array([[1e-3]]))
+        lam = nodes.Gamma(1, 1e-3, 1e-3)
+        ys = [nodes.Gaussian(1, mu, lam) for _ in y]
+        for n, v in zip(ys, y):
+            n.observe(np.array([[v]]))
+        mu.qmu, mu.qcov, lam.qb = np.array([[0.5]]), np.array([[2.0]]), 0.7
+        return [mu, lam] + ys
+
+    def build():
+        g = G.build_graph(nodes, Y[0], pri, st0)
+        lds = Network([g["A"]]); lds.fetch_network(verbose=False)
+        pca = G.pca_build_graph(pyvb_amd, init, ppri)
+        sm = small(np.random.default_rng(5))
+        return g, lds.nodes, pca, pca["net"].nodes, sm
+
+    iters = 3
+    g, lds_nodes, pca, pca_nodes, sm = build()
+    parts = []
+    for lst in (lds_nodes, pca_nodes, sm):
+        net = Network(lst)
+        net.learn(iters, tol=-np.inf, verbose=False)
+        parts.append(net.llb)
+    want = (np.hstack([x.qmu for x in g["Xs"]]), np.hstack([w.qmu for w in pca["Ws"]]), float(sm[0].qmu[0, 0]), float(sm[1].qb))
+    g2, lds_nodes, pca2, pca_nodes, sm2 = build()
+    mixed = Network(sm2[:1] + lds_nodes + pca_nodes + sm2[1:])          # the small graph's nodes on both sides of the others
+    mixed.learn(iters, tol=-np.inf, verbose=False)
+    assert isinstance(g2["Xs"][0]._plan, _recognise.LDSPlan) and isinstance(pca2["Ws"][0]._plan, _recognise.PCAPlan)
+    assert isinstance(sm2[0]._plan, generic.GenericPlan)
+    assert abs(mixed.llb - sum(parts)) <= 1e-9 * abs(sum(parts))
+    assert _rel(np.hstack([x.qmu for x in g2["Xs"]]), want[0]) <= 1e-12 and _rel(np.hstack([w.qmu for w in pca2["Ws"]]), want[1]) <= 1e-12
+    assert abs(float(sm2[0].qmu[0, 0]) - want[2]) <= 1e-12 * abs(want[2]) and abs(float(sm2[1].qb) - want[3]) <= 1e-12 * want[3]
+    # a list that holds only PART of a fused graph's random nodes: the reference sums the listed nodes' terms
+    g3, lds_nodes, _, _, _ = build()
+    part = Network([n for n in lds_nodes if n is not g3["Q"]])
+    part.learn(2, tol=-np.inf, verbose=False)
+    iterable = [n for n in lds_nodes if isinstance(n, (nodes.Gaussian, nodes.DiagonalGamma)) and n is not g3["Q"]]
+    assert abs(part.llb - sum(float(n.log_lower_bound()) for n in iterable)) <= 1e-9 * abs(part.llb)
+
+
+def test_pca_q_ln_det_comes_from_the_device():
+    """pyvb_pca_get_qld: the q_ln_det of W's columns, the Z_n, Mu and the rows without observations as the device's updates
+    left them (quirk Q1 form, gaussian.py:120) -- equal to the formula evaluated on the fetched covariances, NaN before the
+    first update -- and PCAPlan._sync_host uses them instead of factorising on the host."""
+    import inspect
+    from pyvb_amd import _recognise
+    from pyvb_amd.pca import PCABatch
+    rng = np.random.default_rng(3)
+    N, d, q = 60, 7, 3
+    X = rng.standard_normal((N, q)) @ rng.standard_normal((q, d)) + 0.1 * rng.standard_normal((N, d))
+    obs = rng.random((N, d)) > 0.2
+    obs[5] = False
+    obs[17] = False
+    init = {"obs": obs, "X": np.where(obs, X, 0.0), "W_mean": rng.standard_normal((d, q)), "W_var": np.ones((q, d)),
+            "Z": rng.standard_normal((N, q)), "Z_cov": np.eye(q), "Mu_mean": np.zeros(d), "Mu_var": np.ones(d), "beta_b": 1.0}
+    pri = {"W_prior_mean": np.zeros((d, q)), "W_prior_prec": np.full((q, d), 1e-3), "Mu_prior_mean": np.zeros(d),
+           "Mu_prior_prec": np.full(d, 1e-3), "beta_a0": 1e-3, "beta_b0": 1e-3}
+    b = PCABatch.from_problem(init, pri)
+    q0 = b.get_qld()
+    assert np.all(np.isnan(q0["W"])) and np.isnan(q0["Z"]) and np.isnan(q0["Mu"])
+    b.iterate(2)
+    st, ql = b.get_state(), b.get_qld()
+    b.close()
+    qld = lambda cov: 0.5 / np.sum(np.log(np.diag(np.linalg.cholesky(np.linalg.inv(cov)))))
+    for i in range(q):
+        assert abs(ql["W"][i] - qld(np.diag(st["W_var"][i]))) <= 1e-10 * abs(ql["W"][i])
+    assert abs(ql["Z"] - qld(st["Z_cov"])) <= 1e-10 * abs(ql["Z"]) and abs(ql["Mu"] - qld(np.diag(st["Mu_var"]))) <= 1e-10 * abs(ql["Mu"])
+    none = ~obs.any(1)
+    assert np.array_equal(np.isfinite(ql["X"]), none)
+    assert np.allclose(ql["X"][none], 0.5 / (0.5 * d * np.log(1.0 / st["X_rowvar"][none])), rtol=1e-12)
+    src = inspect.getsource(_recognise.PCAPlan._sync_host)
+    assert "cholesky" not in src and "linalg" not in src
