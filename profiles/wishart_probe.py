@@ -15,7 +15,7 @@ pri["R_a0"], pri["R_b0"] = np.float64(0.5 * K + 1.0), np.eye(K) * 0.05
 b = LDSBatch.from_problem(Y, st0, pri)
 b.iterate(2); b.sync(); b.timing(True)
 t0 = time.perf_counter()
-iters = 10
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 b.iterate(iters); b.sync()
 dt = (time.perf_counter() - t0) / iters
 print("Wishart noise, N=%d T=%d D=%d K=%d: %.3f ms per iteration" % (N, T, D, K, dt * 1e3),

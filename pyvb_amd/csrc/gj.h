@@ -77,3 +77,84 @@ __device__ static void gj_inverse(double (&v)[NP][16], int D, int tid, double* r
     __syncthreads();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same elimination by ONE wavefront per matrix: lane (a = lane / 8, b = lane % 8) owns the 8 x 8 tile of elements
+// (8a + ra, 8b + cb), v[ra][cb] (64 doubles per lane, the matrix padded to 64 x 64 with the identity).  A step is then 64
+// FMAs per lane against 8 + 8 broadcast values -- four times the arithmetic per exchanged value of the 4 x 4 tiling above --
+// and involves no other wavefront: the pivot row, the pivot column and the reciprocal of the pivot go through a scratch
+// area in LDS that only this wavefront touches (LDS operations of one wavefront execute in order), so there is no
+// workgroup barrier in the loop and the wavefronts of a workgroup invert different matrices independently.
+// rc: this wavefront's scratch [2][GJW_BUF]; pivs: [64] pivots (their logs sum to ln det).  Used for the column
+// covariances under Wishart noise (k_wishart.hip), where a replicate needs 2 D inversions per iteration.
+#define GJW_BUF 136     // row (64), column (64), 1/pivot, padding
+__device__ __forceinline__ double gjw_recip(double x) {
+    // v_rcp_f64 and two Newton steps: the IEEE division is ~40 instructions that all 64 lanes would sit through for one pivot
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ void gjw_sync() {
+    // orders this wavefront's LDS writes before its later LDS reads for the COMPILER (the hardware keeps them in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ static void gj_wave(double (&v)[8][8], int D, int lane, double* rc, double* pivs) {
+    const int a = lane >> 3, b = lane & 7;
+    {
+        double* row = rc;
+        if (a == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) row[8 * b + cb] = v[0][cb];           // row 0
+        }
+        if (b == 0) {
+#pragma unroll
+            for (int ra = 0; ra < 8; ++ra) row[64 + 8 * a + ra] = v[ra][0];      // column 0
+        }
+        if (lane == 0) row[128] = gjw_recip(v[0][0]);
+    }
+    int cur = 0;
+    for (int P = 0; 8 * P < D; ++P) {
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int p = 8 * P + pp;
+            if (p >= D) continue;                               // wave-uniform (no break: the eight steps stay unrolled, pp a constant)
+            const int P1 = (pp == 7) ? P + 1 : P, q1 = (pp + 1) & 7;    // where row / column p + 1 live
+            gjw_sync();
+            const double* row = rc + cur * GJW_BUF;
+            const double* col = row + 64;
+            double* nrow = rc + (cur ^ 1) * GJW_BUF;
+            double* ncol = nrow + 64;
+            const double d = row[128];
+            if (lane == 0) pivs[p] = row[p];
+            double rj[8], ci[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { rj[k] = row[8 * b + k] * d; ci[k] = col[8 * a + k]; }
+#pragma unroll
+            for (int ra = 0; ra < 8; ++ra)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) v[ra][cb] = __builtin_fma(-ci[ra], rj[cb], v[ra][cb]);
+            if (b == P) {                                       // column p
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) v[ra][pp] = -ci[ra] * d;
+            }
+            if (a == P) {                                       // row p
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) v[pp][cb] = (b == P && cb == pp) ? d : rj[cb];
+            }
+            if (a == P1) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) nrow[8 * b + cb] = v[q1][cb];
+            }
+            if (b == P1) {
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) ncol[8 * a + ra] = v[ra][q1];
+            }
+            if (a == P1 && b == P1) nrow[128] = gjw_recip(v[q1][q1]);
+            cur ^= 1;
+        }
+    }
+    gjw_sync();
+}

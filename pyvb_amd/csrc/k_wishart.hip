@@ -128,8 +128,9 @@ __global__ void __launch_bounds__(256) k_dense_pre(WArgs a) {
 // m1 of hstack.pass_up_m1_m2, nodes_todo.py:56), qcov = inverse, q_ln_det (quirk Q1).  The precisions do not depend on
 // the other columns: four columns per workgroup, all of them in parallel.
 __global__ void __launch_bounds__(256) k_colcov(WArgs a) {
-    __shared__ double gjbuf[4 * 2 * GJ_BUF + 4 * 64];
-    const int WHICH = a.which0 + blockIdx.z, n = blockIdx.x, i0 = 4 * blockIdx.y, tid = threadIdx.x, D = a.D, K = a.K;
+    __shared__ double gjbuf[4 * (2 * GJW_BUF + 64)];
+    const int WHICH = a.which0 + blockIdx.z, n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
+    const int wv = tid >> 6, lane = tid & 63, i = 4 * blockIdx.y + wv;      // one wavefront per column (gj_wave)
     const int rows = WHICH == 0 ? D : K;
     const double* Lbar = (WHICH == 0 ? a.Qbar : a.Rbar) + (size_t)n * rows * rows;
     const double* pp = WHICH == 0 ? a.pri.A_pp : a.pri.C_pp;        // [col][row]
@@ -138,50 +139,57 @@ __global__ void __launch_bounds__(256) k_colcov(WArgs a) {
     double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * rows * rows;
     double* var = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
     double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
-    const int ta = tid >> 4, tb = tid & 15;
-    double v[4][16];
-    bool on[4];
+    if (!(i < D && i >= a.c0 && i < a.c1)) return;                  // wave-uniform; no workgroup barrier below
+    double* rc = gjbuf + wv * (2 * GJW_BUF + 64);
+    double* pivs = rc + 2 * GJW_BUF;
+    const int ta = lane >> 3, tb = lane & 7;
+    const double g = G[(size_t)i * D + i];
+    double v[8][8];
+    // loads are unconditional (indices clamped into the matrix, the select afterwards): 64 guarded loads would each wait
+    // for the one before
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int i = i0 + c;
-        on[c] = i < D && i >= a.c0 && i < a.c1;
-        const double g = on[c] ? G[(size_t)i * D + i] : 0.0;
+    for (int ra = 0; ra < 8; ++ra) {
+        const int k = 8 * ta + ra, kc = k < rows ? k : rows - 1;
+        const double pk = pp[(size_t)i * rows + kc];
+        double x[8];
+        if (rows == 64) {
 #pragma unroll
-        for (int ra = 0; ra < 4; ++ra)
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const int k = 4 * ta + ra, l = 4 * tb + cb, u = 4 * ra + cb;
-                double x = (k == l) ? 1.0 : 0.0;
-                if (on[c] && k < rows && l < rows) x = g * Lbar[k * rows + l] + (k == l ? pp[(size_t)i * rows + k] : 0.0);
-                v[c][u] = x;
+            for (int h2 = 0; h2 < 4; ++h2) {
+                const d2 t = *reinterpret_cast<const d2*>(Lbar + k * 64 + 8 * tb + 2 * h2);
+                x[2 * h2] = t[0]; x[2 * h2 + 1] = t[1];
             }
-    }
-    __syncthreads();
-    gj_inverse<4>(v, rows, tid, gjbuf, gjbuf + 4 * 2 * GJ_BUF);
+        } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (!on[c]) continue;
-        const int i = i0 + c;
-        if (tid < 64) {
-            double lp = 0.0;
-            if (tid < rows) {
-                const double piv = gjbuf[4 * 2 * GJ_BUF + c * 64 + tid];
-                if (!(piv > 0.0)) atomicOr(a.status, 1);
-                lp = log(piv);
-            }
-            lp = wave_sum(lp);
-            if (tid == 0) qld[i] = 0.5 / (0.5 * lp);
+            for (int cb = 0; cb < 8; ++cb) { const int l = 8 * tb + cb; x[cb] = Lbar[kc * rows + (l < rows ? l : rows - 1)]; }
         }
 #pragma unroll
-        for (int ra = 0; ra < 4; ++ra)
+        for (int cb = 0; cb < 8; ++cb) {
+            const int l = 8 * tb + cb;
+            const double inside = __builtin_fma(g, x[cb], (k == l) ? pk : 0.0);
+            v[ra][cb] = (k < rows && l < rows) ? inside : ((k == l) ? 1.0 : 0.0);
+        }
+    }
+    gj_wave(v, rows, lane, rc, pivs);
+    double lp = 0.0;
+    if (lane < rows) {
+        const double piv = pivs[lane];
+        if (!(piv > 0.0)) atomicOr(a.status, 1);
+        lp = log(piv);
+    }
+    lp = wave_sum(lp);
+    if (lane == 0) qld[i] = 0.5 / (0.5 * lp);
+    double* ci_ = cov + (size_t)i * rows * rows;
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const int k = 4 * ta + ra, l = 4 * tb + cb;
-                if (k < rows && l < rows) {
-                    cov[(size_t)i * rows * rows + k * rows + l] = v[c][4 * ra + cb];
-                    if (k == l) var[(size_t)i * rows + k] = v[c][4 * ra + cb];
-                }
-            }
+    for (int ra = 0; ra < 8; ++ra) {
+        const int k = 8 * ta + ra;
+        if (rows == 64) {
+#pragma unroll
+            for (int h2 = 0; h2 < 4; ++h2) *reinterpret_cast<d2*>(ci_ + k * 64 + 8 * tb + 2 * h2) = d2{v[ra][2 * h2], v[ra][2 * h2 + 1]};
+        } else if (k < rows) {
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) { const int l = 8 * tb + cb; if (l < rows) ci_[k * rows + l] = v[ra][cb]; }
+        }
+        if (ta == tb && k < rows) var[(size_t)i * rows + k] = v[ra][ra];
     }
 }
 

@@ -65,8 +65,8 @@ class Network(object):
             for p, group in self._groups():
                 if getattr(p, "generic", False):
                     llb += float(p.llb_sum(group).sum())
-                elif len(set(id(n) for n in group)) == p.n_random_nodes:
-                    llb += float(np.sum(p.elbo_parts()))        # every random node of the graph is listed: the class sums
+                elif len(group) == len(set(id(n) for n in group)) == p.n_random_nodes:
+                    llb += float(np.sum(p.elbo_parts()))        # every random node of the graph is listed, once: the class sums
                 else:
                     llb += float(sum(n.log_lower_bound() for n in group))     # a part of a fused graph: its terms one by one
             self.llb = llb                                      # network.py:49

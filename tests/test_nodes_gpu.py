@@ -482,10 +482,12 @@ def test_network_learn_over_several_unconnected_graphs():
 
     def build():
         g = G.build_graph(nodes, Y[0], pri, st0)
-        lds = Network([g["A"]]); lds.fetch_network(verbose=False)
+        # states in chain order, then the parameters: one forward sweep per learn() iteration, which the fused kernels serve
+        # (the crawl order of fetch_network is not a sweep: scenario lds_network_crawl covers that, node by node)
+        lds_list = g["Xs"] + g["As"] + g["Cs"] + [g["Q"], g["R"]] + g["Ys"]
         pca = G.pca_build_graph(pyvb_amd, init, ppri)
         sm = small(np.random.default_rng(5))
-        return g, lds.nodes, pca, pca["net"].nodes, sm
+        return g, lds_list, pca, pca["net"].nodes, sm
 
     iters = 3
     g, lds_nodes, pca, pca_nodes, sm = build()
