@@ -163,9 +163,10 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
         TRY(dev_alloc(&h->lnd, n * 4));
         TRY(dev_alloc(&h->QA, n * D * D)); TRY(dev_alloc(&h->RC, n * K * D));
         TRY(dev_alloc(&h->trA, n * D)); TRY(dev_alloc(&h->trC, n * D));
-        TRY(dev_alloc(&h->A_cov, n * D * D * D)); TRY(dev_alloc(&h->C_cov, n * D * K * K));
+        TRY(dev_alloc(&h->A_cov, n * D * cov_stride(D))); TRY(dev_alloc(&h->C_cov, n * D * cov_stride(K)));
         TRY(dev_alloc(&h->SyyF, n * K * K));
         TRY(dev_alloc(&h->RQ, n * D * D)); TRY(dev_alloc(&h->RR, n * K * K));
+        TRY(dev_alloc(&h->SG, n * 2 * 64 * 64));
     }
     TRYHIP(hipMemset(h->pri.A_obs, 0xFF, ((size_t)D * D + (size_t)K * D) * sizeof(double)));     // all-ones bytes = NaN = nothing observed
     h->fresh = (unsigned char*)calloc(T, 1);
@@ -196,7 +197,7 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
                       h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->sxx, h->U,
-                      h->Q_w, h->R_w, h->Qbar, h->Rbar, h->lnd, h->QA, h->RC, h->trA, h->trC, h->A_cov, h->C_cov, h->SyyF, h->RQ, h->RR,
+                      h->Q_w, h->R_w, h->Qbar, h->Rbar, h->lnd, h->QA, h->RC, h->trA, h->trC, h->A_cov, h->C_cov, h->SyyF, h->RQ, h->RR, h->SG,
                       h->Yobs, h->Yvar, h->Yqld, h->Yent};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
@@ -234,7 +235,7 @@ static void params_changed(pyvb_lds* h) {
     h->gains_valid = false;
     h->u_valid = false;
 }
-static void states_changed(pyvb_lds* h) { h->stats_valid = false; h->resQ_valid = false; h->resR_valid = false; }
+static void states_changed(pyvb_lds* h) { h->stats_valid = false; h->resQ_valid = false; h->resR_valid = false; h->sg_valid[0] = h->sg_valid[1] = false; }
 
 // ln det of a symmetric positive definite matrix (Constant.lndet, node.py:301-302)
 static int host_lndet(const double* Ain, int D, double* out) {
@@ -306,6 +307,7 @@ int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_pre
     HIPCHK(hipStreamSynchronize(h->stream));
     params_changed(h);
     h->resQ_valid = h->resR_valid = false;
+    h->sg_valid[0] = h->sg_valid[1] = false;
     return PYVB_OK;
 }
 
@@ -361,27 +363,53 @@ int pyvb_lds_get_wishart_state(pyvb_lds* h, double* Q_v, double* Q_w, double* R_
     return PYVB_OK;
 }
 
+// dense [N][D][rows][rows] on the host <-> the tiled device storage, through a device staging buffer of at most 64 MB
+static int column_cov_io(pyvb_lds* h, int which, double* host, bool to_device) {
+    if (!host) return PYVB_OK;
+    const size_t D = h->D, rows = which == 0 ? h->D : h->K, per = D * rows * rows;
+    size_t slice = ((size_t)8 << 20) / per;                 // replicates per slice
+    if (slice < 1) slice = 1;
+    if (slice > (size_t)h->N) slice = h->N;
+    double* stage = nullptr;
+    HIPCHK(hipMalloc((void**)&stage, slice * per * sizeof(double)));
+    int rc = PYVB_OK;
+    for (size_t n0 = 0; n0 < (size_t)h->N && rc == PYVB_OK; n0 += slice) {
+        const size_t cnt = (n0 + slice <= (size_t)h->N) ? slice : (size_t)h->N - n0;
+        hipError_t e = hipSuccess;
+        if (to_device) {
+            e = hipMemcpyAsync(stage, host + n0 * per, cnt * per * sizeof(double), hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) rc = launch_cov_convert(h, which, stage, (int)n0, (int)cnt, 1);
+        } else {
+            rc = launch_cov_convert(h, which, stage, (int)n0, (int)cnt, 0);
+            if (rc == PYVB_OK) e = hipMemcpyAsync(host + n0 * per, stage, cnt * per * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);       // the staging buffer is reused by the next slice
+        if (e != hipSuccess && rc == PYVB_OK) rc = pyvb_hip_fail(e, "column covariance transfer", __FILE__, __LINE__);
+    }
+    (void)hipFree(stage);
+    return rc;
+}
+
 int pyvb_lds_set_column_cov(pyvb_lds* h, const double* A_cov, const double* C_cov) {
     ENTER(h);
     ARGCHK(h->dense, "dense column covariances exist with PYVB_NOISE_WISHART only");
-    const size_t N = h->N, D = h->D, K = h->K;
     int rc;
-    if ((rc = h2d(h, h->A_cov, A_cov, N * D * D * D))) return rc;
-    if ((rc = h2d(h, h->C_cov, C_cov, N * D * K * K))) return rc;
+    if ((rc = column_cov_io(h, 0, const_cast<double*>(A_cov), true))) return rc;
+    if ((rc = column_cov_io(h, 1, const_cast<double*>(C_cov), true))) return rc;
     if ((A_cov || C_cov) && (rc = launch_cov_to_colvar(h))) return rc;      // the diagonals (what the lower bound reads) follow
     HIPCHK(hipStreamSynchronize(h->stream));
     params_changed(h);
     h->resQ_valid = h->resR_valid = false;
+    h->sg_valid[0] = h->sg_valid[1] = false;
     return PYVB_OK;
 }
 
 int pyvb_lds_get_column_cov(pyvb_lds* h, double* A_cov, double* C_cov) {
     ENTER(h);
     ARGCHK(h->dense, "dense column covariances exist with PYVB_NOISE_WISHART only");
-    const size_t N = h->N, D = h->D, K = h->K;
     int rc;
-    if ((rc = d2h(h, A_cov, h->A_cov, N * D * D * D))) return rc;
-    if ((rc = d2h(h, C_cov, h->C_cov, N * D * K * K))) return rc;
+    if ((rc = column_cov_io(h, 0, A_cov, false))) return rc;
+    if ((rc = column_cov_io(h, 1, C_cov, false))) return rc;
     return pyvb_lds_sync(h);
 }
 
@@ -496,7 +524,10 @@ int pyvb_lds_set_state(pyvb_lds* h, const double* X, const double* A_mean, const
     if ((rc = h2d(h, h->C_var, C_colvar, N * D * K))) return rc;
     if ((rc = h2d(h, h->Q_b, Q_b, N * D))) return rc;
     if ((rc = h2d(h, h->R_b, R_b, N * K))) return rc;
-    if (h->dense && (A_colvar || C_colvar) && (rc = launch_colvar_to_cov(h))) return rc;     // diagonal initial covariances
+    if (h->dense && (A_colvar || C_colvar)) {       // diagonal initial covariances
+        if ((rc = launch_colvar_to_cov(h))) return rc;
+        h->sg_valid[0] = h->sg_valid[1] = false;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     if (X) { states_changed(h); h->u_valid = false; h->sxx_valid = false; }
     if (A_mean || A_colvar || C_mean || C_colvar || Q_b || R_b) { params_changed(h); h->resQ_valid = h->resR_valid = false; }
@@ -763,35 +794,28 @@ int pyvb_lds_iterate(pyvb_lds* h, int niters) {
         if ((rc = sweep(h, PYVB_FORWARD, false))) return rc;
         if ((rc = join_elbo(h))) return rc;
         if ((rc = sweep(h, PYVB_BACKWARD, true))) return rc;
+        // A and C are independent given the statistics, and so are Q and R given A and C: the pairs
+        // share launches here (same arithmetic as update_A, update_C, update_Q, update_R in turn)
+        if ((rc = ensure_stats(h))) return rc;
         if (h->dense) {
-            // as below: A and C are independent given the statistics, Q and R given A and C -- the pairs share launches
-            if ((rc = ensure_stats(h))) return rc;
             if ((rc = ensure_expect(h))) return rc;
             if ((rc = launch_cols_dense(h, 2, 0, h->D))) return rc;
             params_changed(h);
             if ((rc = launch_wresid(h, 2, 1))) return rc;          // both residual matrices and both qw = w0 + residual
-            h->resQ_valid = h->resR_valid = true;
             h->expect_valid = false;
             params_changed(h);
-            if ((rc = pyvb_lds_elbo(h))) return rc;
-            double* slot = h->elbo_hist + (size_t)(h->hist_count % PYVB_ELBO_HISTORY) * 8;      // same history, main stream
-            if ((rc = launch_elbo_sum(h, slot, h->stream))) return rc;
-            if (h->comm && (rc = pyvb_allreduce_f64(h->comm, slot, 6, h->stream))) return rc;
-            h->hist_count += 1;
-            continue;
+            if ((rc = ensure_expect(h))) return rc;                // E[Q], E[R] of the new posteriors: the bound and the next k_prep read them
+        } else {
+            if ((rc = launch_cols(h, 2, 0, h->D, 3))) return rc;       // columns, residuals and noise update in one launch
+            params_changed(h);
         }
-        // A and C are independent given the statistics, and so are Q and R given A and C: the pairs
-        // share launches here (same arithmetic as update_A, update_C, update_Q, update_R in turn)
-        if ((rc = ensure_stats(h))) return rc;
-        if ((rc = launch_cols(h, 2, 0, h->D, 3))) return rc;       // columns, residuals and noise update in one launch
-        params_changed(h);
         h->resQ_valid = h->resR_valid = true;
         // The lower bound (network.py:49) feeds nothing in the next iteration: it is evaluated on the side stream while
         // the main one goes on with k_prep and the forward sweep.  Its per-iteration totals (summed over the replicates,
         // and over the ranks when a communicator is attached) go into a history ring (pyvb_lds_get_elbo_history).
         HIPCHK(hipEventRecord(h->ev_params, h->stream));
         HIPCHK(hipStreamWaitEvent(h->side, h->ev_params, 0));
-        if ((rc = launch_elbo(h, h->side))) return rc;
+        if ((rc = h->dense ? launch_elbo_dense(h, h->side) : launch_elbo(h, h->side))) return rc;
         double* slot = h->elbo_hist + (size_t)(h->hist_count % PYVB_ELBO_HISTORY) * 8;
         if ((rc = launch_elbo_sum(h, slot, h->side))) return rc;
         if (h->comm && (rc = pyvb_allreduce_f64(h->comm, slot, 6, h->side))) return rc;

@@ -44,6 +44,10 @@ __host__ __device__ static inline size_t pos_perm(int i, int j, int S) {
     return ((size_t)((i >> 4) * S + s) * 64) + q * 16 + (i & 15);
 }
 
+// column covariances under Wishart noise are stored as the upper 8 x 8 tiles of the matrix (k_wishart.hip: cov_pos)
+__host__ __device__ static inline int cov_tiles(int rows) { const int RT = (rows + 7) >> 3; return RT * (RT + 1) / 2; }
+__host__ __device__ static inline size_t cov_stride(int rows) { return (size_t)cov_tiles(rows) * 64; }
+
 static inline int tiles16(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : 4); }
 
 static inline Layout make_layout(int D, int K) {
@@ -120,10 +124,12 @@ struct pyvb_lds {
     double *lnd;                    // [N][4]: ln det E[Q], ln det E[R], ln det sym(Q_w), ln det sym(R_w)
     double *QA, *RC;                // [N][D][D] E[Q]<A>, [N][K][D] E[R]<C>
     double *trA, *trC;              // [N][D] tr(S_i E[Q]), tr(S'_i E[R])
-    double *A_cov, *C_cov;          // [N][D][D][D], [N][D][K][K] column covariances
+    double *A_cov, *C_cov;          // [N][D][cov_stride(D)], [N][D][cov_stride(K)] column covariances, upper 8 x 8 tiles (k_wishart.hip)
     double *SyyF;                   // [N][K][K] sum_t y y^T
     double *RQ, *RR;                // [N][D][D], [N][K][K]: sum over children of 1/2<xx^T> + 1/2<mu mu^T> - <x><mu>^T
     bool expect_valid;              // Qbar, Rbar, lnd belong to the current Q_w, R_w
+    double *SG; bool sg_valid[2];   // [N][2][64][64] sum_i G[i,i] S_i over the columns of A / C (k_cols_wishart); valid while neither the
+                                    // covariances nor the statistics have changed since
     // ---- outputs with missing entries (k_missing.hip); allocated when set_observations sees NaN
     bool has_missing;
     double *Yobs, *Yvar, *Yqld, *Yent;      // [N][T][K] observations (NaN = missing), [N][T][K] variances, [N][T], [N]
@@ -155,9 +161,10 @@ int launch_dense_pre(pyvb_lds* h);                  // QA, RC, trA, trC
 int launch_cols_dense(pyvb_lds* h, int which, int c0, int c1);
 int launch_wresid(pyvb_lds* h, int which, int update);
 int launch_syy_full(pyvb_lds* h);
-int launch_elbo_dense(pyvb_lds* h);
+int launch_elbo_dense(pyvb_lds* h, hipStream_t stream = nullptr);
 int launch_colvar_to_cov(pyvb_lds* h);              // A_var/C_var (diagonals) -> A_cov/C_cov
 int launch_cov_to_colvar(pyvb_lds* h);              // and back
+int launch_cov_convert(pyvb_lds* h, int which, double* dense, int n0, int count, int to_packed);   // dense [count][D][rows][rows] (device) <-> the tiles of replicates n0..
 // k_missing.hip
 int launch_missing_init(pyvb_lds* h, const double* Yq0, const double* Yrowvar0);     // device pointers or null
 int launch_impute(pyvb_lds* h);

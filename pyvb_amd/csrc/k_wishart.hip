@@ -17,8 +17,29 @@
 #include "params.h"
 #include "gj.h"
 
+// ---- storage of the column covariances (symmetric, rows x rows, D of them per matrix and replicate): the upper 8 x 8 TILES
+// only -- tile (A <= B) of the matrix padded to 8 RT rows is number A RT - A (A - 1) / 2 + (B - A), its 64 elements row-major;
+// diagonal tiles hold their whole (symmetric) block.  This is the order in which a lane of gj_wave holds its part of the
+// inverse, so the column kernel stores 512 contiguous bytes per lane, and it is 56 % of the dense size at 64 rows: the
+// covariances are the largest object of the Wishart path (2.4 GB instead of 4.3 GB at N = 1024, D = K = 64).
+// (cov_tiles / cov_stride: common.h)
+__device__ __forceinline__ size_t cov_pos(int rows, int k, int l) {
+    const int RT = (rows + 7) >> 3;
+    const int lo = k < l ? k : l, hi = k < l ? l : k, A = lo >> 3, B = hi >> 3;
+    const int t = A * RT - (A * (A - 1)) / 2 + (B - A);
+    return (size_t)t * 64 + (A == B ? (k & 7) * 8 + (l & 7) : (lo & 7) * 8 + (hi & 7));
+}
+// (A, B) of tile t
+__device__ __forceinline__ void cov_tile_ab(int rows, int t, int& A, int& B) {
+    const int RT = (rows + 7) >> 3;
+    A = 0;
+    while (t >= RT - A) { t -= RT - A; ++A; }
+    B = A + t;
+}
+
 struct WArgs {
     double *Q_w, *R_w, *Qbar, *Rbar, *lnd, *QA, *RC, *trA, *trC, *A_cov, *C_cov, *RQ, *RR, *SyyF;
+    double* SG;         // [N][2][64][64]-slots holding [rows][rows]: sum_i G[i,i] S_i of A's / C's columns (k_cols_wishart), or null: k_wresid sums the covariances itself
     const double *Q_a, *R_a;
     double *A_mean, *A_var, *C_mean, *C_var, *qld_A, *qld_C;
     const double *mom, *X, *Sigma, *Y, *qld_x;
@@ -38,7 +59,7 @@ static WArgs make_wargs(pyvb_lds* h) {
     a.mom = h->mom; a.X = h->X[h->cur]; a.Sigma = h->Sigma; a.Y = h->Y; a.qld_x = h->qld_x; a.elbo = h->elbo;
     a.pri = h->pri; a.status = h->status;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.DP = h->L.DP;
-    a.which0 = 0; a.c0 = 0; a.c1 = h->D; a.update = 0;
+    a.which0 = 0; a.c0 = 0; a.c1 = h->D; a.update = 0; a.SG = nullptr;
     return a;
 }
 
@@ -108,141 +129,191 @@ __global__ void __launch_bounds__(256) k_dense_pre(WArgs a) {
         for (int l = 0; l < rows; ++l) s += Lb[k * WLD + l] * Mb[l * WLD + j];
         out[idx] = s;
     }
-    // traces: four threads per column, a quarter of the rows each
-    const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * rows * rows;
-    const int i = tid >> 2, part = tid & 3;
-    double s = 0.0;
-    if (i < D) {
-        const double* Si = cov + (size_t)i * rows * rows;
-        for (int k = part; k < rows; k += 4) {
-#pragma unroll 16
-            for (int l = 0; l < rows; ++l) s += Si[k * rows + l] * Lb[k * WLD + l];      // both symmetric
-        }
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (i < D && part == 0) (WHICH == 0 ? a.trA : a.trC)[(size_t)n * D + i] = s;
-}
-
-// ---- posterior covariances of the columns: qprec_i = diag(prior) + E[Lambda] * sum_t <x x^T>[i,i]   (gaussian.py:117 with
-// m1 of hstack.pass_up_m1_m2, nodes_todo.py:56), qcov = inverse, q_ln_det (quirk Q1).  The precisions do not depend on
-// the other columns: four columns per workgroup, all of them in parallel.
-__global__ void __launch_bounds__(256) k_colcov(WArgs a) {
-    __shared__ double gjbuf[4 * (2 * GJW_BUF + 64)];
-    const int WHICH = a.which0 + blockIdx.z, n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
-    const int wv = tid >> 6, lane = tid & 63, i = 4 * blockIdx.y + wv;      // one wavefront per column (gj_wave)
-    const int rows = WHICH == 0 ? D : K;
-    const double* Lbar = (WHICH == 0 ? a.Qbar : a.Rbar) + (size_t)n * rows * rows;
-    const double* pp = WHICH == 0 ? a.pri.A_pp : a.pri.C_pp;        // [col][row]
-    const double* mo = a.mom + (size_t)n * mom_total(D, K);
-    const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
-    double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * rows * rows;
-    double* var = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
-    double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
-    if (!(i < D && i >= a.c0 && i < a.c1)) return;                  // wave-uniform; no workgroup barrier below
-    double* rc = gjbuf + wv * (2 * GJW_BUF + 64);
-    double* pivs = rc + 2 * GJW_BUF;
-    const int ta = lane >> 3, tb = lane & 7;
-    const double g = G[(size_t)i * D + i];
-    double v[8][8];
-    // loads are unconditional (indices clamped into the matrix, the select afterwards): 64 guarded loads would each wait
-    // for the one before
-#pragma unroll
-    for (int ra = 0; ra < 8; ++ra) {
-        const int k = 8 * ta + ra, kc = k < rows ? k : rows - 1;
-        const double pk = pp[(size_t)i * rows + kc];
-        double x[8];
-        if (rows == 64) {
-#pragma unroll
-            for (int h2 = 0; h2 < 4; ++h2) {
-                const d2 t = *reinterpret_cast<const d2*>(Lbar + k * 64 + 8 * tb + 2 * h2);
-                x[2 * h2] = t[0]; x[2 * h2 + 1] = t[1];
+    // traces: a wavefront per column (16 columns each), a lane per element of an 8 x 8 tile: every load instruction reads
+    // one whole stored tile (512 contiguous bytes); off-diagonal tiles count twice (both matrices are symmetric)
+    const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * cov_stride(rows);
+    const int wv = tid >> 6, lane = tid & 63, ra = lane >> 3, cb = lane & 7;
+    const int RT = (rows + 7) >> 3;
+    for (int i = wv; i < D; i += 4) {
+        const double* Si = cov + (size_t)i * cov_stride(rows);
+        double s = 0.0;
+        int t = 0;
+        for (int A = 0; A < RT; ++A) {
+#pragma unroll 4
+            for (int B = A; B < RT; ++B, ++t) {
+                const int k = 8 * A + ra, l = 8 * B + cb;
+                const double x = Si[(size_t)t * 64 + lane];
+                const double y = Lb[(k < rows ? k : 0) * WLD + (l < rows ? l : 0)];
+                s = __builtin_fma((k < rows && l < rows) ? (A == B ? 1.0 : 2.0) : 0.0, x * y, s);
             }
-        } else {
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) { const int l = 8 * tb + cb; x[cb] = Lbar[kc * rows + (l < rows ? l : rows - 1)]; }
         }
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
-            const int l = 8 * tb + cb;
-            const double inside = __builtin_fma(g, x[cb], (k == l) ? pk : 0.0);
-            v[ra][cb] = (k < rows && l < rows) ? inside : ((k == l) ? 1.0 : 0.0);
-        }
-    }
-    gj_wave(v, rows, lane, rc, pivs);
-    double lp = 0.0;
-    if (lane < rows) {
-        const double piv = pivs[lane];
-        if (!(piv > 0.0)) atomicOr(a.status, 1);
-        lp = log(piv);
-    }
-    lp = wave_sum(lp);
-    if (lane == 0) qld[i] = 0.5 / (0.5 * lp);
-    double* ci_ = cov + (size_t)i * rows * rows;
-#pragma unroll
-    for (int ra = 0; ra < 8; ++ra) {
-        const int k = 8 * ta + ra;
-        if (rows == 64) {
-#pragma unroll
-            for (int h2 = 0; h2 < 4; ++h2) *reinterpret_cast<d2*>(ci_ + k * 64 + 8 * tb + 2 * h2) = d2{v[ra][2 * h2], v[ra][2 * h2 + 1]};
-        } else if (k < rows) {
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) { const int l = 8 * tb + cb; if (l < rows) ci_[k * rows + l] = v[ra][cb]; }
-        }
-        if (ta == tb && k < rows) var[(size_t)i * rows + k] = v[ra][ra];
+        s = wave_sum(s);
+        if (lane == 0) (WHICH == 0 ? a.trA : a.trC)[(size_t)n * D + i] = s;
     }
 }
 
-// ---- posterior means of the columns, Gauss-Seidel over the columns (column i sees the new columns 0..i-1):
-//   qmu_i = qcov_i ( prior_prec_i prior_mean_i + E[Lambda] ( H[:,i] - sum_{j != i} <m_j> G[i,j] ) )
-// (gaussian.py:122-123 with m2 of hstack.pass_up_m1_m2, nodes_todo.py:59-61).  Lane = row.
-__global__ void __launch_bounds__(64) k_colmean(WArgs a) {
-    __shared__ double Mb[64 * WLD], Lb[64 * WLD], gv[64], rv[64], wv[64];
-    const int WHICH = a.which0 + blockIdx.y, n = blockIdx.x, lane = threadIdx.x, D = a.D, K = a.K;
+// ---- the column update of one matrix in ONE launch: [a.update() for a in As] (or Cs) under Wishart noise.
+// One workgroup of eight wavefronts per (replicate, matrix).  The posterior covariances do not depend on each other, so the
+// wavefronts invert eight columns' precisions side by side (gj_wave, one matrix per wavefront, in registers); the means are a
+// Gauss-Seidel chain over the columns (column i sees the new columns before it), so after its inversion a wavefront waits for
+// its column's turn (a counter in LDS), and then forms
+//   r = H[:,i] - sum_{j != i} <m_j> G[i,j],   w = prior_prec_i prior_mean_i + E[Lambda] r,   qmu_i = qcov_i w
+// with <M> and E[Lambda] in LDS and qcov_i still in its registers -- no covariance is read back from memory -- and adds
+// G[i,i] qcov_i to the running sum the noise update needs (Multiplication.pass_down_ExxT, node.py:260-271: sum_i S_i G_ii),
+// kept in LDS as the 36 upper 8 x 8 tiles; the turns are in column order, so the sum is formed in a fixed order.
+// Against round 2's three kernels (all inversions; then a one-wavefront chain per matrix re-reading every covariance; then the
+// loop over the columns in k_wresid re-reading them again) this saves two passes over the column covariances
+// (profiles/r03/wishart_*).
+#define CW_WAVES 8
+__global__ void __launch_bounds__(64 * CW_WAVES) k_cols_wishart(WArgs a) {
+    __shared__ double Lb[64 * 64];          // E[Lambda], [l][k] (symmetric)
+    __shared__ double Mb[64 * 64];          // <M>, [col][row]
+    __shared__ double SGs[64 * 36];         // sum_i G[i,i] S_i: element e = 8 ra + cb of upper tile t at [e][t]
+    __shared__ double gjbuf[CW_WAVES * (2 * GJW_BUF + 64)];
+    __shared__ double gv[64], rvv[64], wvv[64];
+    __shared__ int turn, turn2;                 // chain steps done / sums done: the column (counted from c0) whose turn it is
+    __shared__ double pre[CW_WAVES][3][64];     // per wavefront: G[i,:], H[:,i], prior_prec_i prior_mean_i of its column, fetched ahead of the chain
+    const int WHICH = a.which0 + blockIdx.y, n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
+    const int wv = tid >> 6, lane = tid & 63;
     const int rows = WHICH == 0 ? D : K;
     const double* Lbar = (WHICH == 0 ? a.Qbar : a.Rbar) + (size_t)n * rows * rows;
     double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
-    const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * rows * rows;
     const double* pm = WHICH == 0 ? a.pri.A_pm : a.pri.C_pm;    // [row][col]
     const double* pp = WHICH == 0 ? a.pri.A_pp : a.pri.C_pp;    // [col][row]
     const double* mo = a.mom + (size_t)n * mom_total(D, K);
     const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
     const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
-    const bool live = lane < rows;
-    for (int idx = lane; idx < rows * D; idx += 64) Mb[(idx % D) * WLD + idx / D] = M[idx];             // Mb[col][row]
-    for (int idx = lane; idx < rows * rows; idx += 64) Lb[(idx / rows) * WLD + idx % rows] = Lbar[idx];
-    __syncthreads();
-    for (int i = a.c0; i < a.c1; ++i) {
-        if (lane < D) gv[lane] = G[(size_t)i * D + lane];
-        __syncthreads();
-        double r = 0.0;
-        if (live) {
-            r = H[(size_t)lane * D + i];
-#pragma unroll 8
-            for (int j = 0; j < D; ++j) r -= (j != i) ? Mb[j * WLD + lane] * gv[j] : 0.0;
-        }
-        rv[lane] = r;
-        __syncthreads();
-        double w = 0.0;
-        if (live) {
-            w = pp[(size_t)i * rows + lane] * pm[(size_t)lane * D + i];
-#pragma unroll 8
-            for (int l = 0; l < rows; ++l) w += Lb[lane * WLD + l] * rv[l];
-        }
-        wv[lane] = w;
-        __syncthreads();
-        if (live) {
-            const double* Si = cov + (size_t)i * rows * rows;
-            double mu = 0.0;
-#pragma unroll 16
-            for (int l = 0; l < rows; ++l) mu += Si[(size_t)l * rows + lane] * wv[l];      // symmetric: read down a column (16 loads in flight)
-            Mb[i * WLD + lane] = mu;
-        }
-        __syncthreads();
+    double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * cov_stride(rows);
+    double* var = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
+    double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
+    const int RT = (rows + 7) >> 3;
+    for (int idx = tid; idx < 64 * 64; idx += 64 * CW_WAVES) {
+        const int k = idx & 63, l = idx >> 6;
+        Lb[idx] = (k < rows && l < rows) ? Lbar[l * rows + k] : 0.0;
+        Mb[idx] = (k < rows && l < D) ? M[(size_t)k * D + l] : 0.0;         // Mb[col l][row k]
     }
-    for (int idx = lane; idx < rows * D; idx += 64) {
-        const int i = idx % D;
-        if (i >= a.c0 && i < a.c1) M[idx] = Mb[i * WLD + idx / D];
+    for (int idx = tid; idx < 64 * 36; idx += 64 * CW_WAVES) SGs[idx] = 0.0;
+    if (tid == 0) { turn = 0; turn2 = 0; }
+    __syncthreads();
+    double* rc = gjbuf + wv * (2 * GJW_BUF + 64);
+    double* pivs = rc + 2 * GJW_BUF;
+    const int ta = lane >> 3, tb = lane & 7;
+    const int tile = ta * 8 - (ta * (ta - 1)) / 2 + (tb - ta);      // index of upper tile (ta <= tb)
+    const int nrounds = (a.c1 - a.c0 + CW_WAVES - 1) / CW_WAVES;
+    for (int round = 0; round < nrounds; ++round) {
+        const int i = a.c0 + round * CW_WAVES + wv;
+        const bool active = i < a.c1;                   // wave-uniform
+        double v[8][8];
+        double g = 0.0;
+        if (active) {
+            // what the chain step will need from memory, fetched before the elimination so that its latency is not in the chain
+            g = G[(size_t)i * D + i];
+            pre[wv][0][lane] = lane < D ? G[(size_t)i * D + lane] : 0.0;
+            pre[wv][1][lane] = lane < rows ? H[(size_t)lane * D + i] : 0.0;
+            pre[wv][2][lane] = lane < rows ? pp[(size_t)i * rows + lane] * pm[(size_t)lane * D + i] : 0.0;
+#pragma unroll
+            for (int ra = 0; ra < 8; ++ra) {
+                const int k = 8 * ta + ra;
+                const double pk = pp[(size_t)i * rows + (k < rows ? k : rows - 1)];
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+                    const int l = 8 * tb + cb;
+                    const double inside = __builtin_fma(g, Lb[l * 64 + k], (k == l) ? pk : 0.0);
+                    v[ra][cb] = (k < rows && l < rows) ? inside : ((k == l) ? 1.0 : 0.0);
+                }
+            }
+            gj_wave(v, rows, lane, rc, pivs);
+            double lp = 0.0;
+            if (lane < rows) {
+                const double piv = pivs[lane];
+                if (!(piv > 0.0)) atomicOr(a.status, 1);
+                lp = log(piv);
+            }
+            lp = wave_sum(lp);
+            if (lane == 0) qld[i] = 0.5 / (0.5 * lp);
+            if (ta <= tb && tb < RT) {          // the upper tiles, 64 contiguous doubles per lane (cov_pos)
+                double* ci_ = cov + (size_t)i * cov_stride(rows) + (size_t)(ta * RT - (ta * (ta - 1)) / 2 + (tb - ta)) * 64;
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra)
+#pragma unroll
+                    for (int h2 = 0; h2 < 4; ++h2) *reinterpret_cast<d2*>(ci_ + 8 * ra + 2 * h2) = d2{v[ra][2 * h2], v[ra][2 * h2 + 1]};
+            }
+            if (ta == tb) {
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) if (8 * ta + ra < rows) var[(size_t)i * rows + 8 * ta + ra] = v[ra][ra];
+            }
+            // ---- the chain step of column i, when the columns before it have had theirs.  No workgroup barrier: a
+            // wavefront that is done goes on with its next elimination while the others take their turns, so in steady
+            // state the turns are staggered and nobody waits.  (All eight wavefronts are resident: the wait cannot deadlock.)
+            const int rel = round * CW_WAVES + wv;
+            while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != rel) __builtin_amdgcn_s_sleep(4);
+            gv[lane] = pre[wv][0][lane];
+            gjw_sync();
+            double r4[4] = {pre[wv][1][lane], 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int j = 0; j < 64; j += 4)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r4[u] = __builtin_fma(-Mb[(j + u) * 64 + lane], (j + u != i) ? gv[j + u] : 0.0, r4[u]);
+            rvv[lane] = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+            gjw_sync();
+            double w4[4] = {pre[wv][2][lane], 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int l = 0; l < 64; l += 4)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w4[u] = __builtin_fma(Lb[(l + u) * 64 + lane], rvv[l + u], w4[u]);
+            wvv[lane] = lane < rows ? (w4[0] + w4[1]) + (w4[2] + w4[3]) : 0.0;
+            gjw_sync();
+            double ws[8];
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) ws[cb] = wvv[8 * tb + cb];
+#pragma unroll
+            for (int ra = 0; ra < 8; ++ra) {
+                double p0 = v[ra][0] * ws[0], p1 = v[ra][1] * ws[1];
+#pragma unroll
+                for (int cb = 2; cb < 8; cb += 2) { p0 = __builtin_fma(v[ra][cb], ws[cb], p0); p1 = __builtin_fma(v[ra][cb + 1], ws[cb + 1], p1); }
+                double part = p0 + p1;
+                part += __shfl_xor(part, 1, 64);
+                part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 4, 64);
+                if (tb == 0) Mb[i * 64 + 8 * ta + ra] = (8 * ta + ra < rows) ? part : 0.0;
+            }
+            __hip_atomic_store(&turn, rel + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ---- the running sum, in column order too, but as a stage of its own behind the chain step: the next column's
+            // chain step does not wait for it
+            while (__hip_atomic_load(&turn2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != rel) __builtin_amdgcn_s_sleep(2);
+            if (ta <= tb) {
+                // eight elements at a time, loads first: written as one statement per element the compiler orders every
+                // load behind the store before it (they could alias for all it knows)
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) {
+                    double t8[8];
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb) t8[cb] = SGs[(8 * ra + cb) * 36 + tile];
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb) t8[cb] = __builtin_fma(g, v[ra][cb], t8[cb]);
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb) SGs[(8 * ra + cb) * 36 + tile] = t8[cb];
+                }
+            }
+            __hip_atomic_store(&turn2, rel + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rows * D; idx += 64 * CW_WAVES) {
+        const int k = idx / D, col = idx % D;
+        if (col >= a.c0 && col < a.c1) M[idx] = Mb[col * 64 + k];
+    }
+    if (a.SG) {
+        double* SG = a.SG + ((size_t)n * 2 + WHICH) * 64 * 64;
+        for (int idx = tid; idx < rows * rows; idx += 64 * CW_WAVES) {
+            const int k = idx / rows, l = idx % rows;
+            const int lo = k < l ? k : l, hi2 = k < l ? l : k;          // element (lo, hi2) of the upper triangle
+            const int A8 = lo >> 3, B8 = hi2 >> 3;
+            int e;
+            if (A8 == B8) { const int r0 = k & 7, c0 = l & 7; e = 8 * (r0 < c0 ? r0 : c0) + (r0 < c0 ? c0 : r0); }    // diagonal tile: its own upper part
+            else e = 8 * (lo & 7) + (hi2 & 7);
+            SG[(size_t)k * rows + l] = SGs[e * 36 + (A8 * 8 - (A8 * (A8 - 1)) / 2 + (B8 - A8))];
+        }
     }
 }
 
@@ -255,7 +326,7 @@ __global__ void __launch_bounds__(256) k_wresid(WArgs a) {
     const int WHICH = a.which0 + blockIdx.y, n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K, T = a.T, DP = a.DP;
     const int rows = WHICH == 0 ? D : K;
     const double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
-    const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * rows * rows;
+    const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * cov_stride(rows);
     const double* mo = a.mom + (size_t)n * mom_total(D, K);
     const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
     const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
@@ -278,8 +349,11 @@ __global__ void __launch_bounds__(256) k_wresid(WArgs a) {
         double e = 0.0, hm = 0.0;
 #pragma unroll 16
         for (int j = 0; j < D; ++j) { e += T1[k * WLD + j] * Mb[l * WLD + j]; hm += H[(size_t)k * D + j] * Mb[l * WLD + j]; }
+        if (a.SG) e += a.SG[((size_t)n * 2 + WHICH) * 64 * 64 + idx];       // sum_i S_i G[i,i], formed by k_cols_wishart
+        else {
 #pragma unroll 16
-        for (int i = 0; i < D; ++i) e += cov[(size_t)i * rows * rows + idx] * G[(size_t)i * D + i];
+            for (int i = 0; i < D; ++i) e += cov[(size_t)i * cov_stride(rows) + cov_pos(rows, k, l)] * G[(size_t)i * D + i];
+        }
         double own;
         if (WHICH == 0) own = GC[idx] - x0[xpos(k)] * x0[xpos(l)] - S0[idx];          // sum_{t >= 1} <x x^T>
         else own = a.SyyF[(size_t)n * K * K + idx];
@@ -327,18 +401,42 @@ __global__ void __launch_bounds__(256) k_syy_full(WArgs a) {
 __global__ void __launch_bounds__(256) k_colvar_to_cov(WArgs a) {
     const int WHICH = blockIdx.z, n = blockIdx.x, i = blockIdx.y, D = a.D;
     const int rows = WHICH == 0 ? a.D : a.K;
-    double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + ((size_t)n * D + i) * rows * rows;
+    double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + ((size_t)n * D + i) * cov_stride(rows);
     const double* var = (WHICH == 0 ? a.A_var : a.C_var) + ((size_t)n * D + i) * rows;
-    for (int idx = threadIdx.x; idx < rows * rows; idx += 256) cov[idx] = (idx / rows == idx % rows) ? var[idx / rows] : 0.0;
+    for (int idx = threadIdx.x; idx < (int)cov_stride(rows); idx += 256) cov[idx] = 0.0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < rows; k += 256) cov[cov_pos(rows, k, k)] = var[k];
 }
 
 // ... and back: the diagonals (what the lower bound reads) of column covariances the caller supplied
 __global__ void __launch_bounds__(64) k_cov_to_colvar(WArgs a) {
     const int WHICH = blockIdx.z, n = blockIdx.x, i = blockIdx.y, D = a.D, k = threadIdx.x;
     const int rows = WHICH == 0 ? a.D : a.K;
-    const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + ((size_t)n * D + i) * rows * rows;
+    const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + ((size_t)n * D + i) * cov_stride(rows);
     double* var = (WHICH == 0 ? a.A_var : a.C_var) + ((size_t)n * D + i) * rows;
-    if (k < rows) var[k] = cov[(size_t)k * rows + k];
+    if (k < rows) var[k] = cov[cov_pos(rows, k, k)];
+}
+
+// ---- the C ABI exchanges dense [rows][rows] covariances (pyvb_lds_get/set_column_cov): dense <-> upper tiles, in slices of
+// replicates so that the dense staging buffer stays small.  to_packed reads the upper triangle of what the caller supplied.
+struct CovConvArgs { double* packed; double* dense; int n0, D, rows, to_packed; };
+__global__ void __launch_bounds__(256) k_cov_convert(CovConvArgs c) {
+    const int n = blockIdx.x, i = blockIdx.y, rows = c.rows;
+    double* P = c.packed + ((size_t)(c.n0 + n) * c.D + i) * cov_stride(rows);
+    double* Dn = c.dense + ((size_t)n * c.D + i) * rows * rows;
+    for (int idx = threadIdx.x; idx < rows * rows; idx += 256) {
+        const int k = idx / rows, l = idx % rows;
+        if (c.to_packed) { if (k <= l || (k >> 3) == (l >> 3)) P[cov_pos(rows, k, l)] = Dn[idx]; }
+        else Dn[idx] = P[cov_pos(rows, k, l)];
+    }
+}
+
+int launch_cov_convert(pyvb_lds* h, int which, double* dense, int n0, int count, int to_packed) {
+    CovConvArgs c; c.packed = which == 0 ? h->A_cov : h->C_cov; c.dense = dense; c.n0 = n0; c.D = h->D;
+    c.rows = which == 0 ? h->D : h->K; c.to_packed = to_packed;
+    hipLaunchKernelGGL(k_cov_convert, dim3(count, h->D), dim3(256), 0, h->stream, c);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
 }
 
 __device__ static double psi_multi(double x, int D) {       // sum_{i<D} psi(x - i/2)
@@ -433,16 +531,23 @@ int launch_cols_dense(pyvb_lds* h, int which, int c0, int c1) {
     WArgs a = make_wargs(h);
     a.which0 = which == 1 ? 1 : 0; a.c0 = c0; a.c1 = c1;
     const int nw = which == 2 ? 2 : 1;
+    a.SG = h->SG;
     TimedLaunch tl(h, PYVB_K_PARAMS);
-    hipLaunchKernelGGL(k_colcov, dim3(h->N, (h->D + 3) / 4, nw), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(k_colmean, dim3(h->N, nw), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(k_cols_wishart, dim3(h->N, nw), dim3(64 * CW_WAVES), 0, h->stream, a);
     HIPCHK(hipGetLastError());
+    // the sums hold every column's covariance as it is now only when all columns went through the launch (and the
+    // statistics they were weighted with stay the current ones: states_changed() drops them)
+    const bool all = c0 == 0 && c1 == h->D;
+    if (which == 0 || which == 2) h->sg_valid[0] = all;
+    if (which == 1 || which == 2) h->sg_valid[1] = all;
     return PYVB_OK;
 }
 
 int launch_wresid(pyvb_lds* h, int which, int update) {
     WArgs a = make_wargs(h);
     a.which0 = which == 1 ? 1 : 0; a.update = update;
+    const bool need0 = which != 1, need1 = which != 0;
+    a.SG = ((!need0 || h->sg_valid[0]) && (!need1 || h->sg_valid[1])) ? h->SG : nullptr;
     TimedLaunch tl(h, PYVB_K_PARAMS);
     hipLaunchKernelGGL(k_wresid, dim3(h->N, which == 2 ? 2 : 1), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
@@ -470,10 +575,11 @@ int launch_cov_to_colvar(pyvb_lds* h) {
     return PYVB_OK;
 }
 
-int launch_elbo_dense(pyvb_lds* h) {
+int launch_elbo_dense(pyvb_lds* h, hipStream_t stream) {
     WArgs a = make_wargs(h);
-    TimedLaunch tl(h, PYVB_K_ELBO);
-    hipLaunchKernelGGL(k_elbo_dense, dim3(h->N), dim3(64), 0, h->stream, a);
+    hipStream_t s = stream ? stream : h->stream;
+    TimedLaunch tl(h, PYVB_K_ELBO, s);
+    hipLaunchKernelGGL(k_elbo_dense, dim3(h->N), dim3(64), 0, s, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
