@@ -30,6 +30,46 @@ __global__ void __launch_bounds__(64) k_rows(const double* __restrict__ src, dou
     }
 }
 
+// U loads in flight per lane, then U stores; NT: non-temporal loads and stores (streaming: no reuse expected)
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) k_copy_u(const f4* __restrict__ src, f4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride); else dst[i + u * stride] = v[u]; }
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+// every workgroup copies one contiguous slab (instead of a grid-stride walk)
+template <int U>
+__global__ void __launch_bounds__(256) k_copy_slab(const f4* __restrict__ src, f4* __restrict__ dst, size_t per_block) {
+    const f4* s = src + (size_t)blockIdx.x * per_block;
+    f4* d = dst + (size_t)blockIdx.x * per_block;
+    for (size_t i = threadIdx.x; i + (U - 1) * 256 < per_block; i += U * 256) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = s[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[i + u * 256] = v[u];
+    }
+}
+__global__ void __launch_bounds__(256) k_read(const f4* __restrict__ src, float* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    f4 acc = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += src[i];
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) out[0] = 1.0f;      // never true: keeps the loads
+}
+__global__ void __launch_bounds__(256) k_fill(f4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const f4 v = {1.0f, 2.0f, 3.0f, 4.0f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
 template <class F>
 static double time_ms(F launch, int reps) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -52,6 +92,31 @@ int main() {
         printf("copy 16 B/lane, %4d workgroups: %.3f ms  %.2f TB/s (read + write)\n", cus * mult, ms, 2.0 * nb / (ms * 1e-3) / 1e12);
         ms = time_ms([&] { hipLaunchKernelGGL(k_copy<d4>, dim3(cus * mult), dim3(256), 0, 0, (const d4*)a, (d4*)b, nb / 32); }, 10);
         printf("copy 32 B/lane, %4d workgroups: %.3f ms  %.2f TB/s\n", cus * mult, ms, 2.0 * nb / (ms * 1e-3) / 1e12);
+    }
+    // the guide's figure (MI355X_MICROARCH.md: "6.29 TB/s measured, float4 copy"): float4 per lane, with several loads in flight
+    // per lane, default and non-temporal, grid-stride and slab-per-workgroup; and read-only / write-only streams
+    const size_t n4 = nb / 16;
+    for (int mult : {2, 4, 8, 16}) {
+        const int g = cus * mult;
+        double ms = time_ms([&] { hipLaunchKernelGGL((k_copy_u<4, false>), dim3(g), dim3(256), 0, 0, (const f4*)a, (f4*)b, n4); }, 10);
+        printf("float4 copy, 4 in flight, %5d workgroups: %.3f ms  %.2f TB/s\n", g, ms, 2.0 * nb / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_copy_u<8, false>), dim3(g), dim3(256), 0, 0, (const f4*)a, (f4*)b, n4); }, 10);
+        printf("float4 copy, 8 in flight, %5d workgroups: %.3f ms  %.2f TB/s\n", g, ms, 2.0 * nb / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_copy_u<4, true>), dim3(g), dim3(256), 0, 0, (const f4*)a, (f4*)b, n4); }, 10);
+        printf("float4 copy, 4 in flight, non-temporal, %5d workgroups: %.3f ms  %.2f TB/s\n", g, ms, 2.0 * nb / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_copy_slab<4>), dim3(g), dim3(256), 0, 0, (const f4*)a, (f4*)b, n4 / g / 1024 * 1024); }, 10);
+        printf("float4 copy, slab per workgroup, %5d workgroups: %.3f ms  %.2f TB/s\n", g, ms, 2.0 * (double)(n4 / g / 1024 * 1024) * g * 16 / (ms * 1e-3) / 1e12);
+    }
+    for (int mult : {4, 16}) {
+        const int g = cus * mult;
+        double ms = time_ms([&] { hipLaunchKernelGGL(k_read, dim3(g), dim3(256), 0, 0, (const f4*)a, (float*)b, n4); }, 10);
+        printf("read only,  %5d workgroups: %.3f ms  %.2f TB/s\n", g, ms, 1.0 * nb / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, 0, (f4*)b, n4); }, 10);
+        printf("write only, %5d workgroups: %.3f ms  %.2f TB/s\n", g, ms, 1.0 * nb / (ms * 1e-3) / 1e12);
+    }
+    {
+        double ms = time_ms([&] { CK(hipMemcpyAsync(b, a, nb, hipMemcpyDeviceToDevice, 0)); }, 10);
+        printf("hipMemcpyAsync device to device: %.3f ms  %.2f TB/s\n", ms, 2.0 * nb / (ms * 1e-3) / 1e12);
     }
     for (int waves : {1024, 2048, 4096}) {
         const int T = (int)(nb / 8 / 64 / waves) / 16 * 16;

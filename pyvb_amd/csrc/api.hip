@@ -71,9 +71,10 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     ARGCHK(out, "out is NULL");
     ARGCHK(N >= 1, "N must be >= 1");
     ARGCHK(T >= 2, "T must be >= 2 (a chain needs X_0 and X_{T-1})");
-    ARGCHK(D >= 1 && D <= 64, "latent dimension D must be in 1..64");
-    ARGCHK(K >= 1 && K <= 64, "observed dimension K must be in 1..64");
+    ARGCHK(D >= 1 && D <= 128, "latent dimension D must be in 1..128");
+    ARGCHK(K >= 1 && K <= 128, "observed dimension K must be in 1..128");
     ARGCHK(noise_kind == PYVB_NOISE_DIAGONAL_GAMMA || noise_kind == PYVB_NOISE_GAMMA || noise_kind == PYVB_NOISE_WISHART, "unknown noise kind");
+    ARGCHK(noise_kind != PYVB_NOISE_WISHART || (D <= 64 && K <= 64), "with Wishart noise D and K must be in 1..64");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     ARGCHK(device >= 0 && device < ndev, "no such device");
@@ -82,6 +83,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     memset(h, 0, sizeof(*h));
     h->device = device; h->N = N; h->T = T; h->D = D; h->K = K; h->noise = noise_kind;
     h->L = make_layout(D, K);
+    h->big = D > 64 || K > 64;           // the workgroup-per-replicate kernels of k_big.hip
     h->dense = noise_kind == PYVB_NOISE_WISHART;
     const Layout& L = h->L;
     int rc = PYVB_OK;
@@ -108,11 +110,10 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRY(dev_alloc(&h->Sigma, n * 3 * D * D)); TRY(dev_alloc(&h->Sigma_new, n * 3 * D * D));
     TRY(dev_alloc(&h->qld_x, n * 3)); TRY(dev_alloc(&h->qld_x_new, n * 3));
     TRY(dev_alloc(&h->gains, n * L.gains_total));
-    TRY(dev_alloc(&h->scratch, n * 2 * D * D));
-    TRY(dev_alloc(&h->trash, n * 256));
-    TRY(dev_alloc(&h->zeros, 64));
-    TRYHIP(hipMemset(h->zeros, 0, 64 * sizeof(double)));
-    TRY(dev_alloc(&h->U, n * T * L.DP));
+    TRY(dev_alloc(&h->scratch, h->big ? n * 2 * L.DP * L.DP : n * 2 * D * D));
+    TRY(dev_alloc(&h->trash, n * 512));
+    TRY(dev_alloc(&h->zeros, 128));
+    TRY(dev_alloc(&h->U, h->big ? 64 : n * T * L.DP));         // the c_t cache of the 64-wide sweeps
     TRYHIP(hipMalloc((void**)&h->warm, n * 2 * sizeof(int)));
     TRYHIP(hipMemset(h->warm, 0, n * 2 * sizeof(int)));
     // time chunks of the statistics kernel: enough wavefronts to fill the chip when N is small
@@ -130,7 +131,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     // ceil(part/16) + J steps (J ~ 32 warm-up steps), the chip runs 1024 of them at a time: W minimises
     // rounds x steps, with parts of at least 64 nodes.  At N >= 1024 that is W = 1.
     h->W = 1;
-    {
+    if (!h->big) {
         const long Tint = T - 2;
         double best = 1e300;
         for (int W = 1; W <= 128 && (W == 1 || Tint / W >= 64); ++W) {
@@ -416,6 +417,7 @@ int pyvb_lds_get_column_cov(pyvb_lds* h, double* A_cov, double* C_cov) {
 int pyvb_lds_set_column_observations(pyvb_lds* h, const double* A_obs, const double* C_obs) {
     ENTER(h);
     if (h->dense) { pyvb_set_error("known entries of A / C together with Wishart noise are not supported"); return PYVB_E_UNSUPPORTED; }
+    if (h->big) { pyvb_set_error("known entries of A / C with D or K above 64 is not served by the fused kernels"); return PYVB_E_UNSUPPORTED; }
     int rc;
     if ((rc = h2d(h, h->pri.A_obs, A_obs, (size_t)h->D * h->D))) return rc;
     if ((rc = h2d(h, h->pri.C_obs, C_obs, (size_t)h->K * h->D))) return rc;
@@ -435,6 +437,7 @@ int pyvb_lds_set_observations(pyvb_lds* h, const double* Y) {
     int rc;
     if (missing) {
         if (h->dense) { pyvb_set_error("outputs with missing entries together with Wishart noise are not supported"); return PYVB_E_UNSUPPORTED; }
+        if (h->big) { pyvb_set_error("outputs with missing entries with D or K above 64 is not served by the fused kernels"); return PYVB_E_UNSUPPORTED; }
         if (!h->Yobs) {
             if ((rc = dev_alloc(&h->Yobs, n))) return rc;
             if ((rc = dev_alloc(&h->Yvar, n))) return rc;
@@ -595,6 +598,7 @@ int pyvb_lds_set_time_split(pyvb_lds* h, int W) {
     ENTER(h);
     ARGCHK(W >= 1 && W <= 128, "W must be in 1..128");
     ARGCHK(W == 1 || (h->T - 2) / W >= 16, "parts of fewer than 16 nodes");
+    ARGCHK(W == 1 || !h->big, "the time split exists for D, K <= 64 only");
     HIPCHK(hipStreamSynchronize(h->stream));
     if (W != h->W) {
         double* p = nullptr;
@@ -706,6 +710,7 @@ int pyvb_lds_sweep(pyvb_lds* h, int direction) {
 int pyvb_lds_update_x(pyvb_lds* h, int t) {
     ENTER(h);
     ARGCHK(t >= 0 && t < h->T, "t out of range");
+    if (h->big) { pyvb_set_error("a single X_t.update() with D or K above 64 is not served by the fused kernels"); return PYVB_E_UNSUPPORTED; }
     int rc = ensure_gains(h);
     if (rc) return rc;
     if ((rc = launch_step(h, t))) return rc;

@@ -15,13 +15,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 //   F  = Sigma_1 <Q><A>      B  = Sigma_1 <A>^T<Q>     G  = Sigma_1 <C>^T<R>
 // The two boundary nodes are single matrix-vector chains, mu = Sigma_c (sum of the messages), so for them
 // the block holds the pieces instead of products: S0 = Sigma_0, S2 = Sigma_2 ([row][DP]), qr = <Q> diagonal
-// (64) then <R> diagonal (64), w0 = L0 m0 (the Constant parents of X_0).
+// (QR = 64 entries, 128 in the second shape class) then <R> diagonal (QR), w0 = L0 m0 (the Constant parents of X_0).
 // "n"/"p" blocks are laid out as v_mfma_f64_16x16x4 A-operands: element [(m*S+s)*64+lane]
 // = M[16m + (lane&15)][kidx(s, lane>>4)], kidx natural = 4s+q (F, B: they meet states, which come in
 // accumulator order), permuted = 8(s>>1)+2q+(s&1) (G: it meets rows of Y read 16 bytes per lane).
 // (pos_nat / pos_perm below give the position of element (i, j) in such a block.)
 struct Layout {
     int D, K, DT, KT, DP, KP, DS, KS;
+    int QR;                 // length of each of the two noise diagonals at oqr: 64, or 128 in the second shape class
     size_t oFn, oBn, oGp;
     size_t oS0, oS2, oqr, ow0;
     size_t gains_total;     // doubles per replicate
@@ -48,19 +49,21 @@ __host__ __device__ static inline size_t pos_perm(int i, int j, int S) {
 __host__ __device__ static inline int cov_tiles(int rows) { const int RT = (rows + 7) >> 3; return RT * (RT + 1) / 2; }
 __host__ __device__ static inline size_t cov_stride(int rows) { return (size_t)cov_tiles(rows) * 64; }
 
-static inline int tiles16(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : 4); }
+static inline int tiles16(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 64 ? 4 : 8)); }
 
 static inline Layout make_layout(int D, int K) {
     Layout L;
     L.D = D; L.K = K;
     L.DT = tiles16(D); L.KT = tiles16(K);
+    if (L.DT > 4 || L.KT > 4) L.DT = L.KT = 8;      // the second shape class (k_big.hip): both dimensions padded to 128
+    L.QR = L.DT > 4 ? 128 : 64;
     L.DP = 16 * L.DT; L.KP = 16 * L.KT;
     L.DS = 4 * L.DT; L.KS = 4 * L.KT;
     size_t o = 0;
     size_t dd = (size_t)L.DT * L.DS * 64, dk = (size_t)L.DT * L.KS * 64;
     L.oFn = o; o += dd; L.oBn = o; o += dd; L.oGp = o; o += dk;
     size_t tdd = (size_t)L.DP * L.DP, tkd = (size_t)L.KP * L.DP;
-    L.oS0 = o; o += tdd; L.oS2 = o; o += tdd; L.oqr = o; o += 128; L.ow0 = o; o += L.DP;
+    L.oS0 = o; o += tdd; L.oS2 = o; o += tdd; L.oqr = o; o += 2 * (size_t)L.QR; L.ow0 = o; o += L.DP;
     L.gains_total = o;
     L.oSxx = 0; L.oSx1x = tdd; L.oSyx = 2 * tdd;
     L.stats_total = 2 * tdd + tkd;
@@ -83,6 +86,7 @@ struct KernelTimer {
 
 struct pyvb_lds {
     int device, N, T, D, K, noise;
+    bool big;                       // 64 < max(D, K) <= 128: the workgroup-per-replicate kernels of k_big.hip
     Layout L;
     hipStream_t stream;
     struct EventPair* pool; int pool_used;
@@ -155,6 +159,11 @@ int launch_resid(pyvb_lds* h, int which);     // 0 = Q, 1 = R
 int launch_noise(pyvb_lds* h, int which);
 int launch_elbo(pyvb_lds* h, hipStream_t stream = nullptr);                           // stream: the handle's main one unless given
 int launch_elbo_sum(pyvb_lds* h, double* out = nullptr, hipStream_t stream = nullptr);    // out: h->elbo_sum unless given
+// k_big.hip
+int launch_prep_big(pyvb_lds* h);
+int launch_sweep_big(pyvb_lds* h, int direction);
+int launch_stats_big(pyvb_lds* h);
+int launch_cols_big(pyvb_lds* h, int which, int c0, int c1, int fuse);
 // k_wishart.hip
 int launch_wexpect(pyvb_lds* h);                    // Qbar, Rbar, lnd from Q_w, R_w
 int launch_dense_pre(pyvb_lds* h);                  // QA, RC, trA, trC

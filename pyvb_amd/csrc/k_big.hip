@@ -1,0 +1,699 @@
+// The second shape class of the fused LDS path: 64 < max(D, K) <= 128 (both padded to 128 = eight 16-row tiles).
+// The reference has no size limit (gaussian.py:43-46); the kernels of k_sweep.hip / k_prep.hip / k_stats.hip / k_cols.hip keep one
+// 64 x 64 matrix per wavefront in registers and stop at 64.  Here a replicate is a WORKGROUP of four wavefronts:
+//
+//   k_sweep_big   wavefront w owns the row tiles 2w, 2w+1 (32 rows) of the recurrence matrices R, I as MFMA A operands in
+//                 registers (2 x 64 doubles per lane) and of G in LDS (32 KB per wavefront); the state of the 16 time segments
+//                 (128 x 16, the MFMA B operand) is exchanged through LDS once per step: every wavefront writes the two
+//                 accumulator tiles it has just formed -- accumulator layout = B-operand layout, as in k_sweep.hip -- and
+//                 reads the other six.  Same segmentation of the time axis, same warm-up from k_prep's contraction bound,
+//                 same boundary nodes.  Both sweeps compute all three products (no c_t cache, no fused Sxx).
+//   k_prep_big    one work matrix in LDS (128 x 130 doubles), intermediates in a per-replicate global scratch; the three
+//                 precisions inverted one after the other by the whole workgroup (8 x 8 tile per thread).
+//   k_stats_big   Sxx, Sx1x, Syx as three (replicate, chunk, kind) grids: a wavefront holds 2 x 8 accumulator tiles.
+//   k_cols_big    thread = row of the matrix; the Gauss-Seidel pass over the columns runs column by column (the rows decouple
+//                 under diagonal noise and diagonal column priors), <M> as [col][row] in LDS.
+// Reference methods as in the small kernels: Gaussian.update gaussian.py:102-123, Multiplication.pass_up_m1_m2 node.py:182-232,
+// hstack.pass_up_m1_m2 nodes_todo.py:43-62, Gamma / DiagonalGamma.update nodes_todo.py:130-138, :187-190.
+// Diagonal-Gamma and Gamma noise, fully observed outputs, no known entries: the other variants stay on the 64-wide kernels
+// (larger graphs of those kinds run node by node on the generic plan).
+#include "params.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define BDP 128     // padded dimension
+#define BDT 8       // 16-row tiles
+#define BDS 32      // k-steps of 4
+#define BLD 130     // row stride of the LDS work matrix (A-operand reads conflict free)
+
+// ======================================================================================================================
+// sweep
+// ======================================================================================================================
+struct BigSweepArgs {
+    const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
+    const double *A_mean, *C_mean;
+    double* trash;      // [N][512]
+    int N, T, D, K, dir;
+    Layout L;
+};
+
+// Xs[0].update() / Xs[T-1].update() by the whole workgroup, thread = row (k_sweep.hip: boundary_update).
+// nb(j): entry j of the one neighbour's mean.  vs: 128 doubles of LDS.  Every thread of the workgroup must call it.
+template <class NB>
+__device__ __forceinline__ double big_boundary(bool first, const double* g, const Layout& L, const double* Am, const double* Cm,
+                                               int D, int K, int tid, NB nb, const double* y, double* vs) {
+    const double* qb = g + L.oqr;
+    const double* rb = qb + BDP;
+    double v = 0.0;
+    if (tid < D) {
+        if (first) {
+            v = g[L.ow0 + tid];
+            for (int i = 0; i < D; ++i) v += Am[(size_t)i * D + tid] * (qb[i] * nb(i));
+        } else {
+            double s = 0.0;
+            for (int j = 0; j < D; ++j) s += Am[(size_t)tid * D + j] * nb(j);
+            v = qb[tid] * s;
+        }
+        for (int k = 0; k < K; ++k) v += Cm[(size_t)k * D + tid] * (rb[k] * y[k]);
+    }
+    if (tid < BDP) vs[tid] = v;
+    __syncthreads();
+    const double* S = g + (first ? L.oS0 : L.oS2);
+    double s = 0.0;
+    if (tid < D)
+        for (int j = 0; j < D; ++j) s += S[(size_t)j * BDP + tid] * vs[j];      // Sigma is symmetric
+    __syncthreads();
+    return s;
+}
+
+__global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
+    extern __shared__ double lds[];
+    double* gl = lds;                               // [4 waves][2 tiles][BDS][64]: G as A operands, this wavefront's rows
+    double* xbuf = gl + 4 * 2 * BDS * 64;           // [BDS][64]: the state of the 16 segments, B-operand order
+    double* xs = xbuf + BDS * 64;                   // [128] boundary state exchange
+    double* vs = xs + BDP;                          // [128] boundary scratch
+    const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int T = a.T, D = a.D, K = a.K;
+    const bool fwd = (a.dir == 0);
+    const int sgn = fwd ? 1 : -1;
+    const Layout& L = a.L;
+    const double* g = a.gains + (size_t)n * L.gains_total;
+    const double* Xo = a.Xold + (size_t)n * T * BDP;
+    double* Xn = a.Xnew + (size_t)n * T * BDP;
+    const double* Yn = a.Y + (size_t)n * T * K;
+    const bool yvec = (K & 1) == 0;
+
+    // ---- this wavefront's rows of the recurrence matrices
+    double rn[2][BDS], ip[2][BDS];
+    {
+        const double* Rn = g + (fwd ? L.oFn : L.oBn);
+        const double* Ip = g + (fwd ? L.oBn : L.oFn);
+        const double* Gp = g + L.oGp;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int s = 0; s < BDS; ++s) {
+                const size_t o = ((size_t)(2 * w + mm) * BDS + s) * 64 + lane;
+                rn[mm][s] = Rn[o];
+                ip[mm][s] = Ip[o];
+                gl[((w * 2 + mm) * BDS + s) * 64 + lane] = Gp[o];
+            }
+    }
+    const int Tint = T - 2;
+    const int J = a.warm[n * 2 + a.dir];
+    const int t_first = fwd ? 0 : T - 1, t_last = fwd ? T - 1 : 0;
+    const double* Am = a.A_mean + (size_t)n * D * D;
+    const double* Cm = a.C_mean + (size_t)n * K * D;
+
+    // ---- first boundary node: only the old neighbour
+    {
+        const double* xo = Xo + (size_t)(t_first + sgn) * BDP;
+        const double s = big_boundary(fwd, g, L, Am, Cm, D, K, tid, [&](int j) { return xo[xpos(j)]; }, Yn + (size_t)t_first * K, vs);
+        if (tid < BDP) {
+            Xn[(size_t)t_first * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
+            xs[tid] = (tid < D) ? s : 0.0;
+        }
+    }
+    __syncthreads();
+
+    if (Tint > 0) {
+        const int Lseg = (Tint + 15) >> 4;
+        const int cL = c * Lseg;
+        const int jc = -(J < cL ? J : cL);                                   // first loop index of this column
+        const int jstart = -((J < 15 * Lseg) ? J : 15 * Lseg);               // of the workgroup
+        // state of the 16 segments as B operands: x[m][r] = row 16m + 4r + q of column c
+        d4 x[BDT];
+#pragma unroll
+        for (int m = 0; m < BDT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[m][r] = (jc == -cL) ? xs[16 * m + 4 * r + q] : 0.0;
+        const int tbase = fwd ? (1 + cL) : (T - 2 - cL);
+        const int tsafe = fwd ? 1 : T - 2;
+        auto active = [&](int j) { int tt = cL + j; return j >= jc && j < Lseg && tt < Tint; };
+        double* const trash = a.trash + (size_t)n * 512;
+        for (int j = jstart; j < Lseg; ++j) {
+            const bool act = active(j);
+            const int trow = act ? tbase + sgn * j : tsafe;
+            // operands of this step: y_t (permuted k order, as k_sweep.hip) and the old neighbour mean
+            const double* yp = Yn + (size_t)trow * K;
+            const double* op = Xo + (size_t)(trow + sgn) * BDP;
+            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+            // G y_t
+#pragma unroll 4
+            for (int i = 0; i < BDS / 2; ++i) {
+                const int d0 = 8 * i + 2 * q;
+                d2 yv;
+                if (yvec && d0 + 1 < K) yv = *reinterpret_cast<const d2*>(yp + d0);
+                else { yv[0] = yp[d0 < K ? d0 : K - 1]; yv[1] = yp[d0 + 1 < K ? d0 + 1 : K - 1]; }      // padded k meet zero gains
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+                        acc[mm] = MFMA(gl[((w * 2 + mm) * BDS + 2 * i + h2) * 64 + lane], yv[h2], acc[mm]);
+            }
+            // R mu_{t-dir} (new): the segments' state
+#pragma unroll
+            for (int s = 0; s < BDS; ++s)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(rn[mm][s], x[s >> 2][s & 3], acc[mm]);
+            // I mu_{t+dir} (old)
+#pragma unroll
+            for (int m = 0; m < BDT; ++m) {
+                const d4 mo = *reinterpret_cast<const d4*>(op + (m * 4 + q) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(ip[mm][4 * m + r], mo[r], acc[mm]);
+            }
+            // this wavefront's rows of the new state: kept where the column is active, then shared
+            double* out = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * BDP : trash;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = 2 * w + mm;
+                d4 nx;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nx[r] = act ? acc[mm][r] : x[m][r];
+                *reinterpret_cast<d4*>(out + (m * 4 + q) * 4) = nx;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xbuf[(4 * m + r) * 64 + lane] = nx[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < BDT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[m][r] = xbuf[(4 * m + r) * 64 + lane];
+            __syncthreads();
+        }
+        // the column that holds the last interior node hands its state to the closing boundary step
+        const int clast = (Tint - 1) / Lseg;
+        if (w == 0 && c == clast) {
+#pragma unroll
+            for (int m = 0; m < BDT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs[16 * m + 4 * r + q] = x[m][r];
+        }
+        __syncthreads();
+    }
+    // ---- closing boundary node: only the new neighbour
+    {
+        const double s = big_boundary(!fwd, g, L, Am, Cm, D, K, tid, [&](int j) { return xs[j]; }, Yn + (size_t)t_last * K, vs);
+        if (tid < BDP) Xn[(size_t)t_last * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
+    }
+}
+
+int launch_sweep_big(pyvb_lds* h, int direction) {
+    BigSweepArgs a;
+    a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
+    a.A_mean = h->A_mean; a.C_mean = h->C_mean; a.trash = h->trash;
+    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
+    const size_t lds = ((size_t)4 * 2 * BDS * 64 + (size_t)BDS * 64 + 2 * BDP) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_sweep_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    {
+        TimedLaunch tl(h, direction == PYVB_FORWARD ? PYVB_K_SWEEP_FWD : PYVB_K_SWEEP_BWD);
+        hipLaunchKernelGGL(k_sweep_big, dim3(h->N), dim3(256), lds, h->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+// ======================================================================================================================
+// statistics
+// ======================================================================================================================
+struct BigStatsArgs {
+    const double* X; const double* Y; double* part; const double* zeros;     // zeros: 128 doubles
+    int N, T, D, K, nchunk, chunk_len;
+    Layout L;
+};
+
+// kind (blockIdx.z): 0  Sxx = sum_t mu_t mu_t^T;  1  Sx1x = sum_t mu_{t+1} mu_t^T;  2  Syx = sum_t y_t mu_t^T.
+// T is the MFMA K dimension (k_stats.hip); wavefront w forms row tiles 2w, 2w+1 against all eight column tiles.
+__global__ void __launch_bounds__(256) k_stats_big(BigStatsArgs a) {
+    const int ch = blockIdx.x, n = blockIdx.y, kind = blockIdx.z;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int T = a.T, K = a.K;
+    const double* X = a.X + (size_t)n * T * BDP;
+    const double* Y = a.Y + (size_t)n * T * K;
+    const double* Z = a.zeros;
+    const int t0 = ch * a.chunk_len;
+    const int t1 = (t0 + a.chunk_len < T) ? t0 + a.chunk_len : T;
+    double* P = a.part + ((size_t)n * a.nchunk + ch) * a.L.stats_total + (kind == 0 ? a.L.oSxx : (kind == 1 ? a.L.oSx1x : a.L.oSyx));
+    int xoff[BDT], aoff[2];
+#pragma unroll
+    for (int m = 0; m < BDT; ++m) xoff[m] = xpos(16 * m + r);
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+        const int dim = 16 * (2 * w + mm) + r;
+        aoff[mm] = kind == 2 ? (dim < K ? dim : -1) : xpos(dim);
+    }
+    d4 acc[2][BDT];
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int k = 0; k < BDT; ++k) acc[mm][k] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += 4) {
+        const int t = tb + q;
+        const double* xb = t < t1 ? X + (size_t)t * BDP : Z;
+        const double* ap;
+        if (kind == 0) ap = xb;
+        else if (kind == 1) ap = (t < t1 && t + 1 < T) ? X + (size_t)(t + 1) * BDP : Z;
+        else ap = t < t1 ? Y + (size_t)t * K : Z;
+        double av[2], bv[BDT];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) av[mm] = aoff[mm] >= 0 ? ap[aoff[mm]] : 0.0;
+#pragma unroll
+        for (int k = 0; k < BDT; ++k) bv[k] = xb[xoff[k]];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int k = 0; k < BDT; ++k) acc[mm][k] = MFMA(av[mm], bv[k], acc[mm][k]);
+    }
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int k = 0; k < BDT; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P[(size_t)(16 * (2 * w + mm) + 4 * e + q) * BDP + 16 * k + r] = acc[mm][k][e];
+}
+
+int launch_stats_big(pyvb_lds* h) {
+    BigStatsArgs a;
+    a.X = h->X[h->cur]; a.Y = h->Y; a.part = h->stats; a.zeros = h->zeros;
+    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.nchunk = h->nchunk; a.chunk_len = h->chunk_len; a.L = h->L;
+    {
+        TimedLaunch tl(h, PYVB_K_STATS);
+        hipLaunchKernelGGL(k_stats_big, dim3(h->nchunk, h->N, 3), dim3(256), 0, h->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+// ======================================================================================================================
+// prep
+// ======================================================================================================================
+struct BigPrepArgs {
+    const double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *x0_mean, *x0_prec;
+    double *Sigma, *qld, *gains, *scratch;      // scratch: [N][2][128][128]
+    int *warm, *status;
+    int N, T, D, K, noise;
+    Layout L;
+};
+
+// C = A * B, 128 x 128 x 128 on the matrix cores; wavefront w owns row tiles w and w + 4; a_at(i, k), b_at(k, j) fetch
+// operand elements, store(i, j, v) consumes results
+template <class FA, class FB, class FS>
+__device__ __forceinline__ void mm128(int wave, int lane, FA a_at, FB b_at, FS store) {
+    const int r = lane & 15, q = lane >> 4;
+    for (int m = wave; m < BDT; m += 4) {
+        d4 acc[BDT];
+#pragma unroll
+        for (int nn = 0; nn < BDT; ++nn) acc[nn] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+        for (int s = 0; s < BDS; ++s) {
+            const double av = a_at(16 * m + r, 4 * s + q);
+#pragma unroll
+            for (int nn = 0; nn < BDT; ++nn) acc[nn] = MFMA(av, b_at(4 * s + q, 16 * nn + r), acc[nn]);
+        }
+#pragma unroll
+        for (int nn = 0; nn < BDT; ++nn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store(16 * m + 4 * e + q, 16 * nn + r, acc[nn][e]);
+    }
+}
+
+// W <- W * W in place (LDS, stride BLD): both row tiles of every wavefront into registers, a barrier, then out
+__device__ static void square128(double* W, int wave, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    d4 acc[2][BDT];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const int m = wave + 4 * h2;
+#pragma unroll
+        for (int nn = 0; nn < BDT; ++nn) acc[h2][nn] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+        for (int s = 0; s < BDS; ++s) {
+            const double av = W[(16 * m + r) * BLD + 4 * s + q];
+#pragma unroll
+            for (int nn = 0; nn < BDT; ++nn) acc[h2][nn] = MFMA(av, W[(4 * s + q) * BLD + 16 * nn + r], acc[h2][nn]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int nn = 0; nn < BDT; ++nn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) W[(16 * (wave + 4 * h2) + 4 * e + q) * BLD + 16 * nn + r] = acc[h2][nn][e];
+    __syncthreads();
+}
+
+// max_i sum_j |W_ij| over the 128 x 128 matrix: two threads per row
+__device__ static double inf_norm128(const double* W, int tid, double* red) {
+    const int row = tid >> 1, part = tid & 1;
+    double s = 0.0;
+#pragma unroll 8
+    for (int u = 0; u < 64; ++u) s += fabs(W[row * BLD + 64 * part + u]);
+    s += __shfl_xor(s, 1, 64);
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) s = fmax(s, __shfl_xor(s, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    return m;
+}
+
+// k_prep.hip: warmup_length, for the 128 x 128 recurrence matrix in W (clobbered)
+__device__ static int warmup128(double* W, int tid, double* red) {
+    const double lntol = -41.4465316738928;   // ln(1e-18)
+    const int wave = tid >> 6, lane = tid & 63;
+    double l2 = 1.0, l3 = 1.0, l4 = 1.0, l5 = 1.0;
+    for (int k = 1; k <= 5; ++k) {
+        square128(W, wave, lane);
+        if (k >= 2) {
+            const double nrm = inf_norm128(W, tid, red);
+            const double l = nrm < 1.0 ? ((nrm > 0.0) ? log(nrm) : -1e300) : 1.0;
+            if (k == 2) l2 = l; else if (k == 3) l3 = l; else if (k == 4) l4 = l; else l5 = l;
+        }
+    }
+    int best = 1 << 30;
+    if (tid == 0) {
+        for (int d = 0; d <= 16; ++d)
+            for (int abc = 0; abc < 8; ++abc) {
+                const int a = abc & 1, b = (abc >> 1) & 1, c = abc >> 2;
+                if ((a && l2 > 0.0) || (b && l3 > 0.0) || (c && l4 > 0.0) || (d && l5 > 0.0)) continue;
+                const double bound = (a ? l2 : 0.0) + (b ? l3 : 0.0) + (c ? l4 : 0.0) + (d ? d * l5 : 0.0);
+                const int J = 4 * a + 8 * b + 16 * c + 32 * d;
+                if (J > 0 && bound <= lntol && J < best) best = J;
+            }
+    }
+    return best;
+}
+
+// Inverse of the symmetric positive definite matrix held as 8 x 8 tiles by the 16 x 16 threads of the workgroup (thread
+// (a = tid / 16, b = tid % 16) owns elements (8a + ra, 8b + cb)), Gauss-Jordan without pivoting as gj.h; rc: [2][264] doubles
+// of LDS (row 128, column 128, 1/pivot), pivs: [128].
+#define GJB_BUF 264
+__device__ static void gj_wg128(double (&v)[8][8], int D, int tid, double* rc, double* pivs) {
+    const int a = tid >> 4, b = tid & 15;
+    if (a == 0) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) rc[8 * b + cb] = v[0][cb];
+    }
+    if (b == 0) {
+#pragma unroll
+        for (int ra = 0; ra < 8; ++ra) rc[128 + 8 * a + ra] = v[ra][0];
+    }
+    if (tid == 0) rc[256] = 1.0 / v[0][0];
+    int cur = 0;
+    for (int P = 0; 8 * P < D; ++P) {
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int p = 8 * P + pp;
+            if (p >= D) continue;                                   // block-uniform
+            const int P1 = (pp == 7) ? P + 1 : P, q1 = (pp + 1) & 7;
+            __syncthreads();
+            const double* row = rc + cur * GJB_BUF;
+            const double* col = row + 128;
+            double* nrow = rc + (cur ^ 1) * GJB_BUF;
+            double* ncol = nrow + 128;
+            const double d = row[256];
+            if (tid == 0) pivs[p] = row[p];
+            double rj[8], ci[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { rj[k] = row[8 * b + k] * d; ci[k] = col[8 * a + k]; }
+#pragma unroll
+            for (int ra = 0; ra < 8; ++ra)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) v[ra][cb] = __builtin_fma(-ci[ra], rj[cb], v[ra][cb]);
+            if (b == P) {
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) v[ra][pp] = -ci[ra] * d;
+            }
+            if (a == P) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) v[pp][cb] = (b == P && cb == pp) ? d : rj[cb];
+            }
+            if (a == P1) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) nrow[8 * b + cb] = v[q1][cb];
+            }
+            if (b == P1) {
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) ncol[8 * a + ra] = v[ra][q1];
+            }
+            if (a == P1 && b == P1) nrow[256] = 1.0 / v[q1][q1];
+            cur ^= 1;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
+    extern __shared__ double lds[];
+    double* Pm = lds;                       // [128][BLD]
+    double* qbar = Pm + BDP * BLD;          // [128]
+    double* rbar = qbar + BDP;
+    double* rowp = rbar + BDP;              // tr(S'_i <R>), later scratch of the norms
+    double* colp = rowp + BDP;              // tr(S_i <Q>)
+    double* gjrc = colp + BDP;              // [2][GJB_BUF]
+    double* pivs = gjrc + 2 * GJB_BUF;      // [128]
+    const int n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
+    const int wave = tid >> 6, lane = tid & 63;
+    const Layout& L = a.L;
+    const double* Am = a.A_mean + (size_t)n * D * D;
+    const double* Av = a.A_var + (size_t)n * D * D;
+    const double* Cm = a.C_mean + (size_t)n * K * D;
+    const double* Cv = a.C_var + (size_t)n * D * K;
+    double* g = a.gains + (size_t)n * L.gains_total;
+    double* S1 = a.scratch + (size_t)n * 2 * BDP * BDP;     // M_C, then F (zero padded)
+    if (tid < BDP) {
+        qbar[tid] = tid < D ? a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid] : 0.0;
+        rbar[tid] = tid < K ? a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid] : 0.0;
+    }
+    auto A_at = [&](int i, int j) { const double v = Am[(size_t)(i < D ? i : D - 1) * D + (j < D ? j : D - 1)]; return (i < D && j < D) ? v : 0.0; };
+    auto C_at = [&](int k, int j) { const double v = Cm[(size_t)(k < K ? k : K - 1) * D + (j < D ? j : D - 1)]; return (k < K && j < D) ? v : 0.0; };
+    __syncthreads();
+    if (tid < BDP) {        // traces of the column covariances against the noise expectations (diagonal of node.py:223-227)
+        double tc = 0.0, ta = 0.0;
+        if (tid < D) {
+            for (int k = 0; k < K; ++k) tc += Cv[(size_t)tid * K + k] * rbar[k];
+            for (int k = 0; k < D; ++k) ta += Av[(size_t)tid * D + k] * qbar[k];
+        }
+        rowp[tid] = tc; colp[tid] = ta;
+    }
+    __syncthreads();
+    // <C^T R C> -> S1;  <C^T R C> + <A^T Q A> -> Pm        (node.py:213-227)
+    mm128(wave, lane, [&](int i, int k) { return C_at(k, i) * rbar[k]; }, [&](int k, int j) { return C_at(k, j); },
+          [&](int i, int j, double v) { S1[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? rowp[i] : 0.0) : 0.0; });
+    mm128(wave, lane, [&](int i, int k) { return A_at(k, i) * qbar[k]; }, [&](int k, int j) { return A_at(k, j); },
+          [&](int i, int j, double v) { Pm[i * BLD + j] = (i < D && j < D) ? S1[(size_t)i * BDP + j] + v + (i == j ? colp[i] : 0.0) : 0.0; });
+    __syncthreads();
+
+    // the three posterior precisions (gaussian.py:117), inverted one after the other (qcov, :118-119; q_ln_det, :120)
+    const int ta = tid >> 4, tb = tid & 15;
+    for (int cc = 0; cc < 3; ++cc) {
+        const int c = cc == 0 ? 0 : (cc == 1 ? 2 : 1);             // the interior class last: its inverse stays in Pm
+        double v[8][8];
+#pragma unroll
+        for (int ra = 0; ra < 8; ++ra)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const int i = 8 * ta + ra, j = 8 * tb + cb;
+                const bool in = i < D && j < D;
+                const double qd = (in && i == j) ? qbar[i] : 0.0;
+                const double pad = (!in && i == j) ? 1.0 : 0.0;
+                double x;
+                if (c == 0) x = (in ? a.x0_prec[(size_t)i * D + j] : 0.0) + Pm[i * BLD + j];
+                else if (c == 1) x = qd + Pm[i * BLD + j];
+                else x = qd + S1[(size_t)i * BDP + j];
+                v[ra][cb] = x + pad;
+            }
+        __syncthreads();
+        gj_wg128(v, D, tid, gjrc, pivs);
+        if (tid < 64) {
+            double lp = 0.0;
+            for (int k = tid; k < D; k += 64) {
+                const double piv = pivs[k];
+                if (!(piv > 0.0)) atomicOr(a.status, 1);
+                lp += log(piv);
+            }
+            lp = wave_sum(lp);
+            if (tid == 0) a.qld[(size_t)n * 3 + c] = 0.5 / (0.5 * lp);
+        }
+#pragma unroll
+        for (int ra = 0; ra < 8; ++ra)
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const int i = 8 * ta + ra, j = 8 * tb + cb;
+                const bool in = i < D && j < D;
+                if (in) a.Sigma[((size_t)n * 3 + c) * D * D + (size_t)i * D + j] = v[ra][cb];
+                if (c == 0) g[L.oS0 + (size_t)i * BDP + j] = in ? v[ra][cb] : 0.0;
+                if (c == 2) g[L.oS2 + (size_t)i * BDP + j] = in ? v[ra][cb] : 0.0;
+                if (c == 1) Pm[i * BLD + j] = in ? v[ra][cb] : 0.0;          // every thread has read its tile of Pm: barriers inside gj_wg128
+            }
+        __syncthreads();
+    }
+    if (tid < BDP) {
+        g[L.oqr + tid] = qbar[tid]; g[L.oqr + BDP + tid] = rbar[tid];
+        double s = 0.0;        // L0 m0: the Constant mean parent of X_0 through its Constant precision
+        if (tid < D) for (int j = 0; j < D; ++j) s += a.x0_prec[(size_t)tid * D + j] * a.x0_mean[j];
+        g[L.ow0 + tid] = s;
+    }
+    // gains of the interior class: F = Sigma <Q><A>, B = Sigma <A>^T<Q>, G = Sigma <C>^T<R>
+    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return qbar[k] * A_at(k, j); },
+          [&](int i, int j, double v) { const bool in = i < D && j < D; g[L.oFn + pos_nat(i, j, BDS)] = in ? v : 0.0; S1[(size_t)i * BDP + j] = in ? v : 0.0; });
+    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return A_at(j, k) * qbar[j]; },
+          [&](int i, int j, double v) { g[L.oBn + pos_nat(i, j, BDS)] = (i < D && j < D) ? v : 0.0; });
+    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int l) { return C_at(l, k) * rbar[l]; },
+          [&](int i, int l, double v) { g[L.oGp + pos_perm(i, l, BDS)] = (i < D && l < K) ? v : 0.0; });
+    __syncthreads();
+    // warm-up lengths: powers of F, and of B^T (inf-norm of powers of B^T = 1-norm of powers of B)
+    for (int idx = tid; idx < BDP * BDP; idx += 256) Pm[(idx >> 7) * BLD + (idx & 127)] = S1[idx];
+    __syncthreads();
+    int Jw = warmup128(Pm, tid, rowp);
+    if (tid == 0) a.warm[n * 2 + 0] = Jw;
+    __syncthreads();
+    for (int idx = tid; idx < BDP * BDP; idx += 256) {
+        const int i = idx >> 7, j = idx & 127;
+        Pm[i * BLD + j] = g[L.oBn + pos_nat(j, i, BDS)];       // B^T (zero padded by the store above)
+    }
+    __syncthreads();
+    Jw = warmup128(Pm, tid, rowp);
+    if (tid == 0) a.warm[n * 2 + 1] = Jw;
+}
+
+int launch_prep_big(pyvb_lds* h) {
+    BigPrepArgs a;
+    a.A_mean = h->A_mean; a.A_var = h->A_var; a.C_mean = h->C_mean; a.C_var = h->C_var;
+    a.Q_a = h->Q_a; a.Q_b = h->Q_b; a.R_a = h->R_a; a.R_b = h->R_b;
+    a.x0_mean = h->pri.x0_mean; a.x0_prec = h->pri.x0_prec;
+    a.Sigma = h->Sigma_new; a.qld = h->qld_x_new; a.gains = h->gains; a.scratch = h->scratch;
+    a.warm = h->warm; a.status = h->status;
+    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L;
+    const size_t lds = ((size_t)BDP * BLD + 4 * BDP + 2 * GJB_BUF + BDP) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_prep_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    {
+        TimedLaunch tl(h, PYVB_K_PREP);
+        hipLaunchKernelGGL(k_prep_big, dim3(h->N), dim3(256), lds, h->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+// ======================================================================================================================
+// columns of A and C, residuals, noise update
+// ======================================================================================================================
+// sum over the (up to) 128 threads of the workgroup; red: 2 doubles of LDS
+__device__ __forceinline__ double bsum128(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1];
+}
+
+// k_cols.hip for up to 128 rows: thread = row, columns in order (Gauss-Seidel); fuse bit 0: residuals of the noise node,
+// bit 1: and its update
+__global__ void __launch_bounds__(128) k_cols_big(ParamArgs a) {
+    extern __shared__ double lds[];
+    double* Mb = lds;                   // [col][row], 128 x 128
+    double* gv = Mb + BDP * BDP;        // [128] row i of G
+    double* red = gv + BDP;             // [2]
+    const int WHICH = a.which0 + blockIdx.y, n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
+    const int rows = WHICH == 0 ? D : K;
+    double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
+    double* V = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
+    double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
+    const double* pm = WHICH == 0 ? a.pri.A_pm : a.pri.C_pm;    // [row][col]
+    const double* pp = WHICH == 0 ? a.pri.A_pp : a.pri.C_pp;    // [col][row]
+    const double* mo = a.mom + (size_t)n * mom_total(D, K);
+    const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
+    const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
+    const bool live = tid < rows;
+    const int lr = live ? tid : 0;
+    for (int idx = tid; idx < BDP * BDP; idx += 128) {
+        const int col = idx >> 7, row = idx & 127;
+        Mb[idx] = (row < rows && col < D) ? M[(size_t)row * D + col] : 0.0;
+    }
+    const double lam = live ? (WHICH == 0 ? a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid]
+                                          : a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid]) : 0.0;
+    __syncthreads();
+    for (int i = a.c0; i < a.c1; ++i) {
+        gv[tid] = tid < D ? G[(size_t)i * D + tid] : 0.0;
+        __syncthreads();
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < BDP; j += 2) {
+            acc0 = __builtin_fma(Mb[j * BDP + tid], (j != i) ? gv[j] : 0.0, acc0);
+            acc1 = __builtin_fma(Mb[(j + 1) * BDP + tid], (j + 1 != i) ? gv[j + 1] : 0.0, acc1);
+        }
+        const double p0 = pp[(size_t)i * rows + lr];
+        const double prec = p0 + lam * gv[i];                                           // qprec  gaussian.py:117
+        const double var = 1.0 / prec;                                                  // qcov   gaussian.py:118-119
+        const double val = (p0 * pm[(size_t)lr * D + i] + lam * (H[(size_t)lr * D + i] - (acc0 + acc1))) * var;   // qmu :122-123
+        const double lp = bsum128(live ? log(prec) : 0.0, red);                         // also the barrier before Mb / gv change
+        if (live) { Mb[i * BDP + tid] = val; V[(size_t)i * rows + tid] = var; }
+        if (tid == 0) qld[i] = 0.5 / (0.5 * lp);                                        // quirk Q1, gaussian.py:120
+    }
+    __syncthreads();
+    if (a.c0 < a.c1) {
+        for (int idx = tid; idx < rows * D; idx += 128) {
+            const int row = idx / D, col = idx % D;
+            if (col >= a.c0 && col < a.c1) M[idx] = Mb[col * BDP + row];
+        }
+    }
+    if (a.fuse & 1) {
+        // res[k] = 1/2 own[k] + 1/2 (sum_ij M[k,i] G[i,j] M[k,j] + sum_i var_i[k] G[i,i]) - sum_i H[k,i] M[k,i]   (node.py:260-271)
+        double e = 0.0, hm = 0.0;
+        for (int i = 0; i < D; ++i) {
+            __syncthreads();
+            gv[tid] = tid < D ? G[(size_t)i * D + tid] : 0.0;
+            __syncthreads();
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < BDP; j += 2) {
+                s0 = __builtin_fma(Mb[j * BDP + tid], gv[j], s0);
+                s1 = __builtin_fma(Mb[(j + 1) * BDP + tid], gv[j + 1], s1);
+            }
+            const double mi = Mb[i * BDP + tid];
+            e += mi * (s0 + s1) + V[(size_t)i * rows + lr] * gv[i];
+            hm += H[(size_t)lr * D + i] * mi;
+        }
+        const double own = WHICH == 0 ? mo[MOM_DP(D, K) + lr] : a.Syy[(size_t)n * K + lr];
+        double r = 0.5 * own + 0.5 * e - hm;
+        if (live) (WHICH == 0 ? a.resQ : a.resR)[(size_t)n * rows + tid] = r;
+        if (a.fuse & 2) {
+            const double* b0 = WHICH == 0 ? a.pri.Q_b0 : a.pri.R_b0;
+            double* qb = (WHICH == 0 ? a.Q_b : a.R_b) + (size_t)n * rows;
+            r = live ? r : 0.0;
+            if (a.noise == PYVB_NOISE_GAMMA) {
+                r = bsum128(r, red);
+                if (live) qb[tid] = b0[0] + r;
+            } else if (live) {
+                qb[tid] = b0[tid] + r;
+            }
+        }
+    }
+}
+
+int launch_cols_big(pyvb_lds* h, int which, int c0, int c1, int fuse) {
+    ParamArgs a = make_args(h);
+    a.c0 = c0; a.c1 = c1; a.which0 = which == 1 ? 1 : 0; a.fuse = fuse;
+    const size_t lds = ((size_t)BDP * BDP + BDP + 8) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_cols_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    TimedLaunch tl(h, PYVB_K_PARAMS);
+    hipLaunchKernelGGL(k_cols_big, dim3(h->N, which == 2 ? 2 : 1), dim3(128), lds, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}

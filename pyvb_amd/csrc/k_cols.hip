@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(64) k_cols(ParamArgs a) {
 // which: 0 = A / Q, 1 = C / R, 2 = both in one launch (they are independent given the statistics)
 // fuse: bit 0 = also the residuals of the noise node, bit 1 = and its update
 int launch_cols(pyvb_lds* h, int which, int c0, int c1, int fuse) {
+    if (h->big) return launch_cols_big(h, which, c0, c1, fuse);
     ParamArgs a = make_args(h);
     a.c0 = c0; a.c1 = c1; a.which0 = which == 1 ? 1 : 0; a.fuse = fuse;
     TimedLaunch tl(h, PYVB_K_PARAMS);

@@ -48,7 +48,22 @@ __global__ void __launch_bounds__(256) k_moments(ParamArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(64) k_noise(ParamArgs a) {
+// sum over the workgroup: one wavefront (lane = row or column, D, K <= 64), or two in the second shape class (k_big.hip)
+template <int NW>
+__device__ __forceinline__ double blk_sum(double v, double* red) {
+    v = wave_sum(v);
+    if constexpr (NW == 1) return v;
+    else {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1];
+    }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_noise(ParamArgs a) {
+    __shared__ double red[2];
     const int WHICH = a.which0 + blockIdx.y;
     const int n = blockIdx.x, lane = threadIdx.x;
     const int dim = WHICH == 0 ? a.D : a.K;
@@ -58,7 +73,7 @@ __global__ void __launch_bounds__(64) k_noise(ParamArgs a) {
     const bool live = lane < dim;
     double r = live ? res[lane] : 0.0;
     if (a.noise == PYVB_NOISE_GAMMA) {
-        r = wave_sum(r);                       // traces instead of diagonals  nodes_todo.py:138
+        r = blk_sum<NW>(r, red);               // traces instead of diagonals  nodes_todo.py:138
         if (live) qb[lane] = b0[0] + r;
     } else if (live) {
         qb[lane] = b0[lane] + r;               // nodes_todo.py:188-190
@@ -73,7 +88,9 @@ __device__ static double gamma_llb(double a0, double b0, double qa, double qb) {
     return ret;
 }
 
-__global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_elbo(ParamArgs a) {
+    __shared__ double red[2];
     const int n = blockIdx.x, lane = threadIdx.x, D = a.D, K = a.K, T = a.T;
     const double* S0 = a.Sigma + (size_t)n * 3 * D * D;
     const double* x0 = a.X + (size_t)n * T * a.L.DP;
@@ -92,9 +109,9 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
         if (a.noise == PYVB_NOISE_DIAGONAL_GAMMA) lr = gamma_llb(a.pri.R_a0[lane], a.pri.R_b0[lane], ra, rb);
         else if (lane == 0) lr = gamma_llb(a.pri.R_a0[0], a.pri.R_b0[0], ra, rb);
     }
-    const double lndQ = wave_sum(lnq), lndR = wave_sum(lnr);       // pass_down_lndet (quirk Q2)
-    const double trQ = wave_sum(rq), trR = wave_sum(rr);
-    const double LQ = wave_sum(lq), LR = wave_sum(lr);
+    const double lndQ = blk_sum<NW>(lnq, red), lndR = blk_sum<NW>(lnr, red);       // pass_down_lndet (quirk Q2)
+    const double trQ = blk_sum<NW>(rq, red), trR = blk_sum<NW>(rr, red);
+    const double LQ = blk_sum<NW>(lq, red), LR = blk_sum<NW>(lr, red);
     // --- X_0 against its Constant parents
     double e0 = 0.0;
     if (lane < D) {
@@ -106,7 +123,7 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
             e0 += a.pri.x0_prec[i * D + j] * ex;
         }
     }
-    e0 = wave_sum(e0);
+    e0 = blk_sum<NW>(e0, red);
     const double nint = (double)(T - 2);
     double LX = -0.5 * D * LN2PI + 0.5 * a.pri.x0_lndet - 0.5 * e0;
     LX += (double)(T - 1) * (-0.5 * D * LN2PI + 0.5 * lndQ) - trQ;
@@ -159,7 +176,7 @@ __global__ void __launch_bounds__(64) k_elbo(ParamArgs a) {
         lc = column(K, a.pri.C_pp, a.pri.C_pm, a.C_mean + (size_t)n * K * D, a.C_var + (size_t)n * D * K, a.pri.C_obs,
                     a.qld_C[(size_t)n * D + i], a.pri.C_pld[i]);
     }
-    const double LA = wave_sum(la), LC = wave_sum(lc);
+    const double LA = blk_sum<NW>(la, red), LC = blk_sum<NW>(lc, red);
     if (lane == 0) {
         double* o = a.elbo + (size_t)n * 6;
         o[0] = LX; o[1] = LY; o[2] = LA; o[3] = LC; o[4] = LQ; o[5] = LR;
@@ -228,7 +245,8 @@ int launch_noise(pyvb_lds* h, int which) {
     ParamArgs a = make_args(h);
     a.which0 = which == 1 ? 1 : 0;
     TimedLaunch tl(h, PYVB_K_PARAMS);
-    hipLaunchKernelGGL(k_noise, dim3(h->N, which == 2 ? 2 : 1), dim3(64), 0, h->stream, a);
+    if (h->big) hipLaunchKernelGGL(k_noise<2>, dim3(h->N, which == 2 ? 2 : 1), dim3(128), 0, h->stream, a);
+    else hipLaunchKernelGGL(k_noise<1>, dim3(h->N, which == 2 ? 2 : 1), dim3(64), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
@@ -237,7 +255,8 @@ int launch_elbo(pyvb_lds* h, hipStream_t stream) {
     ParamArgs a = make_args(h);
     if (!stream) stream = h->stream;
     TimedLaunch tl(h, PYVB_K_ELBO, stream);
-    hipLaunchKernelGGL(k_elbo, dim3(h->N), dim3(64), 0, stream, a);
+    if (h->big) hipLaunchKernelGGL(k_elbo<2>, dim3(h->N), dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL(k_elbo<1>, dim3(h->N), dim3(64), 0, stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

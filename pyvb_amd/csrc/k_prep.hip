@@ -370,6 +370,7 @@ static void launch_prep_t(pyvb_lds* h, const PrepArgs& a) {
 }
 
 int launch_prep(pyvb_lds* h) {
+    if (h->big) return launch_prep_big(h);
     PrepArgs a;
     a.A_mean = h->A_mean; a.A_var = h->A_var; a.C_mean = h->C_mean; a.C_var = h->C_var;
     a.Q_a = h->Q_a; a.Q_b = h->Q_b; a.R_a = h->R_a; a.R_b = h->R_b;

@@ -251,6 +251,7 @@ static void launch_stats_t(pyvb_lds* h, const StatsArgs& a, bool with_sxx) {
 }
 
 int launch_stats(pyvb_lds* h, bool with_sxx) {
+    if (h->big) return launch_stats_big(h);
     StatsArgs a;
     a.X = h->X[h->cur]; a.Y = h->Y; a.part = h->stats; a.zeros = h->zeros;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.nchunk = h->nchunk; a.chunk_len = h->chunk_len; a.L = h->L;

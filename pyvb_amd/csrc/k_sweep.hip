@@ -433,6 +433,14 @@ static int launch_sweep_t(pyvb_lds* h, const SweepArgs& a) {
 }
 
 int launch_sweep(pyvb_lds* h, int direction, bool keep_x) {
+    if (h->big) {       // both sweeps compute everything and write every state (k_big.hip): no c_t cache, no fused Sxx
+        int rc = launch_sweep_big(h, direction);
+        if (rc) return rc;
+        h->cur = 1 - h->cur;
+        h->sxx_valid = false;
+        h->u_valid = false;
+        return PYVB_OK;
+    }
     SweepArgs a;
     a.keep_x = (keep_x || direction != PYVB_FORWARD) ? 1 : 0;
     a.W = h->W;
@@ -466,8 +474,10 @@ int launch_sweep(pyvb_lds* h, int direction, bool keep_x) {
 // API layout [N][T][D] <-> internal layout [N][T][DP] (accumulator order, zero padded)
 struct PermArgs { const double* src; double* dst; size_t rows; int D, DP, to_internal; };
 __global__ void __launch_bounds__(256) k_permute(PermArgs a) {
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int d = threadIdx.x & 63;
+    // 64 threads per row, or 128 in the second shape class (DP = 128)
+    const int per = a.DP > 64 ? 128 : 64;
+    const size_t row = (size_t)blockIdx.x * (256 / per) + (threadIdx.x / per);
+    const int d = threadIdx.x % per;
     if (row >= a.rows || d >= a.DP) return;
     if (a.to_internal) a.dst[row * a.DP + xpos(d)] = (d < a.D) ? a.src[row * a.D + d] : 0.0;
     else if (d < a.D) a.dst[row * a.D + d] = a.src[row * a.DP + xpos(d)];
@@ -475,7 +485,8 @@ __global__ void __launch_bounds__(256) k_permute(PermArgs a) {
 
 int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal) {
     PermArgs a; a.src = src; a.dst = dst; a.rows = (size_t)h->N * h->T; a.D = h->D; a.DP = h->L.DP; a.to_internal = to_internal;
-    hipLaunchKernelGGL(k_permute, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, h->stream, a);
+    const size_t per_block = a.DP > 64 ? 2 : 4;
+    hipLaunchKernelGGL(k_permute, dim3((unsigned)((a.rows + per_block - 1) / per_block)), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

@@ -491,6 +491,9 @@ CASES = [
     ("knowns_d3k4_t50", 50, 3, 4, "diagonal_gamma", (1, 2, 4), 20249, True, True),
     ("missing_d3k4_t30", 30, 3, 4, "diagonal_gamma", (1, 3), 20250, True, False, True),
     ("missing_gamma_d2k5_t20", 20, 2, 5, "gamma", (1, 2), 20251, True, False, True),
+    # beyond one 64 x 64 tile set (the fused kernels' second shape class, D, K <= 128): one iteration, about an hour of the
+    # reference's D^5 tensor work
+    ("d80k80_t3", 3, 80, 80, "diagonal_gamma", (1,), 20252, False),
 ]
 
 
@@ -518,6 +521,6 @@ if __name__ == "__main__":
     for c in CASES:
         if sel and sel != ["small"] and c[0] not in sel:
             continue
-        if sel == ["small"] and c[2] >= 64:
+        if sel == ["small"] and c[2] >= 64:         # python tests/golden/make_golden.py d64k64_t4 d80k80_t3 for the slow ones
             continue
         run_case(ref, *c)

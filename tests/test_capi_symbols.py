@@ -31,7 +31,9 @@ def test_error_string_and_argument_checks_without_gpu():
     rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 1, 4, 4, 0)     # T = 1 is refused before any HIP call
     assert rc == _capi.E_ARG
     assert b"T must be" in _capi.lib.pyvb_last_error()
-    rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 10, 65, 4, 0)
+    rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 10, 129, 4, 0)        # D, K <= 128
+    assert rc == _capi.E_ARG
+    rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 10, 65, 4, _capi.NOISE_WISHART)     # Wishart noise: D, K <= 64
     assert rc == _capi.E_ARG
 
 

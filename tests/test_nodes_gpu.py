@@ -409,13 +409,15 @@ def test_the_example_exactly_as_the_reference_writes_it(name):
         assert abs(llb - float(z[tag + "llb"])) <= 1e-7 * abs(float(z[tag + "llb"]))
 
 
-def test_shapes_beyond_the_fused_kernels_run_node_by_node():
-    """D = 66 > 64: the fused LDS kernels hold one 64 x 64 matrix per wavefront, so the recogniser hands the graph to the generic
-    plan (no shape limit there); checked against the closed-form oracle, which has none either."""
-    from pyvb_amd import synth, generic
+@pytest.mark.parametrize("D,K,fused", [(66, 3, True), (130, 2, False)])
+def test_shapes_beyond_64(D, K, fused):
+    """D = 66: the recogniser binds the graph to the fused plan's second shape class (k_big.hip, D, K <= 128); D = 130: no fused
+    kernel takes it, the graph runs node by node on the generic plan (no shape limit there).  Both against the closed-form
+    oracle, which has none either."""
+    from pyvb_amd import synth, generic, _recognise
     from oracle import lds_closed_form as O
     G = _golden_module()
-    T, D, K = 4, 66, 3
+    T = 4
     Y, st0, pri = synth.make_problem(T, D, K, 1, seed=9)
     g = G.build_graph(__import__("pyvb_amd").nodes, Y[0], pri, st0)
     st = O.expand_state(st0, pri, T)
@@ -423,7 +425,7 @@ def test_shapes_beyond_the_fused_kernels_run_node_by_node():
         [x.update() for x in g["Xs"]]; [x.update() for x in reversed(g["Xs"])]
         [a.update() for a in g["As"]]; [c.update() for c in g["Cs"]]; g["Q"].update(); g["R"].update()
         O.iterate(st, pri, Y, with_elbo=False)
-    assert isinstance(g["Xs"][0]._plan, generic.GenericPlan)
+    assert isinstance(g["Xs"][0]._plan, _recognise.LDSPlan if fused else generic.GenericPlan)
     assert _rel(np.hstack([x.qmu for x in g["Xs"]]).T, st["X"][0]) < 1e-7
     assert _rel(np.hstack([a.qmu for a in g["As"]]), st["A_mean"][0]) < 1e-7
     assert _rel(g["R"].qb, st["R_b"][0]) < 1e-7
