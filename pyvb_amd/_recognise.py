@@ -422,8 +422,6 @@ def describe(start):
     if kind == "diagonal_gamma":
         pri.update(Q_a0=Q.a0s, Q_b0=Q.b0s, R_a0=R.a0s, R_b0=R.b0s)
     elif kind == "wishart":
-        if any(c.observed or c.partially_observed for c in As + Cs):
-            _fail("known entries of the matrices together with Wishart noise")
         pri.update(Q_a0=float(Q.v0), Q_b0=np.array(Q.w0, dtype=float), R_a0=float(R.v0), R_b0=np.array(R.w0, dtype=float))
     else:
         pri.update(Q_a0=float(Q.a0), Q_b0=float(Q.b0), R_a0=float(R.a0), R_b0=float(R.b0))

@@ -168,6 +168,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
         TRY(dev_alloc(&h->SyyF, n * K * K));
         TRY(dev_alloc(&h->RQ, n * D * D)); TRY(dev_alloc(&h->RR, n * K * K));
         TRY(dev_alloc(&h->SG, n * 2 * 64 * 64));
+        TRY(dev_alloc(&h->ldm, n * 2 * D));
     }
     TRYHIP(hipMemset(h->pri.A_obs, 0xFF, ((size_t)D * D + (size_t)K * D) * sizeof(double)));     // all-ones bytes = NaN = nothing observed
     h->fresh = (unsigned char*)calloc(T, 1);
@@ -198,7 +199,7 @@ int pyvb_lds_destroy(pyvb_lds* h) {
     double* bufs[] = {h->Y, h->Syy, h->X[0], h->X[1], h->A_mean, h->A_var, h->C_mean, h->C_var, h->Q_a, h->Q_b, h->R_a, h->R_b,
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
                       h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->sxx, h->U,
-                      h->Q_w, h->R_w, h->Qbar, h->Rbar, h->lnd, h->QA, h->RC, h->trA, h->trC, h->A_cov, h->C_cov, h->SyyF, h->RQ, h->RR, h->SG,
+                      h->Q_w, h->R_w, h->Qbar, h->Rbar, h->lnd, h->QA, h->RC, h->trA, h->trC, h->A_cov, h->C_cov, h->SyyF, h->RQ, h->RR, h->SG, h->ldm,
                       h->Yobs, h->Yvar, h->Yqld, h->Yent};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
@@ -416,12 +417,15 @@ int pyvb_lds_get_column_cov(pyvb_lds* h, double* A_cov, double* C_cov) {
 
 int pyvb_lds_set_column_observations(pyvb_lds* h, const double* A_obs, const double* C_obs) {
     ENTER(h);
-    if (h->dense) { pyvb_set_error("known entries of A / C together with Wishart noise are not supported"); return PYVB_E_UNSUPPORTED; }
     if (h->big) { pyvb_set_error("known entries of A / C with D or K above 64 is not served by the fused kernels"); return PYVB_E_UNSUPPORTED; }
     int rc;
     if ((rc = h2d(h, h->pri.A_obs, A_obs, (size_t)h->D * h->D))) return rc;
     if ((rc = h2d(h, h->pri.C_obs, C_obs, (size_t)h->K * h->D))) return rc;
     if ((rc = launch_observe(h))) return rc;
+    if (h->dense) {
+        if ((rc = launch_cov_observe(h))) return rc;
+        h->sg_valid[0] = h->sg_valid[1] = false;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     params_changed(h);
     h->resQ_valid = h->resR_valid = false;

@@ -132,6 +132,7 @@ struct pyvb_lds {
     double *SyyF;                   // [N][K][K] sum_t y y^T
     double *RQ, *RR;                // [N][D][D], [N][K][K]: sum over children of 1/2<xx^T> + 1/2<mu mu^T> - <x><mu>^T
     bool expect_valid;              // Qbar, Rbar, lnd belong to the current Q_w, R_w
+    double *ldm;                    // [N][2][D] ln det of the covariance of the unknown entries of partially known columns of A / C
     double *SG; bool sg_valid[2];   // [N][2][64][64] sum_i G[i,i] S_i over the columns of A / C (k_cols_wishart); valid while neither the
                                     // covariances nor the statistics have changed since
     // ---- outputs with missing entries (k_missing.hip); allocated when set_observations sees NaN
@@ -173,6 +174,7 @@ int launch_syy_full(pyvb_lds* h);
 int launch_elbo_dense(pyvb_lds* h, hipStream_t stream = nullptr);
 int launch_colvar_to_cov(pyvb_lds* h);              // A_var/C_var (diagonals) -> A_cov/C_cov
 int launch_cov_to_colvar(pyvb_lds* h);              // and back
+int launch_cov_observe(pyvb_lds* h);                // zero covariance of the fully known columns
 int launch_cov_convert(pyvb_lds* h, int which, double* dense, int n0, int count, int to_packed);   // dense [count][D][rows][rows] (device) <-> the tiles of replicates n0..
 // k_missing.hip
 int launch_missing_init(pyvb_lds* h, const double* Yq0, const double* Yrowvar0);     // device pointers or null

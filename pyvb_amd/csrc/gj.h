@@ -158,3 +158,50 @@ __device__ static void gj_wave(double (&v)[8][8], int D, int lane, double* rc, d
     }
     gjw_sync();
 }
+
+// The same step applied once more to the pivots in `mask` (bit p set) of a matrix that gj_wave has already inverted.  The step
+// is an exchange operator (an involution): exchanging back the indices o of the mask leaves, for the others (u),
+//   block [u, u] = inv(P_uu),   block [u, o] = inv(P_uu) P_uo
+// of the ORIGINAL matrix P -- the conditional covariance and the regression of a Gaussian conditioned on the entries o
+// (gaussian.py:125-134), and sum_o ln(pivot) + ln det P = ln det P_uu.  The pivots need not be consecutive, so every step
+// publishes its own row, column and reciprocal first (two wave-level syncs per step); pivs2 [64] gets the pivots met.
+__device__ static void gj_wave_subset(double (&v)[8][8], unsigned long long mask, int lane, double* rc, double* pivs2) {
+    const int a = lane >> 3, b = lane & 7;
+    for (int P = 0; P < 8; ++P) {
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int p = 8 * P + pp;
+            if (!((mask >> p) & 1ull)) continue;                // wave-uniform
+            double* row = rc;
+            double* col = rc + 64;
+            gjw_sync();
+            if (a == P) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) row[8 * b + cb] = v[pp][cb];
+            }
+            if (b == P) {
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) col[8 * a + ra] = v[ra][pp];
+            }
+            if (a == P && b == P) { row[128] = gjw_recip(v[pp][pp]); pivs2[p] = v[pp][pp]; }
+            gjw_sync();
+            const double d = row[128];
+            double rj[8], ci[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { rj[k] = row[8 * b + k] * d; ci[k] = col[8 * a + k]; }
+#pragma unroll
+            for (int ra = 0; ra < 8; ++ra)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) v[ra][cb] = __builtin_fma(-ci[ra], rj[cb], v[ra][cb]);
+            if (b == P) {
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) v[ra][pp] = -ci[ra] * d;
+            }
+            if (a == P) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) v[pp][cb] = (b == P && cb == pp) ? d : rj[cb];
+            }
+        }
+    }
+    gjw_sync();
+}

@@ -39,6 +39,7 @@ __device__ __forceinline__ void cov_tile_ab(int rows, int t, int& A, int& B) {
 
 struct WArgs {
     double *Q_w, *R_w, *Qbar, *Rbar, *lnd, *QA, *RC, *trA, *trC, *A_cov, *C_cov, *RQ, *RR, *SyyF;
+    double* ldm;        // [N][2][D]: ln det of the covariance of the UNKNOWN entries of a column that has known ones (gaussian.py:150)
     double* SG;         // [N][2][64][64]-slots holding [rows][rows]: sum_i G[i,i] S_i of A's / C's columns (k_cols_wishart), or null: k_wresid sums the covariances itself
     const double *Q_a, *R_a;
     double *A_mean, *A_var, *C_mean, *C_var, *qld_A, *qld_C;
@@ -59,7 +60,7 @@ static WArgs make_wargs(pyvb_lds* h) {
     a.mom = h->mom; a.X = h->X[h->cur]; a.Sigma = h->Sigma; a.Y = h->Y; a.qld_x = h->qld_x; a.elbo = h->elbo;
     a.pri = h->pri; a.status = h->status;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.DP = h->L.DP;
-    a.which0 = 0; a.c0 = 0; a.c1 = h->D; a.update = 0; a.SG = nullptr;
+    a.which0 = 0; a.c0 = 0; a.c1 = h->D; a.update = 0; a.SG = nullptr; a.ldm = h->ldm;
     return a;
 }
 
@@ -161,6 +162,12 @@ __global__ void __launch_bounds__(256) k_dense_pre(WArgs a) {
 // with <M> and E[Lambda] in LDS and qcov_i still in its registers -- no covariance is read back from memory -- and adds
 // G[i,i] qcov_i to the running sum the noise update needs (Multiplication.pass_down_ExxT, node.py:260-271: sum_i S_i G_ii),
 // kept in LDS as the 36 upper 8 x 8 tiles; the turns are in column order, so the sum is formed in a fixed order.
+// Known entries of a column (As[i].observe with NaN, examples/LDS_knowns_in_A.py:73-74; gaussian.py:125-134): conditioning
+// N(qmu, qcov) on them leaves, for the unknown entries u and the known ones o, qcov_uu = inv(P_uu) and
+// qmu_u = inv(P_uu) (w_u - P_uo value_o) with P the precision of the unconditioned update and w its weighted mean.  After the
+// full inversion (whose pivots give q_ln_det, as in the reference) the elimination step is applied once more to the pivots
+// in o (gj_wave_subset): that exchanges them back and leaves inv(P_uu) and inv(P_uu) P_uo in place; the known entries are
+// pinned, their rows and columns of the covariance zero.
 // Against round 2's three kernels (all inversions; then a one-wavefront chain per matrix re-reading every covariance; then the
 // loop over the columns in k_wresid re-reading them again) this saves two passes over the column covariances
 // (profiles/r03/wishart_*).
@@ -172,7 +179,7 @@ __global__ void __launch_bounds__(64 * CW_WAVES) k_cols_wishart(WArgs a) {
     __shared__ double gjbuf[CW_WAVES * (2 * GJW_BUF + 64)];
     __shared__ double gv[64], rvv[64], wvv[64];
     __shared__ int turn, turn2;                 // chain steps done / sums done: the column (counted from c0) whose turn it is
-    __shared__ double pre[CW_WAVES][3][64];     // per wavefront: G[i,:], H[:,i], prior_prec_i prior_mean_i of its column, fetched ahead of the chain
+    __shared__ double pre[CW_WAVES][4][64];     // per wavefront: G[i,:], H[:,i], prior_prec_i prior_mean_i, known values (NaN: unknown) of its column, fetched ahead of the chain
     const int WHICH = a.which0 + blockIdx.y, n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
     const int wv = tid >> 6, lane = tid & 63;
     const int rows = WHICH == 0 ? D : K;
@@ -183,9 +190,11 @@ __global__ void __launch_bounds__(64 * CW_WAVES) k_cols_wishart(WArgs a) {
     const double* mo = a.mom + (size_t)n * mom_total(D, K);
     const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
     const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
+    const double* obs = WHICH == 0 ? a.pri.A_obs : a.pri.C_obs; // [row][col], NaN = not known
     double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * cov_stride(rows);
     double* var = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
     double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
+    double* ldm = a.ldm + ((size_t)n * 2 + WHICH) * D;
     const int RT = (rows + 7) >> 3;
     for (int idx = tid; idx < 64 * 64; idx += 64 * CW_WAVES) {
         const int k = idx & 63, l = idx >> 6;
@@ -211,6 +220,9 @@ __global__ void __launch_bounds__(64 * CW_WAVES) k_cols_wishart(WArgs a) {
             pre[wv][0][lane] = lane < D ? G[(size_t)i * D + lane] : 0.0;
             pre[wv][1][lane] = lane < rows ? H[(size_t)lane * D + i] : 0.0;
             pre[wv][2][lane] = lane < rows ? pp[(size_t)i * rows + lane] * pm[(size_t)lane * D + i] : 0.0;
+            const double ob = lane < rows ? obs[(size_t)lane * D + i] : __builtin_nan("");
+            pre[wv][3][lane] = ob;
+            const unsigned long long kmask = __ballot(ob == ob);        // bit k: entry k of the column is known (wave-uniform)
 #pragma unroll
             for (int ra = 0; ra < 8; ++ra) {
                 const int k = 8 * ta + ra;
@@ -230,17 +242,29 @@ __global__ void __launch_bounds__(64 * CW_WAVES) k_cols_wishart(WArgs a) {
                 lp = log(piv);
             }
             lp = wave_sum(lp);
-            if (lane == 0) qld[i] = 0.5 / (0.5 * lp);
+            const unsigned long long allrows = rows == 64 ? ~0ull : ((1ull << rows) - 1ull);
+            if (lane == 0 && kmask != allrows) qld[i] = 0.5 / (0.5 * lp);      // q_ln_det, gaussian.py:120 (quirk Q1): of the whole precision
+            bool rk[8], ck[8];              // this lane's rows / columns that are known entries
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { rk[u] = (kmask >> (8 * ta + u)) & 1ull; ck[u] = (kmask >> (8 * tb + u)) & 1ull; }
+            if (kmask != 0) {               // wave-uniform
+                gj_wave_subset(v, kmask, lane, rc, pivs);
+                double l2 = (lane < rows && ((kmask >> lane) & 1ull)) ? log(pivs[lane]) : 0.0;
+                l2 = wave_sum(l2);
+                if (lane == 0) ldm[i] = -(lp + l2);         // ln det qcov_uu = -ln det P_uu: what the bound of such a column reads (:150)
+            }
             if (ta <= tb && tb < RT) {          // the upper tiles, 64 contiguous doubles per lane (cov_pos)
                 double* ci_ = cov + (size_t)i * cov_stride(rows) + (size_t)(ta * RT - (ta * (ta - 1)) / 2 + (tb - ta)) * 64;
 #pragma unroll
                 for (int ra = 0; ra < 8; ++ra)
 #pragma unroll
-                    for (int h2 = 0; h2 < 4; ++h2) *reinterpret_cast<d2*>(ci_ + 8 * ra + 2 * h2) = d2{v[ra][2 * h2], v[ra][2 * h2 + 1]};
+                    for (int h2 = 0; h2 < 4; ++h2)
+                        *reinterpret_cast<d2*>(ci_ + 8 * ra + 2 * h2) = d2{(rk[ra] || ck[2 * h2]) ? 0.0 : v[ra][2 * h2],
+                                                                          (rk[ra] || ck[2 * h2 + 1]) ? 0.0 : v[ra][2 * h2 + 1]};
             }
             if (ta == tb) {
 #pragma unroll
-                for (int ra = 0; ra < 8; ++ra) if (8 * ta + ra < rows) var[(size_t)i * rows + 8 * ta + ra] = v[ra][ra];
+                for (int ra = 0; ra < 8; ++ra) if (8 * ta + ra < rows) var[(size_t)i * rows + 8 * ta + ra] = rk[ra] ? 0.0 : v[ra][ra];
             }
             // ---- the chain step of column i, when the columns before it have had theirs.  No workgroup barrier: a
             // wavefront that is done goes on with its next elimination while the others take their turns, so in steady
@@ -261,7 +285,10 @@ __global__ void __launch_bounds__(64 * CW_WAVES) k_cols_wishart(WArgs a) {
             for (int l = 0; l < 64; l += 4)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) w4[u] = __builtin_fma(Lb[(l + u) * 64 + lane], rvv[l + u], w4[u]);
-            wvv[lane] = lane < rows ? (w4[0] + w4[1]) + (w4[2] + w4[3]) : 0.0;
+            const double wl = (w4[0] + w4[1]) + (w4[2] + w4[3]);
+            const double obl = pre[wv][3][lane];
+            // qmu_u = [u,u] w_u - [u,o] value_o (gj_wave_subset): the known entries enter with their negated values
+            wvv[lane] = lane < rows ? ((obl == obl) ? -obl : wl) : 0.0;
             gjw_sync();
             double ws[8];
 #pragma unroll
@@ -275,7 +302,10 @@ __global__ void __launch_bounds__(64 * CW_WAVES) k_cols_wishart(WArgs a) {
                 part += __shfl_xor(part, 1, 64);
                 part += __shfl_xor(part, 2, 64);
                 part += __shfl_xor(part, 4, 64);
-                if (tb == 0) Mb[i * 64 + 8 * ta + ra] = (8 * ta + ra < rows) ? part : 0.0;
+                if (tb == 0) {
+                    const double known = pre[wv][3][8 * ta + ra];
+                    Mb[i * 64 + 8 * ta + ra] = (8 * ta + ra < rows) ? ((known == known) ? known : part) : 0.0;
+                }
             }
             __hip_atomic_store(&turn, rel + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             // ---- the running sum, in column order too, but as a stage of its own behind the chain step: the next column's
@@ -290,7 +320,7 @@ __global__ void __launch_bounds__(64 * CW_WAVES) k_cols_wishart(WArgs a) {
 #pragma unroll
                     for (int cb = 0; cb < 8; ++cb) t8[cb] = SGs[(8 * ra + cb) * 36 + tile];
 #pragma unroll
-                    for (int cb = 0; cb < 8; ++cb) t8[cb] = __builtin_fma(g, v[ra][cb], t8[cb]);
+                    for (int cb = 0; cb < 8; ++cb) t8[cb] = __builtin_fma(g, (rk[ra] || ck[cb]) ? 0.0 : v[ra][cb], t8[cb]);
 #pragma unroll
                     for (int cb = 0; cb < 8; ++cb) SGs[(8 * ra + cb) * 36 + tile] = t8[cb];
                 }
@@ -431,6 +461,24 @@ __global__ void __launch_bounds__(256) k_cov_convert(CovConvArgs c) {
     }
 }
 
+// Gaussian.observe on fully known columns (gaussian.py:97-100) under Wishart noise: their dense covariance is zero too
+// (k_observe, k_params.hip, has set the means and the diagonal)
+__global__ void __launch_bounds__(256) k_cov_observe(WArgs a) {
+    const int WHICH = blockIdx.z, n = blockIdx.x, i = blockIdx.y, D = a.D;
+    const int rows = WHICH == 0 ? a.D : a.K;
+    const double* obs = WHICH == 0 ? a.pri.A_obs : a.pri.C_obs;
+    for (int k = 0; k < rows; ++k) { const double ob = obs[(size_t)k * D + i]; if (!(ob == ob)) return; }      // block-uniform
+    double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + ((size_t)n * D + i) * cov_stride(rows);
+    for (int idx = threadIdx.x; idx < (int)cov_stride(rows); idx += 256) cov[idx] = 0.0;
+}
+
+int launch_cov_observe(pyvb_lds* h) {
+    WArgs a = make_wargs(h);
+    hipLaunchKernelGGL(k_cov_observe, dim3(h->N, h->D, 2), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
 int launch_cov_convert(pyvb_lds* h, int which, double* dense, int n0, int count, int to_packed) {
     CovConvArgs c; c.packed = which == 0 ? h->A_cov : h->C_cov; c.dense = dense; c.n0 = n0; c.D = h->D;
     c.rows = which == 0 ? h->D : h->K; c.to_packed = to_packed;
@@ -483,16 +531,26 @@ __global__ void __launch_bounds__(64) k_elbo_dense(WArgs a) {
     double la = 0.0, lc = 0.0;
     if (lane < D) {
         const int i = lane;
-        auto column = [&](int rows, const double* pp, const double* pm, const double* M, const double* V, double qld, double lndet) {
+        // the last term depends on how much of the column is known (gaussian.py:145-150, as k_elbo in k_params.hip): nothing ->
+        // the q_ln_det form, some entries -> ln det of the covariance of the rest (ldm, from k_cols_wishart), all -> no term
+        auto column = [&](int rows, const double* pp, const double* pm, const double* M, const double* V, double qld, double lndet,
+                          const double* obs, double ldmv) {
             double trc = 0.0;
+            int missing = 0;
             for (int k = 0; k < rows; ++k) {
-                const double m = M[(size_t)k * D + i], m0 = pm[(size_t)k * D + i];
+                const double m = M[(size_t)k * D + i], m0 = pm[(size_t)k * D + i], ob = obs[(size_t)k * D + i];
                 trc += pp[(size_t)i * rows + k] * (m * m + V[(size_t)i * rows + k] + m0 * m0 - 2.0 * m * m0);
+                if (!(ob == ob)) ++missing;
             }
-            return -0.5 * rows * LN2PI + 0.5 * lndet - 0.5 * trc + 0.5 * rows * LN2PI + 0.5 * qld + 0.5 * rows;
+            double r = -0.5 * rows * LN2PI + 0.5 * lndet - 0.5 * trc;
+            if (missing == rows) r += 0.5 * rows * LN2PI + 0.5 * qld + 0.5 * rows;
+            else if (missing > 0) r -= 0.5 * missing * LN2PI - 0.5 * ldmv - 0.5 * missing;
+            return r;
         };
-        la = column(D, a.pri.A_pp, a.pri.A_pm, a.A_mean + (size_t)n * D * D, a.A_var + (size_t)n * D * D, a.qld_A[(size_t)n * D + i], a.pri.A_pld[i]);
-        lc = column(K, a.pri.C_pp, a.pri.C_pm, a.C_mean + (size_t)n * K * D, a.C_var + (size_t)n * D * K, a.qld_C[(size_t)n * D + i], a.pri.C_pld[i]);
+        la = column(D, a.pri.A_pp, a.pri.A_pm, a.A_mean + (size_t)n * D * D, a.A_var + (size_t)n * D * D, a.qld_A[(size_t)n * D + i], a.pri.A_pld[i],
+                    a.pri.A_obs, a.ldm[((size_t)n * 2 + 0) * D + i]);
+        lc = column(K, a.pri.C_pp, a.pri.C_pm, a.C_mean + (size_t)n * K * D, a.C_var + (size_t)n * D * K, a.qld_C[(size_t)n * D + i], a.pri.C_pld[i],
+                    a.pri.C_obs, a.ldm[((size_t)n * 2 + 1) * D + i]);
     }
     const double LA = wave_sum(la), LC = wave_sum(lc);
     if (lane == 0) {

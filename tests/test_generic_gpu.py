@@ -341,3 +341,48 @@ def test_programs_of_many_node_tapes_on_device(name, monkeypatch):
     monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
     plan = check_programs(name, lambda n: nodes._plan_of(n))
     assert isinstance(plan.ex, generic.DeviceExecutor)
+
+
+def test_wishart_noise_with_known_entries_fused_against_node_by_node(monkeypatch):
+    """A Wishart-noise LDS whose A and C have known entries (examples/LDS_knowns_in_A.py:73-74 with the Wishart lines of
+    Linear_Dynamic_System.py:55-56): the recogniser now binds it to the fused kernels (round 2 refused the combination);
+    the same script forced onto the node-by-node plan -- the reference's own schedule, gaussian.py:125-134 on dense
+    covariances -- must agree in every posterior and in the bound of the columns."""
+    from pyvb_amd import nodes, synth, generic, _recognise
+    import make_golden as MG
+    T, D, K = 20, 3, 4
+    Y, st0, pri = synth.make_problem(T, D, K, 1, 83)
+    pri["noise"] = "wishart"
+    pri["Q_a0"], pri["Q_b0"] = np.float64(0.5 * D + 1.0), np.eye(D) * 0.05
+    pri["R_a0"], pri["R_b0"] = np.float64(0.5 * K + 1.0), np.eye(K) * 0.05
+    A_obs = np.full((D, D), np.nan); C_obs = np.full((K, D), np.nan)
+    A_obs[0, 0] = 0.8; A_obs[2, 1] = -0.3
+    C_obs[1, 2] = 2.0; C_obs[:, 0] = np.arange(K) - 1.0
+    pri["A_obs"], pri["C_obs"] = A_obs, C_obs
+
+    def script(force_generic):
+        if force_generic:
+            monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+        else:
+            monkeypatch.undo()
+        g = MG.build_graph(nodes, Y[0], pri, st0)
+        Xs, As, Cs, Q, R = g["Xs"], g["As"], g["Cs"], g["Q"], g["R"]
+        rng = np.random.default_rng(1)          # positive definite starting qw (the constructor's is rank one)
+        W = rng.standard_normal((D, D)); Q.qw = W @ W.T + D * np.eye(D)
+        W = rng.standard_normal((K, K)); R.qw = W @ W.T + K * np.eye(K)
+        for _ in range(2):
+            [x.update() for x in Xs]
+            Xs.reverse(); [x.update() for x in Xs]; Xs.reverse()
+            [a.update() for a in As]; [c.update() for c in Cs]
+            Q.update(); R.update()
+        llb = [float(n.log_lower_bound()) for n in As + Cs]
+        return (np.hstack([x.qmu for x in Xs]), np.hstack([a.qmu for a in As]), np.hstack([c.qmu for c in Cs]),
+                np.stack([a.qcov for a in As]), np.stack([c.qcov for c in Cs]), np.asarray(Q.qw), np.asarray(R.qw),
+                np.array(llb), Xs[0]._plan)
+
+    ref = script(True)
+    got = script(False)
+    assert isinstance(got[8], _recognise.LDSPlan) and isinstance(ref[8], generic.GenericPlan)
+    assert got[1][0, 0] == 0.8 and got[2][1, 2] == 2.0 and got[3][0][0, 0] == 0.0
+    for a, b, what in zip(got[:8], ref[:8], ("X", "A", "C", "cov A", "cov C", "Q.qw", "R.qw", "column bounds")):
+        _close(a, b, what, 1e-8)

@@ -621,6 +621,33 @@ def test_known_matrix_entries_vs_oracle():
     _stagewise(Y, st0, pri, iters=3)
 
 
+@pytest.mark.parametrize("T,D,K,N", [(60, 5, 6, 2), (40, 17, 9, 1), (30, 64, 64, 1)])
+def test_known_matrix_entries_with_wishart_noise(T, D, K, N):
+    """Known entries of A and C together with Wishart noise (gaussian.py:125-134 on dense column covariances): the column kernel
+    conditions on them by exchanging the known pivots back after the inversion (gj_wave_subset); partially known, fully
+    known and free columns side by side, three iterations stage by stage against the oracle (which applies the reference's
+    conditioning formula to the dense covariance), the lower bound's partial-observation branch (:148-150) included."""
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=70 + D)
+    _wishart_priors(pri, D, K, np.random.default_rng(D))
+    rng = np.random.default_rng(5)
+    A_obs = np.full((D, D), np.nan); C_obs = np.full((K, D), np.nan)
+    A_obs[0, 0] = 0.9; A_obs[min(3, D - 1), 2] = -0.25; A_obs[D - 1, 2] = 0.1
+    A_obs[:, D - 1] = np.linspace(-0.2, 0.2, D)                 # a fully known column
+    C_obs[rng.random((K, D)) < 0.15] = 0.5
+    C_obs[:, 1] = np.arange(K) * 0.1 - 0.2                      # another
+    C_obs[:, 0] = np.nan                                         # and a free one
+    pri["A_obs"], pri["C_obs"] = A_obs, C_obs
+    _stagewise(Y, st0, pri, iters=3)
+    b = _batch(Y, st0, pri)
+    st = O.expand_state(st0, pri, T)
+    for it in range(2):
+        parts = O.iterate(st, pri, Y)
+        b.iterate(1)
+    _close(b.get_state(("A_mean",))["A_mean"], st["A_mean"], "A after iterate (Wishart, known entries)")
+    _close(b.elbo().sum(1), parts.sum(1), "elbo after iterate (Wishart, known entries)")
+    b.close()
+
+
 def test_wishart_column_covariances_round_trip():
     """pyvb_lds_set_column_cov / get_column_cov / get_wishart_state: what goes in comes out, the diagonals follow."""
     T, D, K, N = 12, 5, 3, 4
