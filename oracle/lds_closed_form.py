@@ -234,7 +234,9 @@ def statistics(st, Y):
         "Syy": np.einsum("ntk,ntl->nkl", Y, Y),
         "x0x0": x0 + Sig[:, 0],
     }
-    if Yvar is not None:        # <y y^T> = qmu qmu^T + qcov (gaussian.py:162-168); the covariances are diagonal here
+    if "Ycovsum" in st:         # <y y^T> = qmu qmu^T + qcov (gaussian.py:162-168) with dense covariances (Wishart noise)
+        S["Syy"] = S["Syy"] + st["Ycovsum"]
+    elif Yvar is not None:      # the covariances are diagonal here
         K = Y.shape[2]
         S["Syy"][:, np.arange(K), np.arange(K)] += Yvar.sum(axis=1)
     return S
@@ -259,13 +261,39 @@ def update_Y(st, pri):
     qprec = <R>, qmu = <C> mu_t (gaussian.py:112-123); then the known entries are conditioned on (:125-134), which for
     a diagonal covariance pins them and leaves the others alone."""
     kind = pri["noise"]
-    assert kind != "wishart", "missing outputs with Wishart noise are not restated"
     K = st["C_mean"].shape[1]
     Rb = noise_expect(kind, st["R_a"], st["R_b"], K)
-    rdiag = np.einsum("nkk->nk", Rb)
     pmu = np.einsum("nkj,ntj->ntk", st["C_mean"], st["X"])
     miss = np.isnan(st["Yobs"])
     upd = miss.any(axis=2)                  # partially observed or latent rows
+    if kind == "wishart":
+        # dense <R>: the general form of gaussian.py:117-134, row by row (every row has its own set of known entries)
+        N, T = upd.shape
+        cov_full = np.linalg.inv(Rb)
+        qld = np.array([_chol_qld(Rb[n:n + 1])[0] for n in range(N)])
+        st.setdefault("Yld", np.full((N, T), np.nan))
+        st["Ycovsum"] = np.zeros((N, K, K))
+        for n in range(N):
+            for t in np.nonzero(upd[n])[0]:
+                mu, cov = pmu[n, t].copy(), cov_full[n].copy()
+                oi = np.nonzero(~miss[n, t])[0]
+                if len(oi):
+                    cov_obs_inv = np.linalg.inv(cov[np.ix_(oi, oi)])
+                    cov_obs_all = cov[:, oi]
+                    gain = cov_obs_all @ cov_obs_inv
+                    mu = mu + gain @ (st["Yobs"][n, t, oi] - mu[oi])
+                    cov = cov - gain @ cov_obs_all.T
+                    mu[oi] = st["Yobs"][n, t, oi]           # exact pins (the formula gives them up to rounding)
+                    cov[oi, :] = 0.0
+                    cov[:, oi] = 0.0
+                    mi = np.nonzero(miss[n, t])[0]
+                    st["Yld"][n, t] = np.linalg.slogdet(cov[np.ix_(mi, mi)])[1]
+                st["Yq"][n, t] = mu
+                st["Yvar"][n, t] = np.diag(cov)
+                st["Yqld"][n, t] = qld[n]
+                st["Ycovsum"][n] += cov
+        return
+    rdiag = np.einsum("nkk->nk", Rb)
     st["Yq"] = np.where(upd[:, :, None], np.where(miss, pmu, np.nan_to_num(st["Yobs"])), st["Yq"])
     st["Yvar"] = np.where(upd[:, :, None], np.where(miss, 1.0 / rdiag[:, None, :], 0.0), st["Yvar"])
     qld = 0.5 / np.sum(0.5 * np.log(rdiag), axis=1)          # gaussian.py:120 (quirk Q1)
@@ -280,6 +308,8 @@ def _y_entropy_terms(st):
     latent, partial = nm == K, (nm > 0) & (nm < K)
     with np.errstate(divide="ignore", invalid="ignore"):
         lv = np.where(miss, np.log(st["Yvar"]), 0.0).sum(axis=2)
+    if "Yld" in st:     # dense covariances (Wishart noise): ln det of the block of the missing entries, once a row has been updated
+        lv = np.where(np.isnan(st["Yld"]), lv, st["Yld"])
     tp = np.where(partial, 0.5 * nm * LN2PI - 0.5 * lv - 0.5 * nm, 0.0)
     tl = np.where(latent, -0.5 * K * LN2PI - 0.5 * st["Yqld"] - 0.5 * K, 0.0)
     return (tp + tl).sum(axis=1)

@@ -390,8 +390,6 @@ def describe(start):
         _fail("observed states")
     for y in Ys:
         if not y.observed:
-            if isinstance(Q, N.Wishart):
-                _fail("outputs with missing entries together with Wishart noise")
             cov = y.__dict__["_h_qcov"]
             if np.abs(cov - np.eye(K) * cov[0, 0]).max() != 0.0:
                 _fail("the initial covariance of an output with missing entries must be a multiple of the identity")

@@ -200,7 +200,7 @@ int pyvb_lds_destroy(pyvb_lds* h) {
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
                       h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->sxx, h->U,
                       h->Q_w, h->R_w, h->Qbar, h->Rbar, h->lnd, h->QA, h->RC, h->trA, h->trC, h->A_cov, h->C_cov, h->SyyF, h->RQ, h->RR, h->SG, h->ldm,
-                      h->Yobs, h->Yvar, h->Yqld, h->Yent};
+                      h->Yobs, h->Yvar, h->Yqld, h->Yent, h->Yld, h->YcovS};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
     if (h->status) (void)hipFree(h->status);
@@ -432,6 +432,15 @@ int pyvb_lds_set_column_observations(pyvb_lds* h, const double* A_obs, const dou
     return PYVB_OK;
 }
 
+static int ensure_expect(pyvb_lds* h);
+// Wishart noise, after the means of the outputs changed: sum_t qmu qmu^T, and the entropy terms of the rows that are not
+// fully observed (diag_cov: they still carry their diagonal initial covariances, whose sum is formed here too)
+static int outputs_changed_dense(pyvb_lds* h, int diag_cov) {
+    int rc;
+    if ((rc = launch_syy_full(h))) return rc;
+    return launch_missing_ent_dense(h, diag_cov);
+}
+
 int pyvb_lds_set_observations(pyvb_lds* h, const double* Y) {
     ENTER(h);
     ARGCHK(Y, "Y is NULL");
@@ -440,19 +449,22 @@ int pyvb_lds_set_observations(pyvb_lds* h, const double* Y) {
     for (size_t i = 0; i < n && !missing; ++i) missing = Y[i] != Y[i];
     int rc;
     if (missing) {
-        if (h->dense) { pyvb_set_error("outputs with missing entries together with Wishart noise are not supported"); return PYVB_E_UNSUPPORTED; }
         if (h->big) { pyvb_set_error("outputs with missing entries with D or K above 64 is not served by the fused kernels"); return PYVB_E_UNSUPPORTED; }
         if (!h->Yobs) {
             if ((rc = dev_alloc(&h->Yobs, n))) return rc;
             if ((rc = dev_alloc(&h->Yvar, n))) return rc;
             if ((rc = dev_alloc(&h->Yqld, (size_t)h->N * h->T))) return rc;
             if ((rc = dev_alloc(&h->Yent, h->N))) return rc;
+            if (h->dense) {
+                if ((rc = dev_alloc(&h->Yld, (size_t)h->N * h->T))) return rc;
+                if ((rc = dev_alloc(&h->YcovS, (size_t)h->N * h->K * h->K))) return rc;
+            }
         }
         if ((rc = h2d(h, h->Yobs, Y, n))) return rc;
         h->has_missing = true;
         // rows with NaN start as N(0, I) until pyvb_lds_set_output_state says otherwise
         if ((rc = launch_missing_init(h, nullptr, nullptr))) return rc;
-        if ((rc = launch_syy_missing(h))) return rc;
+        if ((rc = h->dense ? outputs_changed_dense(h, 1) : launch_syy_missing(h))) return rc;
     } else {
         h->has_missing = false;
         if ((rc = h2d(h, h->Y, Y, n))) return rc;
@@ -477,7 +489,7 @@ int pyvb_lds_set_output_state(pyvb_lds* h, const double* Yq, const double* Yrowv
     double* dv = h->X[1 - h->cur];      // [N][T][DP] >= [N][T]
     int rc;
     if ((rc = h2d(h, dq, Yq, n)) || (rc = h2d(h, dv, Yrowvar, (size_t)h->N * h->T)) ||
-        (rc = launch_missing_init(h, dq, dv)) || (rc = launch_syy_missing(h))) {
+        (rc = launch_missing_init(h, dq, dv)) || (rc = h->dense ? outputs_changed_dense(h, 1) : launch_syy_missing(h))) {
         if (tmp) { (void)hipStreamSynchronize(h->stream); (void)hipFree(tmp); }
         return rc;
     }
@@ -509,8 +521,14 @@ int pyvb_lds_update_Y(pyvb_lds* h) {
     ENTER(h);
     if (!h->has_missing) return PYVB_OK;            // observed nodes never update (gaussian.py:109-110)
     int rc;
-    if ((rc = launch_impute(h))) return rc;
-    if ((rc = launch_syy_missing(h))) return rc;
+    if (h->dense) {
+        if ((rc = ensure_expect(h))) return rc;     // E[R] and its log-determinant
+        if ((rc = launch_impute_dense(h))) return rc;
+        if ((rc = outputs_changed_dense(h, 0))) return rc;
+    } else {
+        if ((rc = launch_impute(h))) return rc;
+        if ((rc = launch_syy_missing(h))) return rc;
+    }
     h->u_valid = false;                             // c_t = F mu + G y_t was formed with the old y_t
     states_changed(h);
     return PYVB_OK;

@@ -138,6 +138,7 @@ struct pyvb_lds {
     // ---- outputs with missing entries (k_missing.hip); allocated when set_observations sees NaN
     bool has_missing;
     double *Yobs, *Yvar, *Yqld, *Yent;      // [N][T][K] observations (NaN = missing), [N][T][K] variances, [N][T], [N]
+    double *Yld, *YcovS;                    // Wishart noise: [N][T] ln det of each row's covariance of missing entries, [N][K][K] sum_t qcov_t
     // ---- the lower bound does not feed the next iteration: inside pyvb_lds_iterate it runs on a side stream
     hipStream_t side;
     hipEvent_t ev_params, ev_elbo;  // parameters of this iteration complete (main) / lower bound of it read them (side)
@@ -180,6 +181,8 @@ int launch_cov_convert(pyvb_lds* h, int which, double* dense, int n0, int count,
 int launch_missing_init(pyvb_lds* h, const double* Yq0, const double* Yrowvar0);     // device pointers or null
 int launch_impute(pyvb_lds* h);
 int launch_syy_missing(pyvb_lds* h);
+int launch_impute_dense(pyvb_lds* h);                 // Wishart noise: [y.update() for y in Ys if not y.observed]
+int launch_missing_ent_dense(pyvb_lds* h, int diag_cov);
 
 // communicators, shared by the LDS and the PCA path (api.hip): RCCL, or the caller's own host-side all-reduce
 // (pyvb_*_comm_init_host: the sums travel through host memory -- a rehearsal transport for boxes where RCCL cannot run)

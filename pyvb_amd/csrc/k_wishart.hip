@@ -39,6 +39,7 @@ __device__ __forceinline__ void cov_tile_ab(int rows, int t, int& A, int& B) {
 
 struct WArgs {
     double *Q_w, *R_w, *Qbar, *Rbar, *lnd, *QA, *RC, *trA, *trC, *A_cov, *C_cov, *RQ, *RR, *SyyF;
+    const double* YcovS; const double* Yent;   // outputs with missing entries (k_missing.hip): sum_t qcov_t [N][K][K], entropy terms [N]; or null
     double* ldm;        // [N][2][D]: ln det of the covariance of the UNKNOWN entries of a column that has known ones (gaussian.py:150)
     double* SG;         // [N][2][64][64]-slots holding [rows][rows]: sum_i G[i,i] S_i of A's / C's columns (k_cols_wishart), or null: k_wresid sums the covariances itself
     const double *Q_a, *R_a;
@@ -61,6 +62,7 @@ static WArgs make_wargs(pyvb_lds* h) {
     a.pri = h->pri; a.status = h->status;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.DP = h->L.DP;
     a.which0 = 0; a.c0 = 0; a.c1 = h->D; a.update = 0; a.SG = nullptr; a.ldm = h->ldm;
+    a.YcovS = h->has_missing ? h->YcovS : nullptr; a.Yent = h->has_missing ? h->Yent : nullptr;
     return a;
 }
 
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(256) k_wresid(WArgs a) {
         }
         double own;
         if (WHICH == 0) own = GC[idx] - x0[xpos(k)] * x0[xpos(l)] - S0[idx];          // sum_{t >= 1} <x x^T>
-        else own = a.SyyF[(size_t)n * K * K + idx];
+        else own = a.SyyF[(size_t)n * K * K + idx] + (a.YcovS ? a.YcovS[(size_t)n * K * K + idx] : 0.0);        // <y y^T> = qmu qmu^T + qcov
         const double r = 0.5 * (own + e) - hm;
         Rm[idx] = r;
         if (a.update) {
@@ -527,7 +529,8 @@ __global__ void __launch_bounds__(64) k_elbo_dense(WArgs a) {
     double LX = -0.5 * D * LN2PI + 0.5 * a.pri.x0_lndet - 0.5 * e0;
     LX += (double)(T - 1) * (-0.5 * D * LN2PI + 0.5 * ln[0]) - trQ;
     LX += (double)T * (0.5 * D * LN2PI + 0.5 * D) + 0.5 * (qx[0] + nint * qx[1] + qx[2]);
-    const double LY = (double)T * (-0.5 * K * LN2PI + 0.5 * ln[1]) - trR;
+    double LY = (double)T * (-0.5 * K * LN2PI + 0.5 * ln[1]) - trR;
+    if (a.Yent) LY -= a.Yent[n];
     double la = 0.0, lc = 0.0;
     if (lane < D) {
         const int i = lane;

@@ -494,6 +494,9 @@ CASES = [
     # beyond one 64 x 64 tile set (the fused kernels' second shape class, D, K <= 128): one iteration, about an hour of the
     # reference's D^5 tensor work
     ("d80k80_t3", 3, 80, 80, "diagonal_gamma", (1,), 20252, False),
+    # Wishart noise together with known entries of A / C, and with outputs that hold NaN: the FIRST update
+    ("wishart_knowns_d3k4_t30", 30, 3, 4, "wishart", (1,), 20253, True, True),
+    ("wishart_missing_d3k4_t24", 24, 3, 4, "wishart", (1,), 20254, True, False, True),
 ]
 
 

@@ -135,6 +135,10 @@ def test_golden_fixtures(golden):
                 Ac, Cc = b.get_column_cov()
                 _close(Ac[0], z[tag + "A_cov"], tag + "A_cov (dense)")
                 _close(Cc[0], z[tag + "C_cov"], tag + "C_cov (dense)")
+                if missing:
+                    q, v = b.get_outputs()
+                    _close(q[0], z[tag + "Yq"], tag + "Yq")
+                    _close(v[0], z[tag + "Yvar"], tag + "Yvar")
                 assert np.all(np.isfinite(b.elbo()))
                 continue
             for nm in ("Q_a", "Q_b", "R_a", "R_b"):
@@ -280,14 +284,22 @@ def test_outputs_with_missing_entries(T, D, K, N, kind):
     b.close()
 
 
-def test_missing_outputs_are_refused_with_wishart_noise():
-    from pyvb_amd import _capi
-    Y, st0, pri = synth.make_problem(20, 3, 4, 1, seed=1)
-    _wishart_priors(pri, 3, 4)
-    Y[0, 2, 1] = np.nan
-    with pytest.raises(_capi.PyvbHipError) as e:
-        _batch(Y, st0, pri)
-    assert e.value.code == _capi.E_UNSUPPORTED
+@pytest.mark.parametrize("T,D,K,N,frac", [(30, 3, 4, 2, 0.3), (50, 6, 17, 1, 0.15), (24, 20, 64, 1, 0.1)])
+def test_missing_outputs_with_wishart_noise(T, D, K, N, frac):
+    """Outputs with NaN under Wishart noise (round 2 refused the combination): a row's missing entries are correlated and
+    regress on its known ones -- qcov_uu = inv(<R>_uu), gaussian.py:117-134 with a dense precision -- so <y y^T> carries a
+    dense covariance sum into R's Wishart update and the bound's partial-observation terms read ln det qcov_uu.  Partially
+    observed, completely missing and fully observed rows side by side; stage by stage against the oracle, which applies the
+    reference's conditioning formula row by row."""
+    rng = np.random.default_rng(T + K)
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=60 + K)
+    _wishart_priors(pri, D, K, np.random.default_rng(K))
+    Y[rng.random(Y.shape) < frac] = np.nan
+    Y[0, 3] = np.nan                                    # a row without any known entry
+    Y[0, 5] = np.nan_to_num(Y[0, 5])                    # and a fully observed one
+    st0["Yq"] = np.where(np.isnan(Y), rng.standard_normal(Y.shape), Y)
+    st0["Yrowvar"] = rng.uniform(0.5, 2.0, size=Y.shape[:2])
+    _stagewise(Y, st0, pri, iters=3)
 
 
 def test_nondefault_priors():
