@@ -121,6 +121,10 @@ class NumpyExecutor(object):
         self.programs.append(program)
         return len(self.tapes) - 1
 
+    def drop(self, tid):
+        self.tapes[tid] = None
+        self.programs[tid] = None
+
     def run(self, tid):
         """With a program (pyvb_graph_tape_set_program: record ranges the device runs side by side) the blocks of a launch are
         interpreted LAST FIRST: if the independence the program claims did not hold, the results would depend on that order and

@@ -53,6 +53,17 @@ def pca(N, d, q, iters):
     t2 = time.time()
     print("generic PCA N=%d d=%d q=%d through Network.learn: first iteration %.2f s, then %.1f ms per iteration" % (N, d, q, t1 - t0, (t2 - t1) / iters * 1e3), flush=True)
 
+    # the same updates as a hand-written loop (examples/PCA_missing_data.py style, without the lower bound): the requests queue up
+    # and are issued as one tape per pass, independent nodes side by side
+    def it():
+        [w.update() for w in Ws]; [z.update() for z in Zs]; [x.update() for x in Xs]; Mu.update(); Beta.update()
+    t0 = time.time(); it(); _ = Mu.qmu; t1 = time.time()
+    for _i in range(iters):
+        it()
+    _ = Mu.qmu
+    t2 = time.time()
+    print("generic PCA N=%d d=%d q=%d as a hand-written loop: first pass %.2f s, then %.1f ms per pass" % (N, d, q, t1 - t0, (t2 - t1) / iters * 1e3), flush=True)
+
 
 lds(200, 2, 5, 5)
 lds(1000, 4, 8, 3)

@@ -38,6 +38,14 @@ LN2PI = float(np.log(2.0 * np.pi))
 CONST_CAP = 8192          # doubles reserved for the constant pool at the start of the arena
 
 
+# which fields of a record hold arena offsets, per opcode (pyvb_amd/csrc/k_tape.hip: tape_extents); used to move a node's
+# temporaries when its records are issued beside another node's (GenericPlan._relocate)
+_OFFSET_FIELDS = {T_COPY2D: (1, 2), T_FILL: (1,), T_AXPBY: (1, 2, 3, 6, 7), T_GEMM: (1, 2, 3), T_SCALE: (1, 2, 3), T_TRACE: (1, 2),
+                  T_DOT: (1, 2, 3), T_DIAG: (1, 2), T_CHOLINV: (1, 2, 3, 6), T_UNARY: (1, 2), T_GATHER: (1, 2, 3, 7),
+                  T_SCATTER: (1, 2, 3, 7), T_MUL: (1, 2, 3)}
+T_ACC_BIT = 0x40000000
+
+
 class Ref(object):
     """An m x n row-major block of the arena."""
     __slots__ = ("off", "m", "n")
@@ -232,6 +240,9 @@ class DeviceExecutor(object):
     def run(self, tid):
         self.C.check(self.C.lib.pyvb_graph_tape_run(self._h, int(tid)))
 
+    def drop(self, tid):
+        self.C.check(self.C.lib.pyvb_graph_tape_destroy(self._h, int(tid)))
+
     def sync(self):
         self.C.check(self.C.lib.pyvb_graph_sync(self._h))
 
@@ -330,6 +341,8 @@ class GenericPlan(object):
         # set by LDSPlan._demote.  Requests that follow the pattern wait in _buf; anything else runs them node by node.
         self.resume = None
         self._buf = []
+        self._node_span = 0             # doubles of temporaries the largest per-node tape uses
+        self._pending = []              # update() requests not yet issued: a run of them becomes ONE tape (see _flush_pending)
         self.released = False
         if adopt:
             for nd in self.nodes:
@@ -461,13 +474,10 @@ class GenericPlan(object):
     def enqueue(self, node):
         if self.resume is not None and self._buffer(node):
             return
-        self._update_now(node)
+        self._pending.append(node)      # issued at the next read / write / other request (_flush_buf), together
 
     def _update_now(self, node):
-        if isinstance(node, N.Gaussian):
-            self._run(("update", id(node)), lambda t: self._emit_update_gaussian(t, node))
-        else:
-            self._run(("update", id(node)), lambda t: self._emit_update_noise(t, node))
+        self._run(self._node_tape(node), None)
 
     def _buffer(self, node):
         """True if the request was taken into the buffer (it runs later: fused, or node by node at the next flush)."""
@@ -485,8 +495,104 @@ class GenericPlan(object):
 
     def _flush_buf(self):
         buf, self._buf = self._buf, []
-        for nd in buf:
-            self._update_now(nd)
+        self._pending.extend(buf)
+        self._flush_pending()
+
+    # A hand-written loop -- [x.update() for x in Xs]; [z.update() for z in Zs]; Q.update() -- used to cost a launch per node.
+    # The requests now wait until something needs their results and are then issued as ONE tape: the per-node tapes (built
+    # once per node, as before) are concatenated, and the same analysis as for Network.learn's tapes (_program) finds the
+    # nodes that touch disjoint state and lets them run side by side, one workgroup each; the temporaries of nodes that run
+    # side by side are moved apart (every per-node tape allocates from the same base: _relocate).  The combined tape is kept
+    # under the sequence of nodes, so the second pass of a loop re-uses it.  Nodes whose own tape already carries a program
+    # (many children: their messages run side by side) are issued on their own.
+    SEQ_CACHE = 64
+
+    def _node_tape(self, node):
+        key = ("update", id(node))
+        if key not in self._tapes:
+            t = Tape(self)
+            res = self._emit_update_gaussian(t, node) if isinstance(node, N.Gaussian) else self._emit_update_noise(t, node)
+            self._node_span = max(self._node_span, t.top - self.temp_base)
+            self._tapes[key] = (None, t.array(), res)
+            if t.marks:
+                self._programs[key] = self._program(t)
+        return key
+
+    def _relocate(self, ops, shift):
+        """ops with every temporary (offset fields at or beyond temp_base) moved up by `shift`."""
+        if shift == 0:
+            return ops
+        out = ops.copy()
+        for code, fields in _OFFSET_FIELDS.items():
+            rows = np.nonzero(ops[:, 0] == code)[0]
+            if rows.size == 0:
+                continue
+            for f in fields:
+                col = out[rows, f]
+                if code == T_SCATTER and f == 7:
+                    acc = col & T_ACC_BIT
+                    val = col & ~T_ACC_BIT
+                    out[rows, f] = np.where(val >= self.temp_base, val + shift, val) | acc
+                else:
+                    out[rows, f] = np.where(col >= self.temp_base, col + shift, col)
+        return out
+
+    def _flush_pending(self):
+        seq, self._pending = self._pending, []
+        run = []
+
+        def issue(run):
+            if not run:
+                return
+            if len(run) == 1:
+                self._update_now(run[0])
+                return
+            key = ("seq",) + tuple(id(n) for n in run)
+            if key not in self._tapes:
+                if sum(1 for k in self._tapes if k[0] == "seq") >= self.SEQ_CACHE:       # bounded: forget the oldest sequences
+                    for k in [k for k in self._tapes if k[0] == "seq"][:self.SEQ_CACHE // 2]:
+                        tid = self._tapes.pop(k)[0]
+                        self._programs.pop(k, None)
+                        if tid is not None and self.ex is not None:
+                            self.ex.drop(tid)
+                parts = [self._tapes[self._node_tape(n)][1] for n in run]
+                sizes = [len(p) for p in parts]
+                t = Tape(self)
+                t.ops = [tuple(int(v) for v in r) for p in parts for r in p]
+                pos = 0
+                for sz in sizes:
+                    t.marks.append(pos)
+                    pos += sz
+                prog = self._program(t)
+                ops = np.concatenate(parts).astype(np.int32)
+                if prog is not None:
+                    # nodes that share a launch get temporaries of their own
+                    span = self._node_span
+                    blocks, launches = prog
+                    starts = np.cumsum([0] + sizes)
+                    node_of = {int(a): i for i, a in enumerate(starts[:-1])}
+                    worst = 0
+                    for first, count in launches:
+                        if count == 1:
+                            continue
+                        for k in range(count):
+                            a, n_ = int(blocks[first + k][0]), int(blocks[first + k][1])
+                            i = node_of[a]
+                            assert n_ == sizes[i], "a parallel block is exactly one node's records"
+                            ops[a:a + n_] = self._relocate(ops[a:a + n_], k * span)
+                        worst = max(worst, count)
+                    self.temp_high = max(self.temp_high, self.temp_base + worst * span)
+                    self._programs[key] = prog
+                self._tapes[key] = (None, ops, None)
+            self._run(key, None)
+
+        for nd in seq:
+            if self._programs.get(self._node_tape(nd)) is not None:
+                issue(run); run = []
+                self._update_now(nd)
+            else:
+                run.append(nd)
+        issue(run)
 
     def _resume_fused(self):
         """A forward and a backward sweep have queued up with nothing in between: the standard loop is back.  The state goes

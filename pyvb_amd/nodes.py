@@ -45,8 +45,8 @@ class Node(object):
         self._plan = None
 
     def addChild(self, child):
-        self.children.append(child)
         _graph_changed(self)
+        self.children.append(child)
 
     def update(self):
         pass
@@ -79,6 +79,10 @@ def _graph_changed(node):
     pulled back into the nodes and the graph is bound again as it is then."""
     plan = getattr(node, "_plan", None)
     if plan is not None:
+        # requests made so far refer to the graph as it was: they are issued before it changes (the node-by-node plan keeps
+        # update() calls back until a result is needed, and builds a node's tape from its attributes)
+        if not getattr(plan, "stale", False) and not getattr(plan, "released", False):
+            plan.flush()
         plan.stale = True
 
 
@@ -349,9 +353,9 @@ class Gamma(_NoiseNode):                        # nodes_todo.py:88-157
         self.qb = np.random.rand()
 
     def addChild(self, child):
+        _graph_changed(self)
         self.children.append(child)
         self.update_a()
-        _graph_changed(self)
 
     def update_a(self):
         self.qa = self.a0
@@ -377,9 +381,9 @@ class DiagonalGamma(_NoiseNode):                # nodes_todo.py:159-204
 
     def addChild(self, child):
         assert child.shape == (self.shape[0], 1)
+        _graph_changed(self)
         self.children.append(child)
         self.update_a()
-        _graph_changed(self)
 
     def update_a(self):
         self.qa = self.a0s.copy()
@@ -412,9 +416,9 @@ class Wishart(_NoiseNode):                      # nodes_todo.py:205-234
 
     def addChild(self, child):
         assert child.shape == (self.shape[0], 1)
+        _graph_changed(self)
         self.children.append(child)
         self.update_v()
-        _graph_changed(self)
 
     def update_v(self):
         self.qv = self.v0
