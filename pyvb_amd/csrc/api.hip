@@ -113,7 +113,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRY(dev_alloc(&h->scratch, h->big ? n * 2 * L.DP * L.DP : n * 2 * D * D));
     TRY(dev_alloc(&h->trash, n * 512));
     TRY(dev_alloc(&h->zeros, 128));
-    TRY(dev_alloc(&h->U, h->big ? 64 : n * T * L.DP));         // the c_t cache of the 64-wide sweeps
+    TRY(dev_alloc(&h->U, n * T * L.DP));                        // the c_t cache between a forward sweep and the backward one behind it
     TRYHIP(hipMalloc((void**)&h->warm, n * 2 * sizeof(int)));
     TRYHIP(hipMemset(h->warm, 0, n * 2 * sizeof(int)));
     // time chunks of the statistics kernel: enough wavefronts to fill the chip when N is small

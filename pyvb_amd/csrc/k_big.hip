@@ -7,10 +7,10 @@
 //                 (128 x 16, the MFMA B operand) is exchanged through LDS once per step: every wavefront writes the two
 //                 accumulator tiles it has just formed -- accumulator layout = B-operand layout, as in k_sweep.hip -- and
 //                 reads the other six.  Same segmentation of the time axis, same warm-up from k_prep's contraction bound,
-//                 same boundary nodes.  Both sweeps compute all three products (no c_t cache, no fused Sxx).
+//                 same boundary nodes, same c_t cache between the forward sweep and the backward one behind it (no fused Sxx).
 //   k_prep_big    one work matrix in LDS (128 x 130 doubles), intermediates in a per-replicate global scratch; the three
 //                 precisions inverted one after the other by the whole workgroup (8 x 8 tile per thread).
-//   k_stats_big   Sxx, Sx1x, Syx as three (replicate, chunk, kind) grids: a wavefront holds 1 x 8 accumulator tiles.
+//   k_stats_big   Sxx, Sx1x, Syx in one pass per (replicate, chunk): a wavefront holds row tile w of all three (3 x 8 tiles).
 //   k_cols_big    thread = row of the matrix; the Gauss-Seidel pass over the columns runs column by column (the rows decouple
 //                 under diagonal noise and diagonal column priors), <M> as [col][row] in LDS.
 // Reference methods as in the small kernels: Gaussian.update gaussian.py:102-123, Multiplication.pass_up_m1_m2 node.py:182-232,
@@ -31,6 +31,7 @@
 struct BigSweepArgs {
     const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
     const double *A_mean, *C_mean;
+    double* U;          // [N][T][128]: c_t = R mu_{t-1} + G y_t of the interior nodes (MODE 1 writes, MODE 2 reads), accumulator order
     double* trash;      // [N][512]
     int N, T, D, K, dir;
     Layout L;
@@ -65,6 +66,11 @@ __device__ __forceinline__ double big_boundary(bool first, const double* g, cons
     return s;
 }
 
+// MODE (as k_sweep.hip): the parameters are frozen between the two sweeps of an iteration, and the backward update
+//   mu_t <- B mu_{t+1}(new) + F mu_{t-1}(forward result) + G y_t
+// contains c_t = F mu_{t-1} + G y_t, which the forward sweep has just formed.  MODE 1 (forward) stores c_t, MODE 2 (the backward
+// sweep that follows directly) reads it back and runs ONE product per step instead of three; MODE 0 computes everything.
+template <int MODE>
 __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
     extern __shared__ double lds[];
     double* gl = lds;                               // [4 waves][2 tiles][BDS][64]: G as A operands, this wavefront's rows
@@ -94,8 +100,8 @@ __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
             for (int s = 0; s < BDS; ++s) {
                 const size_t o = ((size_t)(2 * w + mm) * BDS + s) * 64 + lane;
                 rn[mm][s] = Rn[o];
-                ip[mm][s] = Ip[o];
-                gl[((w * 2 + mm) * BDS + s) * 64 + lane] = Gp[o];
+                ip[mm][s] = MODE == 2 ? 0.0 : Ip[o];
+                if constexpr (MODE != 2) gl[((w * 2 + mm) * BDS + s) * 64 + lane] = Gp[o];
             }
     }
     const int Tint = T - 2;
@@ -153,33 +159,54 @@ __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
 #pragma unroll
             for (int m = 0; m < BDT; ++m) mo[m] = *reinterpret_cast<const d4*>(op + (m * 4 + q) * 4);
         };
-        load_y(jstart);
-        load_o(jstart);
+        double* const Un = a.U + (size_t)n * T * BDP;
+        d4 cv[2];                       // MODE 2: this wavefront's rows of c_t, a step ahead
+        auto load_c = [&](int j) {
+            const double* cp = Un + (size_t)(active(j) ? tbase + sgn * j : tsafe) * BDP;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) cv[mm] = *reinterpret_cast<const d4*>(cp + ((2 * w + mm) * 4 + q) * 4);
+        };
+        if constexpr (MODE == 2) load_c(jstart);
+        else { load_y(jstart); load_o(jstart); }
         for (int j = jstart; j < Lseg; ++j) {
             const bool act = active(j);
             d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-            // G y_t
+            if constexpr (MODE == 2) {
+                acc[0] = cv[0]; acc[1] = cv[1];
+                __builtin_amdgcn_sched_barrier(0);
+                load_c(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                // G y_t
 #pragma unroll
-            for (int s = 0; s < BDS; ++s)
+                for (int s = 0; s < BDS; ++s)
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm)
-                    acc[mm] = MFMA(gl[((w * 2 + mm) * BDS + s) * 64 + lane], yv[s >> 1][s & 1], acc[mm]);
-            __builtin_amdgcn_sched_barrier(0);
-            load_y(j + 1);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int mm = 0; mm < 2; ++mm)
+                        acc[mm] = MFMA(gl[((w * 2 + mm) * BDS + s) * 64 + lane], yv[s >> 1][s & 1], acc[mm]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_y(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // R mu_{t-dir} (new): the segments' state
 #pragma unroll
             for (int s = 0; s < BDS; ++s)
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(rn[mm][s], xbuf[s * 64 + lane], acc[mm]);
-            // I mu_{t+dir} (old)
+            if constexpr (MODE == 1) {          // c_t for the backward sweep, this wavefront's rows
+                double* ur = (act && j >= 0) ? Un + (size_t)(tbase + sgn * j) * BDP : trash + 256;
 #pragma unroll
-            for (int s = 0; s < BDS; ++s)
+                for (int mm = 0; mm < 2; ++mm) *reinterpret_cast<d4*>(ur + ((2 * w + mm) * 4 + q) * 4) = acc[mm];
+            }
+            if constexpr (MODE != 2) {
+                // I mu_{t+dir} (old)
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(ip[mm][s], mo[s >> 2][s & 3], acc[mm]);
-            __builtin_amdgcn_sched_barrier(0);
-            load_o(j + 1);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < BDS; ++s)
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(ip[mm][s], mo[s >> 2][s & 3], acc[mm]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_o(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // this wavefront's rows of the new state: kept where the column is active, then shared
             double* out = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * BDP : trash;
             d4 nx[2];
@@ -217,17 +244,23 @@ __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
 int launch_sweep_big(pyvb_lds* h, int direction) {
     BigSweepArgs a;
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
-    a.A_mean = h->A_mean; a.C_mean = h->C_mean; a.trash = h->trash;
+    a.A_mean = h->A_mean; a.C_mean = h->C_mean; a.trash = h->trash; a.U = h->U;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
     const size_t lds = ((size_t)4 * 2 * BDS * 64 + (size_t)BDS * 64 + 2 * BDP) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_sweep_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_sweep_big<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_sweep_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_sweep_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    // forward: stores c_t; a backward sweep right behind it (h->u_valid) reads it; anything else computes everything
+    const int mode = direction == PYVB_FORWARD ? 1 : (h->u_valid ? 2 : 0);
     {
         TimedLaunch tl(h, direction == PYVB_FORWARD ? PYVB_K_SWEEP_FWD : PYVB_K_SWEEP_BWD);
-        hipLaunchKernelGGL(k_sweep_big, dim3(h->N), dim3(256), lds, h->stream, a);
+        if (mode == 1) hipLaunchKernelGGL(k_sweep_big<1>, dim3(h->N), dim3(256), lds, h->stream, a);
+        else if (mode == 2) hipLaunchKernelGGL(k_sweep_big<2>, dim3(h->N), dim3(256), lds, h->stream, a);
+        else hipLaunchKernelGGL(k_sweep_big<0>, dim3(h->N), dim3(256), lds, h->stream, a);
     }
     HIPCHK(hipGetLastError());
     return PYVB_OK;
@@ -242,12 +275,13 @@ struct BigStatsArgs {
     Layout L;
 };
 
-// kind (blockIdx.z): 0  Sxx = sum_t mu_t mu_t^T;  1  Sx1x = sum_t mu_{t+1} mu_t^T;  2  Syx = sum_t y_t mu_t^T.
-// T is the MFMA K dimension (k_stats.hip).  Eight wavefronts per workgroup, wavefront w forms row tile w against all eight
-// column tiles: 32 accumulator registers per lane, so four wavefronts share a SIMD and cover each other's load latency (the
-// operands of a k-step are fetched one k-step ahead besides); the eight read the same rows, seven of them from L1.
+// Sxx = sum_t mu_t mu_t^T,  Sx1x = sum_t mu_{t+1} mu_t^T,  Syx = sum_t y_t mu_t^T  in one pass: T is the MFMA K dimension
+// (k_stats.hip).  Eight wavefronts per workgroup; wavefront w forms row tile w of all three sums against the eight column
+// tiles of mu_t, so the eight B operands of a k-step (the expensive part: 4 KB per wavefront) serve 24 MFMAs, and the A
+// operand of Sxx is one of them.  96 accumulator registers per lane; operands are fetched one k-step ahead; the eight
+// wavefronts read the same rows, seven of them from L1.
 __global__ void __launch_bounds__(512) k_stats_big(BigStatsArgs a) {
-    const int ch = blockIdx.x, n = blockIdx.y, kind = blockIdx.z;
+    const int ch = blockIdx.x, n = blockIdx.y;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int T = a.T, K = a.K;
     const double* X = a.X + (size_t)n * T * BDP;
@@ -255,40 +289,53 @@ __global__ void __launch_bounds__(512) k_stats_big(BigStatsArgs a) {
     const double* Z = a.zeros;
     const int t0 = ch * a.chunk_len;
     const int t1 = (t0 + a.chunk_len < T) ? t0 + a.chunk_len : T;
-    double* P = a.part + ((size_t)n * a.nchunk + ch) * a.L.stats_total + (kind == 0 ? a.L.oSxx : (kind == 1 ? a.L.oSx1x : a.L.oSyx));
+    double* P = a.part + ((size_t)n * a.nchunk + ch) * a.L.stats_total;
     int xoff[BDT];
 #pragma unroll
     for (int m = 0; m < BDT; ++m) xoff[m] = xpos(16 * m + r);
-    const int adim = 16 * w + r;
-    const int aoff = kind == 2 ? (adim < K ? adim : -1) : xpos(adim);
-    d4 acc[BDT];
+    const int ydim = 16 * w + r;
+    d4 sxx[BDT], sx1[BDT], syx[BDT];
 #pragma unroll
-    for (int k = 0; k < BDT; ++k) acc[k] = d4{0.0, 0.0, 0.0, 0.0};
-    double av[2], bv[2][BDT];
+    for (int k = 0; k < BDT; ++k) { sxx[k] = d4{0.0, 0.0, 0.0, 0.0}; sx1[k] = sxx[k]; syx[k] = sxx[k]; }
+    double bv[2][BDT], x1v[2], yv[2];
     auto fetch = [&](int tb, int h) {
         const int t = tb + q;
-        const double* xb = t < t1 ? X + (size_t)t * BDP : Z;
-        const double* ap;
-        if (kind == 0) ap = xb;
-        else if (kind == 1) ap = (t < t1 && t + 1 < T) ? X + (size_t)(t + 1) * BDP : Z;
-        else ap = t < t1 ? Y + (size_t)t * K : Z;
-        av[h] = aoff >= 0 ? ap[aoff] : 0.0;
+        const double* xb = t < t1 ? X + (size_t)t * BDP : Z;                          // rows beyond the chunk read as zeros
+        const double* x1 = (t < t1 && t + 1 < T) ? X + (size_t)(t + 1) * BDP : Z;
+        const double* yb = t < t1 ? Y + (size_t)t * K : Z;
 #pragma unroll
         for (int k = 0; k < BDT; ++k) bv[h][k] = xb[xoff[k]];
+        x1v[h] = x1[xoff[w]];
+        yv[h] = ydim < K ? yb[ydim] : 0.0;
+    };
+    auto step = [&](int h) {
+        // row tile w of mu_t is column tile w of the B operands: picked by a compile-time chain (w is wave-uniform)
+        double xa = bv[h][0];
+#pragma unroll
+        for (int k = 1; k < BDT; ++k) xa = (w == k) ? bv[h][k] : xa;
+#pragma unroll
+        for (int k = 0; k < BDT; ++k) {
+            sxx[k] = MFMA(xa, bv[h][k], sxx[k]);
+            sx1[k] = MFMA(x1v[h], bv[h][k], sx1[k]);
+            syx[k] = MFMA(yv[h], bv[h][k], syx[k]);
+        }
     };
     fetch(t0, 0);
     for (int tb = t0; tb < t1; tb += 8) {
         fetch(tb + 4, 1);
-#pragma unroll
-        for (int k = 0; k < BDT; ++k) acc[k] = MFMA(av[0], bv[0][k], acc[k]);
+        step(0);
         fetch(tb + 8, 0);
-#pragma unroll
-        for (int k = 0; k < BDT; ++k) acc[k] = MFMA(av[1], bv[1][k], acc[k]);      // rows beyond the chunk read as zeros
+        step(1);
     }
 #pragma unroll
     for (int k = 0; k < BDT; ++k)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) P[(size_t)(16 * w + 4 * e + q) * BDP + 16 * k + r] = acc[k][e];
+        for (int e = 0; e < 4; ++e) {
+            const size_t pos = (size_t)(16 * w + 4 * e + q) * BDP + 16 * k + r;
+            P[a.L.oSxx + pos] = sxx[k][e];
+            P[a.L.oSx1x + pos] = sx1[k][e];
+            P[a.L.oSyx + pos] = syx[k][e];
+        }
 }
 
 int launch_stats_big(pyvb_lds* h) {
@@ -297,7 +344,7 @@ int launch_stats_big(pyvb_lds* h) {
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.nchunk = h->nchunk; a.chunk_len = h->chunk_len; a.L = h->L;
     {
         TimedLaunch tl(h, PYVB_K_STATS);
-        hipLaunchKernelGGL(k_stats_big, dim3(h->nchunk, h->N, 3), dim3(512), 0, h->stream, a);
+        hipLaunchKernelGGL(k_stats_big, dim3(h->nchunk, h->N), dim3(512), 0, h->stream, a);
     }
     HIPCHK(hipGetLastError());
     return PYVB_OK;

@@ -433,12 +433,12 @@ static int launch_sweep_t(pyvb_lds* h, const SweepArgs& a) {
 }
 
 int launch_sweep(pyvb_lds* h, int direction, bool keep_x) {
-    if (h->big) {       // both sweeps compute everything and write every state (k_big.hip): no c_t cache, no fused Sxx
+    if (h->big) {       // k_big.hip: every state is written (keep_x ignored), no fused Sxx; the c_t cache as below
         int rc = launch_sweep_big(h, direction);
         if (rc) return rc;
         h->cur = 1 - h->cur;
         h->sxx_valid = false;
-        h->u_valid = false;
+        h->u_valid = (direction == PYVB_FORWARD);
         return PYVB_OK;
     }
     SweepArgs a;

@@ -196,10 +196,18 @@ def _plan_of(node):
 
 
 def _generic_view(node):
-    """The generic (tape) plan that can evaluate single messages / single lower-bound terms for `node`: its own plan
-    if the graph runs node by node, else a mirror of the fused plan's current state."""
-    plan = _plan_of(node)
-    return plan if getattr(plan, "generic", False) else plan.mirror()
+    """The generic (tape) plan that can evaluate single messages / single lower-bound terms / expectations for `node`: its own
+    plan if the graph runs node by node, else a mirror of the fused plan's current state.  Issuing the fused plan's queued
+    requests can itself hand the graph to the node-by-node plan (a request no fused kernel serves): looked at again after
+    the flush."""
+    for _ in range(4):
+        plan = _plan_of(node)
+        if getattr(plan, "generic", False):
+            return plan
+        plan.flush()
+        if node._plan is plan and not getattr(plan, "stale", False):
+            return plan.mirror()
+    raise RuntimeError("the graph kept changing plans")
 
 
 def _messages_of(node, requester):

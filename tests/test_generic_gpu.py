@@ -386,3 +386,35 @@ def test_wishart_noise_with_known_entries_fused_against_node_by_node(monkeypatch
     assert got[1][0, 0] == 0.8 and got[2][1, 2] == 2.0 and got[3][0][0, 0] == 0.0
     for a, b, what in zip(got[:8], ref[:8], ("X", "A", "C", "cov A", "cov C", "Q.qw", "R.qw", "column bounds")):
         _close(a, b, what, 1e-8)
+
+
+def test_expectation_of_a_product_when_the_queue_hands_the_graph_over():
+    """Found by profiles/fuzz_ops.py (round 3): an output is re-observed (the plan is bound anew), a lone column update is
+    queued on the fresh fused plan -- a request only the node-by-node plan serves before the first sweep -- and the next call
+    is pass_down_Ex / pass_down_ExxT of a product.  Issuing the queue hands the graph over while the accessor is looking for
+    its plan; it must follow, not read from the closed handle."""
+    from pyvb_amd import nodes, synth, generic
+    import make_golden as MG
+    T, D, K = 12, 3, 4
+    Y, st0, pri = synth.make_problem(T, D, K, 1, 19)
+
+    def script(g):
+        Xs, As, Cs, Q, R, Ys = g["Xs"], g["As"], g["Cs"], g["Q"], g["R"], g["Ys"]
+        [x.update() for x in Xs]; Xs.reverse(); [x.update() for x in Xs]; Xs.reverse()
+        [a.update() for a in As]; [c.update() for c in Cs]; Q.update(); R.update()
+        Ys[5].observe(Ys[5].qmu * 1.5)
+        As[2].update()
+        return Ys[2].mean_parent.pass_down_Ex(), Ys[2].mean_parent.pass_down_ExxT(), Xs[0]._plan
+
+    ex, exxt, plan = script(MG.build_graph(nodes, Y[0], pri, st0))
+    assert isinstance(plan, generic.GenericPlan)
+    from pyvb_amd import _recognise
+    import pytest as _pt
+    mp = _pt.MonkeyPatch()
+    try:
+        mp.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+        ex2, exxt2, _ = script(MG.build_graph(nodes, Y[0], pri, st0))
+    finally:
+        mp.undo()
+    _close(ex, ex2, "pass_down_Ex after the hand-over", 1e-10)
+    _close(exxt, exxt2, "pass_down_ExxT after the hand-over", 1e-10)
