@@ -86,7 +86,7 @@ def cpu_baseline_and_parity(sample, pri, iters, got_elbo, got_X):
     # the reference itself cannot run on the GPU box (Python 2 source, never shipped); its rate is measured in the build
     # container by profiles/reference_cpu.py at the same D, K and a short chain, and extrapolated (cost is linear in T
     # and in the number of replicates): reported next to the port, from the committed file
-    for tag in ("r02",):
+    for tag in ("r03", "r02"):
         path = os.path.join(REPO, "profiles", tag, "reference_cpu.json")
         if os.path.exists(path):
             base["reference_extrapolated"] = json.load(open(path))
@@ -348,7 +348,7 @@ def main():
     # HBM bytes per launch: PMC passes over this workload, committed with the round's profiles (NOT measured in this run)
     traffic, traffic_source = {}, None
     if (N, T, D, K) == (1024, 10000, 64, 64):
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             tpath = os.path.join(REPO, "profiles", tag, "traffic_pmc.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))

@@ -341,7 +341,7 @@ class GenericPlan(object):
         # set by LDSPlan._demote.  Requests that follow the pattern wait in _buf; anything else runs them node by node.
         self.resume = None
         self._buf = []
-        self._node_span = 0             # doubles of temporaries the largest per-node tape uses
+        self._node_temp = {}            # per-node tape -> doubles of temporaries it uses
         self._pending = []              # update() requests not yet issued: a run of them becomes ONE tape (see _flush_pending)
         self.released = False
         if adopt:
@@ -512,7 +512,7 @@ class GenericPlan(object):
         if key not in self._tapes:
             t = Tape(self)
             res = self._emit_update_gaussian(t, node) if isinstance(node, N.Gaussian) else self._emit_update_noise(t, node)
-            self._node_span = max(self._node_span, t.top - self.temp_base)
+            self._node_temp[key] = t.top - self.temp_base
             self._tapes[key] = (None, t.array(), res)
             if t.marks:
                 self._programs[key] = self._program(t)
@@ -566,23 +566,32 @@ class GenericPlan(object):
                 prog = self._program(t)
                 ops = np.concatenate(parts).astype(np.int32)
                 if prog is not None:
-                    # nodes that share a launch get temporaries of their own
-                    span = self._node_span
+                    # nodes that share a launch get temporaries of their own: node k of a launch is moved up by k times the
+                    # largest temporary area among that launch's nodes
                     blocks, launches = prog
                     starts = np.cumsum([0] + sizes)
                     node_of = {int(a): i for i, a in enumerate(starts[:-1])}
-                    worst = 0
+                    need = 0
+                    plan_ok = True
+                    moves = []
                     for first, count in launches:
                         if count == 1:
                             continue
-                        for k in range(count):
-                            a, n_ = int(blocks[first + k][0]), int(blocks[first + k][1])
-                            i = node_of[a]
-                            assert n_ == sizes[i], "a parallel block is exactly one node's records"
-                            ops[a:a + n_] = self._relocate(ops[a:a + n_], k * span)
-                        worst = max(worst, count)
-                    self.temp_high = max(self.temp_high, self.temp_base + worst * span)
-                    self._programs[key] = prog
+                        idx = [node_of[int(blocks[first + k][0])] for k in range(count)]
+                        assert all(int(blocks[first + k][1]) == sizes[i] for k, i in enumerate(idx)), "a parallel block is exactly one node's records"
+                        span = max(self._node_temp[("update", id(run[i]))] for i in idx)
+                        if self.temp_base + count * span >= (1 << 28):          # the arena is addressed with 32-bit offsets
+                            plan_ok = False
+                            break
+                        moves.append((idx, span))
+                        need = max(need, count * span)
+                    if plan_ok:
+                        for idx, span in moves:
+                            for k, i in enumerate(idx):
+                                a = int(starts[i])
+                                ops[a:a + sizes[i]] = self._relocate(ops[a:a + sizes[i]], k * span)
+                        self.temp_high = max(self.temp_high, self.temp_base + need)
+                        self._programs[key] = prog
                 self._tapes[key] = (None, ops, None)
             self._run(key, None)
 
