@@ -418,3 +418,87 @@ def test_expectation_of_a_product_when_the_queue_hands_the_graph_over():
         mp.undo()
     _close(ex, ex2, "pass_down_Ex after the hand-over", 1e-10)
     _close(exxt, exxt2, "pass_down_ExxT after the hand-over", 1e-10)
+
+
+def _plan_stub():
+    from pyvb_amd import generic as G
+
+    class P(object):
+        temp_base, temp_high = 4096, 4096
+        vals = []
+
+        def const(self, v):
+            self.vals.append(float(v))
+            return G.Ref(len(self.vals) - 1, 1, 1)
+
+        def ones(self, n):
+            o = len(self.vals)
+            self.vals.extend([1.0] * n)
+            return G.Ref(o, n, 1)
+    return P()
+
+
+def _run_both(t, plan, fill, size):
+    """The tape on the device and in the numpy interpreter, same arena."""
+    from oracle import tape_ref as R
+    from pyvb_amd import generic as G
+    arena = np.zeros(size)
+    arena[:len(plan.vals)] = plan.vals
+    for off, arr in fill:
+        arena[off:off + arr.size] = arr.reshape(-1)
+    ref = arena.copy()
+    R.run(ref, t.array())
+    ex = G.DeviceExecutor(size)
+    ex.write(0, arena)
+    ex.run(ex.tape(t.array()))
+    got = ex.read(0, size)
+    ex.close()
+    return got, ref
+
+
+def test_long_tapes_are_staged_in_chunks_and_windows_that_do_not_fit_fall_back():
+    """The interpreter keeps a block's working set in LDS when it fits (k_tape.hip): (a) a tape of 1700 records -- more than
+    the 512 staged at a time -- on a small working set, (b) a tape whose working set (three 80 x 80 matrices and their
+    products) exceeds the window and stays on global memory, (c) a tape with a gather record (addresses that are data: never
+    cached).  All three against the numpy interpreter on the same arena."""
+    from pyvb_amd import generic as G
+    rng = np.random.default_rng(4)
+    # (a)
+    plan = _plan_stub()
+    a = G.Ref(2048, 6, 6); b = G.Ref(2100, 6, 6)
+    A = rng.standard_normal((6, 6)) * 0.3; B = rng.standard_normal((6, 6)) * 0.3
+    t = G.Tape(plan)
+    acc = t.copy(a)
+    for k in range(560):                    # three records per turn
+        g = t.gemm(acc, b)
+        t.axpby(0.5, g, 0.5, a, dst=acc)
+        t.mul(acc, acc) if k % 7 == 0 else t.unary(acc, G.U_NEG)
+    assert len(t.ops) > 3 * 512
+    got, ref = _run_both(t, plan, [(a.off, A), (b.off, B)], plan.temp_high + 64)
+    _close(got[acc.off:acc.off + 36], ref[acc.off:acc.off + 36], "result of the long tape", 1e-11)
+    # (b)
+    plan = _plan_stub()
+    m = 80
+    x, y, z = G.Ref(8192, m, m), G.Ref(8192 + m * m, m, m), G.Ref(8192 + 2 * m * m, m, m)
+    plan.temp_base = plan.temp_high = 8192 + 3 * m * m
+    t = G.Tape(plan)
+    p1 = t.gemm(x, y); p2 = t.gemm(p1, z, tb=True); p3 = t.add(p2, t.transpose(p1))
+    tr = t.trace(p3)
+    mats = [rng.standard_normal((m, m)) / m for _ in range(3)]
+    got, ref = _run_both(t, plan, [(x.off, mats[0]), (y.off, mats[1]), (z.off, mats[2])], plan.temp_high + 64)
+    assert (plan.temp_high - 8192) > 12288      # larger than the LDS window
+    _close(got[p3.off:p3.off + m * m], ref[p3.off:p3.off + m * m], "products beyond the window", 1e-11)
+    _close(got[tr.off:tr.off + 1], ref[tr.off:tr.off + 1], "their trace", 1e-11)
+    _close(ref[p3.off:p3.off + m * m].reshape(m, m), (mats[0] @ mats[1]) @ mats[2].T + (mats[0] @ mats[1]).T, "against numpy", 1e-11)
+    # (c)
+    plan = _plan_stub()
+    s = G.Ref(2048, 5, 5); rows = G.Ref(2100, 2, 1); cols = G.Ref(2110, 3, 1)
+    t = G.Tape(plan)
+    sq = t.gemm(s, s, tb=True)
+    ga = t.gather(sq, rows, cols)
+    out = t.scale(ga, 2.0)
+    t.axpby(1.0, out, 1.0, out, dst=out)
+    S = rng.standard_normal((5, 5))
+    got, ref = _run_both(t, plan, [(s.off, S), (rows.off, np.array([4.0, 1.0])), (cols.off, np.array([0.0, 2.0, 3.0]))], plan.temp_high + 64)
+    _close(got[out.off:out.off + 6], ref[out.off:out.off + 6], "gather inside a tape", 1e-12)
+    _close(ref[out.off:out.off + 6].reshape(2, 3), 4.0 * (S @ S.T)[[4, 1]][:, [0, 2, 3]], "against numpy", 1e-12)
