@@ -417,7 +417,6 @@ int pyvb_lds_get_column_cov(pyvb_lds* h, double* A_cov, double* C_cov) {
 
 int pyvb_lds_set_column_observations(pyvb_lds* h, const double* A_obs, const double* C_obs) {
     ENTER(h);
-    if (h->big) { pyvb_set_error("known entries of A / C with D or K above 64 is not served by the fused kernels"); return PYVB_E_UNSUPPORTED; }
     int rc;
     if ((rc = h2d(h, h->pri.A_obs, A_obs, (size_t)h->D * h->D))) return rc;
     if ((rc = h2d(h, h->pri.C_obs, C_obs, (size_t)h->K * h->D))) return rc;
@@ -449,7 +448,6 @@ int pyvb_lds_set_observations(pyvb_lds* h, const double* Y) {
     for (size_t i = 0; i < n && !missing; ++i) missing = Y[i] != Y[i];
     int rc;
     if (missing) {
-        if (h->big) { pyvb_set_error("outputs with missing entries with D or K above 64 is not served by the fused kernels"); return PYVB_E_UNSUPPORTED; }
         if (!h->Yobs) {
             if ((rc = dev_alloc(&h->Yobs, n))) return rc;
             if ((rc = dev_alloc(&h->Yvar, n))) return rc;
@@ -732,7 +730,6 @@ int pyvb_lds_sweep(pyvb_lds* h, int direction) {
 int pyvb_lds_update_x(pyvb_lds* h, int t) {
     ENTER(h);
     ARGCHK(t >= 0 && t < h->T, "t out of range");
-    if (h->big) { pyvb_set_error("a single X_t.update() with D or K above 64 is not served by the fused kernels"); return PYVB_E_UNSUPPORTED; }
     int rc = ensure_gains(h);
     if (rc) return rc;
     if ((rc = launch_step(h, t))) return rc;

@@ -164,6 +164,7 @@ int launch_elbo_sum(pyvb_lds* h, double* out = nullptr, hipStream_t stream = nul
 // k_big.hip
 int launch_prep_big(pyvb_lds* h);
 int launch_sweep_big(pyvb_lds* h, int direction);
+int launch_step_big(pyvb_lds* h, int t);
 int launch_stats_big(pyvb_lds* h);
 int launch_cols_big(pyvb_lds* h, int which, int c0, int c1, int fuse);
 // k_wishart.hip

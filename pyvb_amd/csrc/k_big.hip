@@ -15,8 +15,8 @@
 //                 under diagonal noise and diagonal column priors), <M> as [col][row] in LDS.
 // Reference methods as in the small kernels: Gaussian.update gaussian.py:102-123, Multiplication.pass_up_m1_m2 node.py:182-232,
 // hstack.pass_up_m1_m2 nodes_todo.py:43-62, Gamma / DiagonalGamma.update nodes_todo.py:130-138, :187-190.
-// Diagonal-Gamma and Gamma noise, fully observed outputs, no known entries: the other variants stay on the 64-wide kernels
-// (larger graphs of those kinds run node by node on the generic plan).
+// Diagonal-Gamma and Gamma noise, fully observed outputs (known entries of A / C are served): the other variants stay on the
+// 64-wide kernels (larger graphs of those kinds run node by node on the generic plan).
 #include "params.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -262,6 +262,50 @@ int launch_sweep_big(pyvb_lds* h, int direction) {
         else if (mode == 2) hipLaunchKernelGGL(k_sweep_big<2>, dim3(h->N), dim3(256), lds, h->stream, a);
         else hipLaunchKernelGGL(k_sweep_big<0>, dim3(h->N), dim3(256), lds, h->stream, a);
     }
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+// Xs[t].update() alone, in place in the current buffer (k_sweep.hip: k_step), thread = row
+struct BigStepArgs {
+    double* X; const double* Y; const double* gains; const double *A_mean, *C_mean;
+    int N, T, D, K, t;
+    Layout L;
+};
+
+__global__ void __launch_bounds__(128) k_step_big(BigStepArgs a) {
+    __shared__ double vs[BDP];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int T = a.T, D = a.D, K = a.K, t = a.t;
+    const Layout& L = a.L;
+    const double* g = a.gains + (size_t)n * L.gains_total;
+    double* X = a.X + (size_t)n * T * BDP;
+    const double* y = a.Y + ((size_t)n * T + t) * K;
+    const int cls = (t == 0) ? 0 : (t == T - 1 ? 2 : 1);
+    if (cls != 1) {
+        const double* nbr = X + (size_t)(cls == 0 ? 1 : T - 2) * BDP;
+        const double s = big_boundary(cls == 0, g, L, a.A_mean + (size_t)n * D * D, a.C_mean + (size_t)n * K * D, D, K, tid,
+                                      [&](int j) { return nbr[xpos(j)]; }, y, vs);
+        X[(size_t)t * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
+        return;
+    }
+    // interior node: rows of F, B, G picked out of the MFMA operand blocks (the rare path)
+    double s = 0.0;
+    if (tid < D) {
+        for (int j = 0; j < D; ++j) s += g[L.oFn + pos_nat(tid, j, BDS)] * X[(size_t)(t - 1) * BDP + xpos(j)];
+        for (int j = 0; j < D; ++j) s += g[L.oBn + pos_nat(tid, j, BDS)] * X[(size_t)(t + 1) * BDP + xpos(j)];
+        for (int k = 0; k < K; ++k) s += g[L.oGp + pos_perm(tid, k, BDS)] * y[k];
+    }
+    __syncthreads();            // every thread has read its neighbours' rows (t - 1, t + 1 are other rows: no hazard; kept for clarity)
+    X[(size_t)t * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
+}
+
+int launch_step_big(pyvb_lds* h, int t) {
+    BigStepArgs a;
+    a.X = h->X[h->cur]; a.Y = h->Y; a.gains = h->gains; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
+    a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.t = t; a.L = h->L;
+    TimedLaunch tl(h, PYVB_K_STEP);
+    hipLaunchKernelGGL(k_step_big, dim3(h->N), dim3(128), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
@@ -673,6 +717,7 @@ __global__ void __launch_bounds__(128) k_cols_big(ParamArgs a) {
     double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
     const double* pm = WHICH == 0 ? a.pri.A_pm : a.pri.C_pm;    // [row][col]
     const double* pp = WHICH == 0 ? a.pri.A_pp : a.pri.C_pp;    // [col][row]
+    const double* obs = WHICH == 0 ? a.pri.A_obs : a.pri.C_obs; // [row][col], NaN = not known
     const double* mo = a.mom + (size_t)n * mom_total(D, K);
     const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
     const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
@@ -696,11 +741,18 @@ __global__ void __launch_bounds__(128) k_cols_big(ParamArgs a) {
         }
         const double p0 = pp[(size_t)i * rows + lr];
         const double prec = p0 + lam * gv[i];                                           // qprec  gaussian.py:117
-        const double var = 1.0 / prec;                                                  // qcov   gaussian.py:118-119
-        const double val = (p0 * pm[(size_t)lr * D + i] + lam * (H[(size_t)lr * D + i] - (acc0 + acc1))) * var;   // qmu :122-123
+        double var = 1.0 / prec;                                                        // qcov   gaussian.py:118-119
+        double val = (p0 * pm[(size_t)lr * D + i] + lam * (H[(size_t)lr * D + i] - (acc0 + acc1))) * var;   // qmu :122-123
+        // known entries (Gaussian.observe on a column, LDS_knowns_in_A.py:73-74): conditioning a diagonal Gaussian on them
+        // (gaussian.py:125-134) pins those entries and leaves the others alone; a column whose entries are all known is
+        // never changed (gaussian.py:109-110)
+        const double ob = obs[(size_t)lr * D + i];
+        const bool known = live && (ob == ob);
+        if (known) { val = ob; var = 0.0; }
         const double lp = bsum128(live ? log(prec) : 0.0, red);                         // also the barrier before Mb / gv change
+        const int nknown = (int)bsum128(known ? 1.0 : 0.0, red);
         if (live) { Mb[i * BDP + tid] = val; V[(size_t)i * rows + tid] = var; }
-        if (tid == 0) qld[i] = 0.5 / (0.5 * lp);                                        // quirk Q1, gaussian.py:120
+        if (tid == 0 && nknown < rows) qld[i] = 0.5 / (0.5 * lp);                       // quirk Q1, gaussian.py:120: of the whole precision
     }
     __syncthreads();
     if (a.c0 < a.c1) {

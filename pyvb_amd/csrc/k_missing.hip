@@ -24,67 +24,101 @@ struct MissArgs {
     int N, T, K, D, DP;
 };
 
+// One wavefront per row; a lane handles entries lane and lane + 64 (K <= 128: the second shape class, k_big.hip).
 __global__ void __launch_bounds__(256) k_missing_init(MissArgs a) {
-    const int n = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), k = threadIdx.x & 63, K = a.K;
+    const int n = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, K = a.K;
     if (t >= a.T) return;
     const size_t row = ((size_t)n * a.T + t) * K;
-    const double ob = k < K ? a.Yobs[row + k] : 0.0;
-    const bool any = __ballot(k < K && !(ob == ob)) != 0;
-    if (k >= K) return;
-    a.Y[row + k] = any ? (a.Yq0 ? a.Yq0[row + k] : 0.0) : ob;
-    a.Yvar[row + k] = any ? (a.Yrowvar0 ? a.Yrowvar0[(size_t)n * a.T + t] : 1.0) : 0.0;
-    if (k == 0) { a.Yqld[(size_t)n * a.T + t] = nan(""); if (a.Yld) a.Yld[(size_t)n * a.T + t] = nan(""); }
+    double ob[2];
+    bool miss = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        ob[h] = k < K ? a.Yobs[row + k] : 0.0;
+        miss = miss || (k < K && !(ob[h] == ob[h]));
+    }
+    const bool any = __ballot(miss) != 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        if (k >= K) continue;
+        a.Y[row + k] = any ? (a.Yq0 ? a.Yq0[row + k] : 0.0) : ob[h];
+        a.Yvar[row + k] = any ? (a.Yrowvar0 ? a.Yrowvar0[(size_t)n * a.T + t] : 1.0) : 0.0;
+    }
+    if (lane == 0) { a.Yqld[(size_t)n * a.T + t] = nan(""); if (a.Yld) a.Yld[(size_t)n * a.T + t] = nan(""); }
 }
 
 __global__ void __launch_bounds__(256) k_impute(MissArgs a) {
-    const int n = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), k = threadIdx.x & 63, K = a.K, D = a.D;
+    const int n = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, K = a.K, D = a.D;
     if (t >= a.T) return;
     const size_t row = ((size_t)n * a.T + t) * K;
-    const double ob = k < K ? a.Yobs[row + k] : 0.0;
-    const bool miss = k < K && !(ob == ob);
-    if (__ballot(miss) == 0) return;                    // fully observed: never updates (gaussian.py:109-110)
-    const double rbar = k < K ? a.R_a[(size_t)n * K + k] / a.R_b[(size_t)n * K + k] : 1.0;
-    double lr = k < K ? 0.5 * log(rbar) : 0.0;          // sum log diag chol(<R>)
+    double ob[2], rbar[2];
+    bool miss[2];
+    double lr = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        ob[h] = k < K ? a.Yobs[row + k] : 0.0;
+        miss[h] = k < K && !(ob[h] == ob[h]);
+        rbar[h] = k < K ? a.R_a[(size_t)n * K + k] / a.R_b[(size_t)n * K + k] : 1.0;
+        lr += k < K ? 0.5 * log(rbar[h]) : 0.0;         // sum log diag chol(<R>)
+    }
+    if (__ballot(miss[0] || miss[1]) == 0) return;      // fully observed: never updates (gaussian.py:109-110)
     lr = wave_sum(lr);
-    if (k == 0) a.Yqld[(size_t)n * a.T + t] = 0.5 / lr;    // gaussian.py:120 (quirk Q1)
-    if (k >= K) return;
-    if (miss) {
-        const double* x = a.X + ((size_t)n * a.T + t) * a.DP;
-        const double* c = a.C_mean + ((size_t)n * K + k) * D;
-        double m = 0.0;
-        for (int j = 0; j < D; ++j) m += c[j] * x[xpos(j)];
-        a.Y[row + k] = m;
-        a.Yvar[row + k] = 1.0 / rbar;
-    } else {
-        a.Y[row + k] = ob;
-        a.Yvar[row + k] = 0.0;
+    if (lane == 0) a.Yqld[(size_t)n * a.T + t] = 0.5 / lr;    // gaussian.py:120 (quirk Q1)
+    const double* x = a.X + ((size_t)n * a.T + t) * a.DP;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        if (k >= K) continue;
+        if (miss[h]) {
+            const double* c = a.C_mean + ((size_t)n * K + k) * D;
+            double m = 0.0;
+            for (int j = 0; j < D; ++j) m += c[j] * x[xpos(j)];
+            a.Y[row + k] = m;
+            a.Yvar[row + k] = 1.0 / rbar[h];
+        } else {
+            a.Y[row + k] = ob[h];
+            a.Yvar[row + k] = 0.0;
+        }
     }
 }
 
 __global__ void __launch_bounds__(256) k_syy_missing(MissArgs a) {
-    __shared__ double red[4][65];
-    const int n = blockIdx.x, w = threadIdx.x >> 6, k = threadIdx.x & 63, K = a.K, T = a.T;
+    __shared__ double red[4][130];
+    const int n = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, K = a.K, T = a.T;
     const double* Y = a.Y + (size_t)n * T * K;
     const double* Yo = a.Yobs + (size_t)n * T * K;
     const double* Yv = a.Yvar + (size_t)n * T * K;
-    double s = 0.0, ent = 0.0;
+    double s[2] = {0.0, 0.0}, ent = 0.0;
     for (int t = w; t < T; t += 4) {
-        const bool live = k < K;
-        const double y = live ? Y[(size_t)t * K + k] : 0.0, v = live ? Yv[(size_t)t * K + k] : 0.0, ob = live ? Yo[(size_t)t * K + k] : 0.0;
-        const bool miss = live && !(ob == ob);
-        s += y * y + v;
-        const int nm = __popcll(__ballot(miss));
+        bool miss[2];
+        double lv = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = lane + 64 * h;
+            const bool live = k < K;
+            const double y = live ? Y[(size_t)t * K + k] : 0.0, v = live ? Yv[(size_t)t * K + k] : 0.0, ob = live ? Yo[(size_t)t * K + k] : 0.0;
+            miss[h] = live && !(ob == ob);
+            s[h] += y * y + v;
+            lv += miss[h] ? log(v) : 0.0;
+        }
+        const int nm = __popcll(__ballot(miss[0])) + __popcll(__ballot(miss[1]));
         if (nm == 0) continue;                          // wave-uniform
-        const double lv = wave_sum(miss ? log(v) : 0.0);
+        lv = wave_sum(lv);
         if (nm == K) ent += -0.5 * K * LN2PI - 0.5 * a.Yqld[(size_t)n * T + t] - 0.5 * K;        // gaussian.py:145-147
         else ent += 0.5 * nm * LN2PI - 0.5 * lv - 0.5 * nm;                                        // gaussian.py:148-150
     }
-    red[w][k] = s;
-    if (k == 0) red[w][64] = ent;
+    red[w][lane] = s[0]; red[w][64 + lane] = s[1];
+    if (lane == 0) red[w][128] = ent;
     __syncthreads();
     if (w == 0) {
-        if (k < K) a.Syy[(size_t)n * K + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-        if (k == 0) a.Yent[n] = red[0][64] + red[1][64] + red[2][64] + red[3][64];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = lane + 64 * h;
+            if (k < K) a.Syy[(size_t)n * K + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        }
+        if (lane == 0) a.Yent[n] = red[0][128] + red[1][128] + red[2][128] + red[3][128];
     }
 }
 

@@ -200,7 +200,9 @@ __global__ void __launch_bounds__(256) k_elbo_sum(SumArgs a) {
 }
 
 // Gaussian.observe on fully known columns (gaussian.py:97-100): value in, covariance zero, for every replicate
-__global__ void __launch_bounds__(64) k_observe(ParamArgs a) {
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_observe(ParamArgs a) {
+    __shared__ double red[2];
     const int WHICH = blockIdx.y, n = blockIdx.x, lane = threadIdx.x, D = a.D;
     const int rows = WHICH == 0 ? a.D : a.K;
     double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(64) k_observe(ParamArgs a) {
     const double* obs = WHICH == 0 ? a.pri.A_obs : a.pri.C_obs;
     for (int i = 0; i < D; ++i) {
         const double ob = lane < rows ? obs[(size_t)lane * D + i] : 0.0;
-        const int nknown = (int)wave_sum((lane < rows && ob == ob) ? 1.0 : 0.0);
+        const int nknown = (int)blk_sum<NW>((lane < rows && ob == ob) ? 1.0 : 0.0, red);
         if (nknown == rows && lane < rows) { M[(size_t)lane * D + i] = ob; V[(size_t)i * rows + lane] = 0.0; }
     }
 }
@@ -225,7 +227,8 @@ ParamArgs make_args(pyvb_lds* h) {
 
 int launch_observe(pyvb_lds* h) {
     ParamArgs a = make_args(h);
-    hipLaunchKernelGGL(k_observe, dim3(h->N, 2), dim3(64), 0, h->stream, a);
+    if (h->big) hipLaunchKernelGGL(k_observe<2>, dim3(h->N, 2), dim3(128), 0, h->stream, a);
+    else hipLaunchKernelGGL(k_observe<1>, dim3(h->N, 2), dim3(64), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

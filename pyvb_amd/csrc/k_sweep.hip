@@ -492,6 +492,7 @@ int launch_permute(pyvb_lds* h, const double* src, double* dst, int to_internal)
 }
 
 int launch_step(pyvb_lds* h, int t) {
+    if (h->big) return launch_step_big(h, t);
     StepArgs a;
     a.X = h->X[h->cur]; a.Y = h->Y; a.gains = h->gains; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
     a.QA = h->dense ? h->QA : nullptr; a.RC = h->dense ? h->RC : nullptr;

@@ -181,9 +181,38 @@ def test_stagewise_vs_oracle_beyond_64(T, D, K, N, kind):
     _stagewise(Y, st0, pri, iters=3)
 
 
-def test_beyond_64_iterate_matches_the_staged_calls_and_refuses_what_it_does_not_serve():
-    """pyvb_lds_iterate on the 128-wide kernels equals the separate calls; variants the big kernels do not serve (Wishart noise,
-    known entries, missing outputs, a single X_t.update()) are refused with a status, never computed wrongly."""
+@pytest.mark.parametrize("T,D,K,N,kind", [(25, 40, 100, 2, "diagonal_gamma"), (20, 72, 66, 1, "gamma")])
+def test_outputs_with_missing_entries_beyond_64(T, D, K, N, kind):
+    """Y with NaN (gaussian.py:90-96) where K (or D) exceeds 64: the output kernels handle two entries per lane."""
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=710 + T)
+    rng = np.random.default_rng(T + K)
+    mask = rng.random((N, T, K)) < 0.15
+    mask[:, 1] = True; mask[:, T // 2] = True; mask[:, 0, 0] = True; mask[:, 3] = False
+    Y = np.where(mask, np.nan, Y)
+    st0["Yq"] = rng.standard_normal((N, T, K)); st0["Yrowvar"] = 1.0 / rng.uniform(0.5, 1.5, size=(N, T))
+    pri["noise"] = kind
+    if kind == "gamma":
+        for k in ("Q_a0", "Q_b0", "R_a0", "R_b0"):
+            pri[k] = np.float64(1e-3)
+    _stagewise(Y, st0, pri, iters=3)
+
+
+def test_known_matrix_entries_beyond_64():
+    """Known entries of A and C (LDS_knowns_in_A.py) on the 128-wide kernels: partially known, fully known and free columns."""
+    T, D, K, N = 30, 70, 90, 2
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=43)
+    rng = np.random.default_rng(2)
+    A_obs = np.where(rng.random((D, D)) < 0.1, rng.standard_normal((D, D)) * 0.2, np.nan)
+    C_obs = np.where(rng.random((K, D)) < 0.1, rng.standard_normal((K, D)), np.nan)
+    A_obs[:, 3] = np.linspace(-0.1, 0.1, D); C_obs[:, 0] = np.nan; C_obs[:, 69] = rng.standard_normal(K)
+    pri["A_obs"], pri["C_obs"] = A_obs, C_obs
+    _stagewise(Y, st0, pri, iters=3)
+
+
+def test_beyond_64_iterate_matches_the_staged_calls_and_single_updates():
+    """pyvb_lds_iterate on the 128-wide kernels equals the separate calls; a sweep spelled as T single X_t.update() calls
+    (pyvb_lds_update_x: the time-0 class, interior nodes, the last node) equals the oracle's; Wishart noise above 64
+    dimensions is refused at creation."""
     from pyvb_amd import _capi
     from pyvb_amd.lds import LDSBatch
     T, D, K, N = 40, 72, 90, 2
@@ -198,15 +227,16 @@ def test_beyond_64_iterate_matches_the_staged_calls_and_refuses_what_it_does_not
     assert np.allclose(a.elbo(), b.elbo(), rtol=1e-12)
     hist = a.elbo_history(2)
     assert np.allclose(hist[-1], a.elbo().sum(0), rtol=1e-12)
-    with pytest.raises(_capi.PyvbHipError):
-        b.update_x(3)
-    Ynan = Y.copy(); Ynan[0, 4, 2] = np.nan
-    with pytest.raises(_capi.PyvbHipError):
-        b.set_observations(Ynan)
-    obs = np.full((D, D), np.nan); obs[1, 2] = 0.5
-    with pytest.raises(_capi.PyvbHipError):
-        b.set_column_observations(obs, np.full((K, D), np.nan))
     a.close(); b.close()
+    c = _batch(Y, st0, pri)
+    st = O.expand_state(st0, pri, T)
+    O.sweep(st, pri, Y, "forward"); c.sweep("forward")
+    O.sweep(st, pri, Y, "backward"); c.sweep("backward")
+    S = O.statistics(st, Y); O.update_A(st, pri, S); c.update_A()
+    for t in list(range(T)) + [T - 1, 5, 0]:
+        O.update_x(st, pri, Y, t); c.update_x(t)
+    _close(c.get_state(("X",))["X"], st["X"], "X after single updates of every node")
+    c.close()
     with pytest.raises(_capi.PyvbHipError):
         LDSBatch(1, 10, 65, 4, "wishart")
 
