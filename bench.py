@@ -322,14 +322,17 @@ def main():
     sxx_share = (DT * (DT + 1) / 2.0) / (DT * DT)           # symmetric: upper tiles only
     nt = float(N) * T
     if D > 64 or K > 64:
-        # the second shape class (pyvb_amd/csrc/k_big.hip): a workgroup per replicate, both dimensions padded to 128; both sweeps
-        # compute all three products, the statistics are three full 128-wide products
+        # the second shape class (pyvb_amd/csrc/k_big.hip): a workgroup per replicate, both dimensions padded to 128.  G y_t is a
+        # batched product of its own (k_gy_big), the forward sweep adds the two recurrence products, the backward sweep behind
+        # it reads c_t and runs one; the statistics are three full 128-wide products
         P = 128
         work = {
-            "sweep_fwd": {"kernel": "k_sweep_big(BigSweepArgs)", "executed_flops": nt * (4 * P * P + 2 * P * P),
-                          "algorithmic_flops": nt * (4 * D * D + 2 * D * K), "algorithmic_bytes": nt * 8 * (K + 2 * D)},
-            "sweep_bwd": {"kernel": "k_sweep_big(BigSweepArgs)", "executed_flops": nt * (4 * P * P + 2 * P * P),
-                          "algorithmic_flops": nt * (4 * D * D + 2 * D * K), "algorithmic_bytes": nt * 8 * (K + 2 * D)},
+            "sweep_fwd": {"kernel": "k_sweep_big<3>(BigSweepArgs)", "executed_flops": nt * 4 * P * P,
+                          "algorithmic_flops": nt * 4 * D * D, "algorithmic_bytes": nt * 8 * (4 * P)},
+            "gy": {"kernel": "k_gy_big(BigGyArgs)", "executed_flops": nt * 2 * P * P,
+                   "algorithmic_flops": nt * 2 * D * K, "algorithmic_bytes": nt * 8 * (K + P)},
+            "sweep_bwd": {"kernel": "k_sweep_big<2>(BigSweepArgs)", "executed_flops": nt * 2 * P * P,
+                          "algorithmic_flops": nt * (4 * D * D + 2 * D * K), "algorithmic_bytes": nt * 8 * (2 * P)},
             "stats": {"kernel": "k_stats_big(BigStatsArgs)", "executed_flops": nt * 6 * P * P,
                       "algorithmic_flops": nt * (4 * D * D + 2 * D * K + 2 * K), "algorithmic_bytes": 0.0},
         }

@@ -55,7 +55,7 @@ enum { PYVB_FORWARD = 0, PYVB_BACKWARD = 1 };
 
 /* which kernels pyvb_lds_timing_get() reports on */
 enum { PYVB_K_PREP = 0, PYVB_K_SWEEP_FWD = 1, PYVB_K_STATS = 2, PYVB_K_PARAMS = 3, PYVB_K_STEP = 4,
-       PYVB_K_SWEEP_BWD = 5, PYVB_K_ELBO = 6, PYVB_K_COUNT = 7 };
+       PYVB_K_SWEEP_BWD = 5, PYVB_K_ELBO = 6, PYVB_K_GY = 7 /* 128-wide class: G y_t ahead of a sweep */, PYVB_K_COUNT = 8 };
 
 const char* pyvb_last_error(void);
 int pyvb_version(void);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PYVB_HIP_LIB") or os.path.join(_HERE, "libpyvb_hip.so
 OK, E_ARG, E_HIP, E_LINALG, E_STALE, E_RCCL, E_UNSUPPORTED = range(7)
 NOISE_DIAGONAL_GAMMA, NOISE_GAMMA, NOISE_WISHART = 0, 1, 2
 FORWARD, BACKWARD = 0, 1
-K_PREP, K_SWEEP_FWD, K_STATS, K_PARAMS, K_STEP, K_SWEEP_BWD, K_ELBO = range(7)
+K_PREP, K_SWEEP_FWD, K_STATS, K_PARAMS, K_STEP, K_SWEEP_BWD, K_ELBO, K_GY = range(8)
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)

@@ -66,16 +66,83 @@ __device__ __forceinline__ double big_boundary(bool first, const double* g, cons
     return s;
 }
 
-// MODE (as k_sweep.hip): the parameters are frozen between the two sweeps of an iteration, and the backward update
+// G y_t of every interior node as a batched product of its own, into U (accumulator order, as the sweep reads it): 16 time
+// steps are the 16 MFMA columns, wavefront w forms the row tiles 2w, 2w+1 with its rows of G (A operands, permuted k order of
+// k_prep) in registers; y rows are fetched a block ahead.  Taking this product out of the sweep leaves the sequential kernel
+// two products per step and no operand in LDS except the shared state.
+struct BigGyArgs {
+    const double* Y; const double* gains; double* U; double* trash;
+    int N, T, K, nblk;          // nblk: blocks of 16 time steps per workgroup
+    Layout L;
+};
+
+// (Eight wavefronts with one row tile each, two per SIMD, were slower: 11.0 against 7.3 ms -- every wavefront fetches all of y.)
+template <bool YVEC>     // YVEC: K even, a lane's two k of a step are one 16-byte load
+__global__ void __launch_bounds__(256) k_gy_big(BigGyArgs a) {
+    constexpr int NT = 2;       // row tiles per wavefront
+    const int n = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int T = a.T, K = a.K;
+    const double* g = a.gains + (size_t)n * a.L.gains_total + a.L.oGp;
+    const double* Yn = a.Y + (size_t)n * T * K;
+    double* Un = a.U + (size_t)n * T * BDP;
+    double* const trash = a.trash + (size_t)n * 512 + 256;
+    double gr[NT][BDS];
+#pragma unroll
+    for (int mm = 0; mm < NT; ++mm)
+#pragma unroll
+        for (int s = 0; s < BDS; ++s) gr[mm][s] = g[((size_t)(NT * w + mm) * BDS + s) * 64 + lane];
+    auto load_y = [&](d2 (&yv)[BDS / 2], int t) {
+        const double* yp = Yn + (size_t)(t <= T - 2 ? t : 1) * K;
+#pragma unroll
+        for (int i = 0; i < BDS / 2; ++i) {
+            const int d0 = 8 * i + 2 * q;
+            if constexpr (YVEC) yv[i] = *reinterpret_cast<const d2*>(yp + (d0 + 1 < K ? d0 : K - 2));      // padded k meet zero gains
+            else { yv[i][0] = yp[d0 < K ? d0 : K - 1]; yv[i][1] = yp[d0 + 1 < K ? d0 + 1 : K - 1]; }
+        }
+    };
+    auto block = [&](const d2 (&yv)[BDS / 2], int t) {
+        d4 acc[NT];
+#pragma unroll
+        for (int mm = 0; mm < NT; ++mm) {       // one dependent chain per accumulator (profiles/r01/microbench_f64.txt)
+            acc[mm] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < BDS; ++s) acc[mm] = MFMA(gr[mm][s], yv[s >> 1][s & 1], acc[mm]);
+        }
+        double* ur = (t <= T - 2) ? Un + (size_t)t * BDP : trash;
+#pragma unroll
+        for (int mm = 0; mm < NT; ++mm) *reinterpret_cast<d4*>(ur + ((NT * w + mm) * 4 + q) * 4) = acc[mm];
+    };
+    // two operand sets: the rows of a block are in flight while the block before it is multiplied (nblk is even)
+    d2 ya[BDS / 2], yb[BDS / 2];
+    const int t0 = 1 + blockIdx.x * a.nblk * 16 + c;
+    load_y(ya, t0);
+    for (int b = 0; b < a.nblk; b += 2) {
+        const int t = t0 + b * 16;
+        if (t - c > T - 2) break;
+        load_y(yb, t + 16);
+        __builtin_amdgcn_sched_barrier(0);
+        block(ya, t);
+        __builtin_amdgcn_sched_barrier(0);
+        load_y(ya, t + 32);
+        __builtin_amdgcn_sched_barrier(0);
+        block(yb, t + 16);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// The sweep proper.  The parameters are frozen between the two sweeps of an iteration, and the backward update
 //   mu_t <- B mu_{t+1}(new) + F mu_{t-1}(forward result) + G y_t
-// contains c_t = F mu_{t-1} + G y_t, which the forward sweep has just formed.  MODE 1 (forward) stores c_t, MODE 2 (the backward
-// sweep that follows directly) reads it back and runs ONE product per step instead of three; MODE 0 computes everything.
+// contains c_t = F mu_{t-1} + G y_t, which the forward sweep has just formed (k_sweep.hip).
+//   MODE 3  U holds G y_t (k_gy_big ran just before): R mu (new neighbour) and I mu (old neighbour) are added; a forward
+//           sweep stores c_t back into U, in place.  In the warm-up a column reads rows of the segment before it: it does so at
+//           loop indices j < 0, the owner overwrites them at j >= 0, and a barrier separates the steps.
+//   MODE 2  the backward sweep directly behind a forward one: reads c_t and runs ONE product per step.
+// The state of the 16 segments lives in LDS only, in two buffers (a step reads one and writes the other: one barrier per step).
 template <int MODE>
 __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
     extern __shared__ double lds[];
-    double* gl = lds;                               // [4 waves][2 tiles][BDS][64]: G as A operands, this wavefront's rows
-    double* xbuf = gl + 4 * 2 * BDS * 64;           // [BDS][64]: the state of the 16 segments, B-operand order
-    double* xs = xbuf + BDS * 64;                   // [128] boundary state exchange
+    double* xb0 = lds;                              // 2 x [BDS][64]: the state of the 16 segments, B-operand order
+    double* xs = lds + 2 * BDS * 64;                // [128] boundary state exchange
     double* vs = xs + BDP;                          // [128] boundary scratch
     const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
     const int T = a.T, D = a.D, K = a.K;
@@ -86,14 +153,12 @@ __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
     const double* Xo = a.Xold + (size_t)n * T * BDP;
     double* Xn = a.Xnew + (size_t)n * T * BDP;
     const double* Yn = a.Y + (size_t)n * T * K;
-    const bool yvec = (K & 1) == 0;
 
     // ---- this wavefront's rows of the recurrence matrices
     double rn[2][BDS], ip[2][BDS];
     {
         const double* Rn = g + (fwd ? L.oFn : L.oBn);
         const double* Ip = g + (fwd ? L.oBn : L.oFn);
-        const double* Gp = g + L.oGp;
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
@@ -101,7 +166,6 @@ __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
                 const size_t o = ((size_t)(2 * w + mm) * BDS + s) * 64 + lane;
                 rn[mm][s] = Rn[o];
                 ip[mm][s] = MODE == 2 ? 0.0 : Ip[o];
-                if constexpr (MODE != 2) gl[((w * 2 + mm) * BDS + s) * 64 + lane] = Gp[o];
             }
     }
     const int Tint = T - 2;
@@ -126,111 +190,90 @@ __global__ void __launch_bounds__(256) k_sweep_big(BigSweepArgs a) {
         const int cL = c * Lseg;
         const int jc = -(J < cL ? J : cL);                                   // first loop index of this column
         const int jstart = -((J < 15 * Lseg) ? J : 15 * Lseg);               // of the workgroup
-        // state of the 16 segments, B-operand order, in LDS only (xbuf[4m + r][lane] = row 16m + 4r + q of column c): the
-        // registers go to the matrices and to the operands fetched a step ahead
+        // xb[4m + r][lane] = row 16m + 4r + q of column c: the registers go to the matrices and to the operands fetched a step ahead
         if (w == 0) {
 #pragma unroll
             for (int m = 0; m < BDT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xbuf[(4 * m + r) * 64 + lane] = (jc == -cL) ? xs[16 * m + 4 * r + q] : 0.0;
+                for (int r = 0; r < 4; ++r) xb0[(4 * m + r) * 64 + lane] = (jc == -cL) ? xs[16 * m + 4 * r + q] : 0.0;
         }
         __syncthreads();
         const int tbase = fwd ? (1 + cL) : (T - 2 - cL);
         const int tsafe = fwd ? 1 : T - 2;
         auto active = [&](int j) { int tt = cL + j; return j >= jc && j < Lseg && tt < Tint; };
         double* const trash = a.trash + (size_t)n * 512;
-        // Operands of a step -- y_t in the permuted k order of k_sweep.hip and the old neighbour mean -- are loaded one step
-        // ahead, each set into the registers the step has just finished with: y right after the G y products (it has the R and
-        // I products to arrive), the neighbour right after the I products (it has the next step's G y and R products).  Loads
-        // are unconditional: an inactive column reads a valid row (tsafe) and its result is discarded by the select.
-        d2 yv[BDS / 2];
-        d4 mo[BDT];
-        auto load_y = [&](int j) {
-            const double* yp = Yn + (size_t)(active(j) ? tbase + sgn * j : tsafe) * K;
-#pragma unroll
-            for (int i = 0; i < BDS / 2; ++i) {
-                const int d0 = 8 * i + 2 * q;
-                if (yvec) yv[i] = *reinterpret_cast<const d2*>(yp + (d0 + 1 < K ? d0 : K - 2));      // padded k meet zero gains
-                else { yv[i][0] = yp[d0 < K ? d0 : K - 1]; yv[i][1] = yp[d0 + 1 < K ? d0 + 1 : K - 1]; }
-            }
-        };
-        auto load_o = [&](int j) {
+        // Operands of a step -- this wavefront's rows of U and the old neighbour mean -- are loaded one step ahead, each set into
+        // the registers the step has just finished with.  Loads are unconditional: an inactive column reads a valid row (tsafe)
+        // and its result is discarded by the select.
+        auto load_o = [&](d4 (&mo)[BDT], int j) {
             const double* op = Xo + (size_t)((active(j) ? tbase + sgn * j : tsafe) + sgn) * BDP;
 #pragma unroll
             for (int m = 0; m < BDT; ++m) mo[m] = *reinterpret_cast<const d4*>(op + (m * 4 + q) * 4);
         };
         double* const Un = a.U + (size_t)n * T * BDP;
-        d4 cv[2];                       // MODE 2: this wavefront's rows of c_t, a step ahead
+        d4 cv[2];
         auto load_c = [&](int j) {
             const double* cp = Un + (size_t)(active(j) ? tbase + sgn * j : tsafe) * BDP;
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) cv[mm] = *reinterpret_cast<const d4*>(cp + ((2 * w + mm) * 4 + q) * 4);
         };
-        if constexpr (MODE == 2) load_c(jstart);
-        else { load_y(jstart); load_o(jstart); }
-        for (int j = jstart; j < Lseg; ++j) {
+        // the old neighbour's rows sit in two register sets: the set of step j + 1 is requested before the products of step j
+        d4 moA[BDT], moB[BDT];
+        auto step = [&](int j, const double* xr, double* xw, const d4 (&mo)[BDT], d4 (&mo_next)[BDT]) {
             const bool act = active(j);
-            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-            if constexpr (MODE == 2) {
-                acc[0] = cv[0]; acc[1] = cv[1];
-                __builtin_amdgcn_sched_barrier(0);
-                load_c(j + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                // G y_t
-#pragma unroll
-                for (int s = 0; s < BDS; ++s)
-#pragma unroll
-                    for (int mm = 0; mm < 2; ++mm)
-                        acc[mm] = MFMA(gl[((w * 2 + mm) * BDS + s) * 64 + lane], yv[s >> 1][s & 1], acc[mm]);
-                __builtin_amdgcn_sched_barrier(0);
-                load_y(j + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            d4 acc[2] = {cv[0], cv[1]};
+            __builtin_amdgcn_sched_barrier(0);
+            load_c(j + 1);
+            if constexpr (MODE != 2) load_o(mo_next, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
             // R mu_{t-dir} (new): the segments' state
-#pragma unroll
-            for (int s = 0; s < BDS; ++s)
-#pragma unroll
-                for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(rn[mm][s], xbuf[s * 64 + lane], acc[mm]);
-            if constexpr (MODE == 1) {          // c_t for the backward sweep, this wavefront's rows
-                double* ur = (act && j >= 0) ? Un + (size_t)(tbase + sgn * j) * BDP : trash + 256;
-#pragma unroll
-                for (int mm = 0; mm < 2; ++mm) *reinterpret_cast<d4*>(ur + ((2 * w + mm) * 4 + q) * 4) = acc[mm];
-            }
-            if constexpr (MODE != 2) {
-                // I mu_{t+dir} (old)
-#pragma unroll
-                for (int s = 0; s < BDS; ++s)
-#pragma unroll
-                    for (int mm = 0; mm < 2; ++mm) acc[mm] = MFMA(ip[mm][s], mo[s >> 2][s & 3], acc[mm]);
-                __builtin_amdgcn_sched_barrier(0);
-                load_o(j + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // this wavefront's rows of the new state: kept where the column is active, then shared
-            double* out = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * BDP : trash;
-            d4 nx[2];
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
-                const int m = 2 * w + mm;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) nx[mm][r] = act ? acc[mm][r] : xbuf[(4 * m + r) * 64 + lane];
-                *reinterpret_cast<d4*>(out + (m * 4 + q) * 4) = nx[mm];
-            }
-            __syncthreads();            // every wavefront has read the old state (its R products and the select)
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xbuf[(4 * (2 * w + mm) + r) * 64 + lane] = nx[mm][r];
-            __syncthreads();
+                for (int s = 0; s < BDS; ++s) acc[mm] = MFMA(rn[mm][s], xr[s * 64 + lane], acc[mm]);
+            if constexpr (MODE != 2) {
+                if (fwd) {                      // c_t for the backward sweep, this wavefront's rows
+                    double* ur = (act && j >= 0) ? Un + (size_t)(tbase + sgn * j) * BDP : trash + 256;
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) *reinterpret_cast<d4*>(ur + ((2 * w + mm) * 4 + q) * 4) = acc[mm];
+                }
+                // I mu_{t+dir} (old)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int s = 0; s < BDS; ++s) acc[mm] = MFMA(ip[mm][s], mo[s >> 2][s & 3], acc[mm]);
+            }
+            // this wavefront's rows of the new state: kept where the column is active, then shared
+            double* out = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * BDP : trash;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = 2 * w + mm;
+                d4 nx;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nx[r] = act ? acc[mm][r] : xr[(4 * m + r) * 64 + lane];
+                *reinterpret_cast<d4*>(out + (m * 4 + q) * 4) = nx;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xw[(4 * m + r) * 64 + lane] = nx[r];
+            }
+            __syncthreads();            // the new state is complete; the buffer just read is free for the next step's writes
+        };
+        load_c(jstart);
+        if constexpr (MODE != 2) load_o(moA, jstart);
+        double* const xb1 = xb0 + BDS * 64;
+        int j = jstart;
+        for (; j + 1 < Lseg; j += 2) {
+            step(j, xb0, xb1, moA, moB);
+            step(j + 1, xb1, xb0, moB, moA);
         }
+        const double* xfin = xb0;
+        if (j < Lseg) { step(j, xb0, xb1, moA, moB); xfin = xb1; }
         // the column that holds the last interior node hands its state to the closing boundary step
         const int clast = (Tint - 1) / Lseg;
         if (w == 0 && c == clast) {
 #pragma unroll
             for (int m = 0; m < BDT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xs[16 * m + 4 * r + q] = xbuf[(4 * m + r) * 64 + lane];
+                for (int r = 0; r < 4; ++r) xs[16 * m + 4 * r + q] = xfin[(4 * m + r) * 64 + lane];
         }
         __syncthreads();
     }
@@ -246,21 +289,24 @@ int launch_sweep_big(pyvb_lds* h, int direction) {
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
     a.A_mean = h->A_mean; a.C_mean = h->C_mean; a.trash = h->trash; a.U = h->U;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
-    const size_t lds = ((size_t)4 * 2 * BDS * 64 + (size_t)BDS * 64 + 2 * BDP) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_sweep_big<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void*)k_sweep_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void*)k_sweep_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    const size_t lds = ((size_t)2 * BDS * 64 + 2 * BDP) * sizeof(double);
+    // a backward sweep right behind a forward one (h->u_valid) reads c_t; anything else starts from G y_t
+    const bool cached = direction == PYVB_BACKWARD && h->u_valid;
+    if (!cached && h->T > 2) {
+        BigGyArgs ga;
+        ga.Y = h->Y; ga.gains = h->gains; ga.U = h->U; ga.trash = h->trash;
+        ga.N = h->N; ga.T = h->T; ga.K = h->K; ga.L = h->L;
+        const int blocks = (h->T - 2 + 15) / 16;
+        ga.nblk = blocks < 32 ? ((blocks + 1) & ~1) : 32;
+        TimedLaunch tl(h, PYVB_K_GY);
+        const dim3 grid((blocks + ga.nblk - 1) / ga.nblk, h->N);
+        if ((h->K & 1) == 0) hipLaunchKernelGGL(k_gy_big<true>, grid, dim3(256), 0, h->stream, ga);
+        else hipLaunchKernelGGL(k_gy_big<false>, grid, dim3(256), 0, h->stream, ga);
     }
-    // forward: stores c_t; a backward sweep right behind it (h->u_valid) reads it; anything else computes everything
-    const int mode = direction == PYVB_FORWARD ? 1 : (h->u_valid ? 2 : 0);
     {
         TimedLaunch tl(h, direction == PYVB_FORWARD ? PYVB_K_SWEEP_FWD : PYVB_K_SWEEP_BWD);
-        if (mode == 1) hipLaunchKernelGGL(k_sweep_big<1>, dim3(h->N), dim3(256), lds, h->stream, a);
-        else if (mode == 2) hipLaunchKernelGGL(k_sweep_big<2>, dim3(h->N), dim3(256), lds, h->stream, a);
-        else hipLaunchKernelGGL(k_sweep_big<0>, dim3(h->N), dim3(256), lds, h->stream, a);
+        if (cached) hipLaunchKernelGGL(k_sweep_big<2>, dim3(h->N), dim3(256), lds, h->stream, a);
+        else hipLaunchKernelGGL(k_sweep_big<3>, dim3(h->N), dim3(256), lds, h->stream, a);
     }
     HIPCHK(hipGetLastError());
     return PYVB_OK;

@@ -225,7 +225,7 @@ class LDSBatch(object):
 
     def kernel_times(self):
         names = {"prep": C.K_PREP, "sweep_fwd": C.K_SWEEP_FWD, "sweep_bwd": C.K_SWEEP_BWD, "stats": C.K_STATS,
-                 "params": C.K_PARAMS, "elbo": C.K_ELBO, "step": C.K_STEP}
+                 "params": C.K_PARAMS, "elbo": C.K_ELBO, "step": C.K_STEP, "gy": C.K_GY}
         out = {}
         for nm, k in names.items():
             ms, cnt = C.ctypes.c_double(), C.ctypes.c_int()
