@@ -24,7 +24,7 @@ int pyvb_pca_destroy(pyvb_pca* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) pyvb_comm_free(h->comm);
     void* bufs[] = {h->X, h->M, h->xvar, h->nmiss, h->Z, h->W_mean, h->W_var, h->Mu_mean, h->Mu_var, h->Z_cov, h->qld_W, h->W_pm, h->W_pp,
-                    h->Mu_pm, h->Mu_pp, h->scal, h->Gz, h->g0, h->part, h->stats, h->aux, h->elbo, h->status, h->red2, h->Xdata, h->pinned};
+                    h->Mu_pm, h->Mu_pp, h->scal, h->Gz, h->g0, h->part, h->stats, h->aux, h->elbo, h->status, h->red2, h->Xdata, h->pinned, h->sx_local};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -71,6 +71,7 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     TRY(alloc_d(&h->Gz, (size_t)h->QT * (DP / 4) * 64)); TRY(alloc_d(&h->g0, QP));
     TRY(alloc_d(&h->part, (size_t)h->nchunk * (h->SL.total + h->DT)));
     TRY(alloc_d(&h->stats, h->SL.total));
+    TRY(alloc_d(&h->sx_local, DP));
     TRY(alloc_d(&h->red2, (size_t)PCA_RED * h->SL.total));
     TRY(alloc_d(&h->aux, (size_t)4 * h->nchunk * QP + QP + DP));
     TRY(alloc_d(&h->elbo, 8));
@@ -92,9 +93,19 @@ static int down(pyvb_pca* h, double* dst, const double* src, size_t n) {
     return PYVB_OK;
 }
 
+// A requested Z update whose rows have not been written (see pyvb_pca_update_Z) is carried out: pass 1 on its own.  Called by
+// everything that reads or replaces Z, X or the parameters outside the fused sweep.
+static int resolve_z(pyvb_pca* h) {
+    if (!h->z_pending) return PYVB_OK;
+    int rc = pca_launch_pass1(h);
+    h->z_pending = false; h->z0_done = false;
+    return rc;
+}
+
 int pyvb_pca_set_priors(pyvb_pca* h, const double* W_pm, const double* W_pp, const double* Mu_pm, const double* Mu_pp,
                         double beta_a0, double beta_b0) {
     ENTER(h);
+    { int rz = resolve_z(h); if (rz) return rz; }
     ARGCHK(W_pm && W_pp && Mu_pm && Mu_pp, "all prior arrays are required");
     int rc;
     if ((rc = up(h, h->W_pm, W_pm, (size_t)h->d * h->q))) return rc;
@@ -129,6 +140,7 @@ static int download_rows(pyvb_pca* h, double* dst, const double* src, int cols, 
 
 int pyvb_pca_set_data(pyvb_pca* h, const double* X) {
     ENTER(h);
+    { int rz = resolve_z(h); if (rz) return rz; }
     ARGCHK(X, "X is NULL");
     const long N = h->N; const int d = h->d, DP = h->DP;
     std::vector<double> xb((size_t)N * DP, 0.0);
@@ -162,6 +174,7 @@ int pyvb_pca_set_data(pyvb_pca* h, const double* X) {
 int pyvb_pca_set_state(pyvb_pca* h, const double* X_missing, const double* W_mean, const double* Z, const double* Z_cov,
                        const double* Mu_mean, const double* beta_b) {
     ENTER(h);
+    { int rz = resolve_z(h); if (rz) return rz; }
     const long N = h->N; const int d = h->d, q = h->q, DP = h->DP;
     int rc;
     if (X_missing) {        // posterior means of the missing entries; observed positions of the argument are ignored
@@ -186,6 +199,7 @@ int pyvb_pca_set_state(pyvb_pca* h, const double* X_missing, const double* W_mea
 
 int pyvb_pca_set_initial_variances(pyvb_pca* h, const double* W_var, const double* Mu_var) {
     ENTER(h);
+    { int rz = resolve_z(h); if (rz) return rz; }
     int rc;
     if ((rc = up(h, h->W_var, W_var, (size_t)h->q * h->d))) return rc;
     if ((rc = up(h, h->Mu_var, Mu_var, h->d))) return rc;
@@ -196,6 +210,7 @@ int pyvb_pca_set_initial_variances(pyvb_pca* h, const double* W_var, const doubl
 
 int pyvb_pca_set_unpinned_rows(pyvb_pca* h, const double* X_full, const double* row_var) {
     ENTER(h);
+    { int rz = resolve_z(h); if (rz) return rz; }
     ARGCHK(X_full && row_var, "X_full and row_var are required");
     const long N = h->N; const int d = h->d, DP = h->DP;
     std::vector<double> xb((size_t)N * DP), xv(N);
@@ -244,6 +259,7 @@ int pyvb_pca_sync(pyvb_pca* h) {
 int pyvb_pca_get_state(pyvb_pca* h, double* X, double* X_rowvar, double* W_mean, double* W_var, double* Z, double* Z_cov,
                        double* Mu_mean, double* Mu_var, double* beta_ab) {
     ENTER(h);
+    { int rz = resolve_z(h); if (rz) return rz; }
     const int d = h->d, q = h->q;
     int rc;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -285,8 +301,13 @@ int pyvb_pca_get_qld(pyvb_pca* h, double* qld_W, double* qld_Z, double* qld_Mu, 
 // ---- dependency tracking: "full" = every sum current, "lin" = at least sum x and sum z ----
 static int full_stats(pyvb_pca* h, long lo_upd, long hi_upd) {
     int rc;
-    if ((rc = pca_launch_pass2(h, lo_upd, hi_upd))) return rc;
+    if (h->z_pending) {          // the Z update rides along: one sweep over X instead of two
+        rc = pca_launch_pass12(h, lo_upd, hi_upd);
+        h->z_pending = false; h->z0_done = false;
+        if (rc) return rc;
+    } else if ((rc = pca_launch_pass2(h, lo_upd, hi_upd))) return rc;
     if ((rc = pca_launch_reduce(h, 0))) return rc;
+    HIPCHK(hipMemcpyAsync(h->sx_local, h->stats + h->SL.osx, h->DP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     if (h->comm && (rc = pyvb_allreduce_f64(h->comm, h->stats, h->SL.total, h->stream))) return rc;
     h->full_valid = h->lin_valid = true;
     if (hi_upd > lo_upd) h->res_valid = false;          // rows changed: the cached residual of the last Beta update is stale
@@ -313,13 +334,15 @@ static int exchange_lin(pyvb_pca* h) {
 int pyvb_pca_update_Z(pyvb_pca* h) {
     ENTER(h);
     int rc;
-    const bool had_lin = h->lin_valid;
-    if ((rc = pca_launch_small(h, PCA_PREPZ))) return rc;
-    if ((rc = pca_launch_pass1(h))) return rc;
-    if ((rc = pca_launch_reduce(h, 1))) return rc;
-    HIPCHK(hipMemsetAsync(h->aux + (size_t)4 * h->nchunk * h->QP + h->QP, 0, h->DP * sizeof(double), h->stream));
+    // Deferred: the posterior of the Z_n (Sigma_z, Gz, g0) and the one sum the next nodes in the crawl order read, sum z, are
+    // formed now (sum z = Gz sum x - N g0 over this rank's rows, from the sum of x kept from the last sweep; all-reduced like
+    // the sum a pass over the rows would give); the rows of Z are written by the next sweep over X -- normally the X update
+    // that follows (k_pca_pass12) -- or by resolve_z() if something asks for them first.
+    if (!h->lin_valid && (rc = ensure_full(h))) return rc;      // may carry out an earlier pending request
+    h->z_pending = true; h->z0_done = false;
+    if ((rc = pca_launch_small(h, PCA_PREPZ))) { h->z_pending = false; return rc; }
     if ((rc = exchange_lin(h))) return rc;
-    h->full_valid = false; h->lin_valid = had_lin; h->res_valid = false;
+    h->full_valid = false; h->res_valid = false;                // lin_valid stays: sum x is unchanged, sum z is the new one
     return PYVB_OK;
 }
 
@@ -334,6 +357,7 @@ static int x0_step(pyvb_pca* h) {
     if (h->comm && h->row_offset != 0)
         HIPCHK(hipMemsetAsync(v, 0, h->QP * sizeof(double), h->stream));
     if ((rc = pca_launch_small(h, PCA_X0))) return rc;      // a no-op for the data of the other ranks (k_pca.hip checks row_offset)
+    if (h->z_pending && h->row_offset == 0) h->z0_done = true;     // the kernel has stored z_0 from the row as it was
     if ((rc = exchange_lin(h))) return rc;
     h->full_valid = false; h->res_valid = false;
     return PYVB_OK;

@@ -22,11 +22,13 @@ struct PcaArgs {
     const double* Xdata; unsigned char* pinned;     // null unless some rows have not been conditioned on their observations yet
     double *W_mean, *W_var, *Mu_mean, *Mu_var, *Z_cov, *qld_W;
     const double *W_pm, *W_pp, *Mu_pm, *Mu_pp;
-    double* scal; double* Gz; double* g0;
+    double* scal; double* Gz; double* g0; double* sx_local;
     double* part; double* stats; double* aux; double* elbo; int* status;
     long N, N_total, chunk_rows, lo_upd, hi_upd, n_part_missing, n_none_rows, row_offset;
     int d, q, DP, QP, DT, QT, nchunk, mode;
     int res_cached;     // PCA_ELBO: scal[PS_RES] holds the residual already
+    int keep_z0;        // Z of global row 0 is final already (k_pca_pass12, k_pca_pass1)
+    int z_deferred;     // PCA_PREPZ: also form sum z analytically;  PCA_X0: Z of row 0 is formed here
     PcaStatsLayout SL;
 };
 
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(256) k_pca_pass1(PcaArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long row = n0 + 4 * r + qk;                         // accumulator: row = 4*reg + lane/16
-                if (row < r1) { a.Z[row * QP + 16 * t + c] = acc[t][r]; szc[t] += acc[t][r]; }
+                if (row < r1 && !(a.keep_z0 && row == 0 && a.row_offset == 0)) { a.Z[row * QP + 16 * t + c] = acc[t][r]; szc[t] += acc[t][r]; }
             }
     }
     // column sums over the 4 lane groups -> part1[chunk][QP]
@@ -250,6 +252,226 @@ __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
     sxx = wsum(sxx);
     if (lane == 0) P[a.SL.total + wave] = sxx;            // DT slots, one per wavefront here, the rest zero
     if (wave == 0 && lane >= (a.DT + P2T - 1) / P2T && lane < a.DT) P[a.SL.total + lane] = 0.0;
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            double s = sz[t];
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            if (qk == 0) P[a.SL.osz + 16 * t + c] = s;
+#pragma unroll
+            for (int u = 0; u < QT; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[a.SL.oSzz + (size_t)(16 * t + 4 * r + qk) * QP + 16 * u + c] = szz[t][u][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// passes 1 and 2 in ONE sweep over X (the iteration's order W, Z, X_0, Mu, X_1.. allows it: the only thing between the Z and
+// the X updates that needs a sum over all rows is Mu, and the sum it needs, sum_n <z_n>, is linear in sum_n <x_n>:
+// Gz sum x - N g0, which k_pca_small(PCA_PREPZ) forms before any row is touched).  X is then read once per iteration.
+//
+// One workgroup per row chunk, wavefront w owns columns [32w, 32w + 32) of the chunk's rows, 16 rows (one MFMA tile) at a time:
+//   1. its part of Z = X Gz^T over its 32 columns (X in A layout: lane = row, 4 consecutive columns per load) -> LDS
+//   2. the parts are summed (thread = element), g0 subtracted, Z stored; both operand layouts of Z are read back from LDS
+//   3. the prediction of its columns, TRANSPOSED product <W> Z^T with the rows of the <W> tile permuted (row m <-> dimension
+//      4 (m % 4) + m / 4), so that the accumulator holds lane = row, register r = column 4 (lane / 16) + r: the layout X was
+//      loaded in.  Missing entries take it; a lane stores its 32 bytes if one of them changed (whole sectors).
+//   4. the tile goes through a per-wavefront LDS buffer into accumulator layout (row = 4 reg + lane / 16: the A operand of
+//      X^T) for sum x z^T, sum x, sum |x|^2, exactly as k_pca_pass2.
+// keep_z0: global row 0 has had its own update since Z was defined (Xs[0].update() comes before Mu in the crawl order): its z
+// was stored by that step and is taken from Z instead of being recomputed from the changed row.
+// ---------------------------------------------------------------------------------------------------
+#define P12_XS 36       // row stride (doubles) of the transposition buffer: 32 columns + pad, 32-byte aligned rows
+template <int QT, bool PIN>     // PIN as in k_pca_pass2
+__global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
+    extern __shared__ double lds12[];
+    const int nw = blockDim.x >> 6;
+    double* zp = lds12;                                 // [nw][QT][4][64] accumulator dumps of the partial products
+    double* zf = zp + (size_t)nw * QT * 256;            // [QT][4][64] Z of the 16 rows, accumulator layout
+    double* zT = zf + QT * 256;                         // [QP][17] the same, latent index major (the operand of the prediction)
+    double* xt = zT + QT * 16 * 17 + (size_t)(threadIdx.x >> 6) * 16 * P12_XS;      // [16][P12_XS] per wavefront
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, qk = lane >> 4;
+    const int DP = a.DP, QP = a.QP, d = a.d, q = a.q, DS = DP / 4;
+    constexpr int QS = 4 * QT;
+    constexpr int PF = QT == 1 ? 4 : 2;         // tiles of X in flight per wavefront (register budget: 256 at two wavefronts per SIMD)
+    const long r0 = (long)blockIdx.x * a.chunk_rows;
+    const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
+    // ---- constant operands of this wavefront's two column tiles j = 2 wave + jj
+    bool tok[2];
+    double gz[2][4][QT], wa[2][QS];
+    d4 mu4[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * wave + jj;
+        tok[jj] = 16 * j < DP;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) gz[jj][e][t] = tok[jj] ? a.Gz[(size_t)(t * DS + 4 * j + e) * 64 + lane] : 0.0;
+        const int dimA = 16 * j + 4 * (c & 3) + (c >> 2);        // permuted row of the <W> tile (see 3. above)
+#pragma unroll
+        for (int s = 0; s < QS; ++s) { const int i = 4 * s + qk; wa[jj][s] = (dimA < d && i < q) ? a.W_mean[(size_t)dimA * q + i] : 0.0; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int dim = 16 * j + 4 * qk + e; mu4[jj][e] = dim < d ? a.Mu_mean[dim] : 0.0; }
+    }
+    const int col0 = 32 * wave + 2 * c;                 // this lane's two columns in the statistics (k_pca_pass2's interleaved tiles)
+    const bool colok = col0 < DP;
+    d4 sxz[P2T][QT], szz[QT][QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int p = 0; p < P2T; ++p) sxz[p][t] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < QT; ++u) szz[t][u] = d4{0, 0, 0, 0};
+    }
+    double sx[P2T] = {0.0, 0.0}, sxx = 0.0, sz[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) sz[t] = 0.0;
+    double* const Xc = a.X + (size_t)r0 * DP;
+    const unsigned char* const Mc = a.M + (size_t)r0 * DP;
+    double* const Zc = a.Z + (size_t)r0 * QP;
+    const unsigned nrows = (unsigned)(r1 - r0);
+    const unsigned lo = a.lo_upd > r0 ? (unsigned)((a.lo_upd < r1 ? a.lo_upd : r1) - r0) : 0u;     // rows [lo, hi) of the chunk are updated
+    const unsigned hi = a.hi_upd > r0 ? (unsigned)((a.hi_upd < r1 ? a.hi_upd : r1) - r0) : 0u;
+    const bool z0_here = a.keep_z0 && a.row_offset == 0 && r0 == 0;
+    double g0r[QT];         // step 2: a thread's elements all have latent index 16 t + tid % 16 (the workgroup is a multiple of 64 wide)
+#pragma unroll
+    for (int t = 0; t < QT; ++t) g0r[t] = a.g0[16 * t + (tid & 15)];
+    // X in A layout for this wavefront: lane = row n0 + c, columns 32 wave + 16 jj + 4 qk .. + 3.  A tile of a workgroup is 36 KB
+    // and a CU holds one workgroup: PF register sets per lane keep three tiles in flight behind the one being worked on
+    // (with one, the sweep ran at the latency of a load per tile: 1.23 ms, 2.5 TB/s).
+    d4 xq[PF][2]; unsigned mq[PF][2];
+    auto fetch = [&](unsigned n0, d4 (&x)[2], unsigned (&m)[2]) {
+        const unsigned row = (n0 + c < nrows) ? n0 + c : nrows - 1;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const unsigned off = row * DP + (tok[jj] ? 32 * wave + 16 * jj + 4 * qk : 0);
+            x[jj] = *reinterpret_cast<const d4*>(Xc + off);
+            m[jj] = *reinterpret_cast<const unsigned*>(Mc + off);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(16u * u < nrows ? 16u * u : 0u, xq[u], mq[u]);
+    auto tile = [&](unsigned n0, d4 (&xa)[2], unsigned (&ma)[2]) {
+        // ---- 1. this wavefront's part of Z
+        d4 zacc[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            zacc[t] = d4{0, 0, 0, 0};
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zacc[t] = MFMA(xa[jj][e], gz[jj][e][t], zacc[t]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zp[((size_t)(wave * QT + t) * 4 + r) * 64 + lane] = zacc[t][r];
+        }
+        __syncthreads();
+        // ---- 2. sum of the parts: thread = (t, r, lane) element of the accumulator layout
+        for (int el = tid; el < QT * 256; el += blockDim.x) {
+            const int t = el >> 8, r = (el >> 6) & 3, ln = el & 63, cc = ln & 15, qq = ln >> 4;
+            double s = -(QT == 1 || t == 0 ? g0r[0] : g0r[QT - 1]);
+            for (int w2 = 0; w2 < nw; ++w2) s += zp[((size_t)(w2 * QT + t) * 4 + r) * 64 + ln];
+            const unsigned row = n0 + 4 * r + qq;
+            if (row < nrows) {
+                if (z0_here && row == 0) s = Zc[16 * t + cc];
+                else Zc[(size_t)row * QP + 16 * t + cc] = s;
+            }
+            zf[el] = row < nrows ? s : 0.0;
+            zT[(16 * t + cc) * 17 + 4 * r + qq] = s;
+        }
+        __syncthreads();
+        double za[QS], zb[4][QT];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) za[s] = zT[(4 * s + qk) * 17 + c];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) zb[s][t] = zf[(size_t)t * 256 + s * 64 + lane];
+        // ---- 3. prediction, imputation, write-back
+        const unsigned rowl = n0 + c;
+        const bool rowupd = rowl < nrows && rowl >= lo && rowl < hi;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            d4 pred = mu4[jj];
+#pragma unroll
+            for (int s = 0; s < QS; ++s) pred = MFMA(wa[jj][s], za[s], pred);
+            d4 v = xa[jj];
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (rowupd && ((ma[jj] >> (8 * e)) & 0xffu) == 0) { v[e] = pred[e]; any = true; }
+            if (PIN && rowupd && tok[jj] && !a.pinned[r0 + rowl]) {          // first update of a row that still carries its initial mean
+                const d4 dat = *reinterpret_cast<const d4*>(a.Xdata + (size_t)(r0 + rowl) * DP + 32 * wave + 16 * jj + 4 * qk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)                                  // everywhere: the observed entries take their data
+                    if (((ma[jj] >> (8 * e)) & 0xffu) != 0) v[e] = dat[e];
+                any = true;
+            }
+            if (any && tok[jj]) *reinterpret_cast<d4*>(Xc + (size_t)rowl * DP + 32 * wave + 16 * jj + 4 * qk) = v;
+            *reinterpret_cast<d4*>(xt + c * P12_XS + 16 * jj + 4 * qk) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- 4. statistics on the transposed tile: element r of tile p = row n0 + 4 r + qk, column col0 + p
+        d4 xn[P2T];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const d2 v = *reinterpret_cast<const d2*>(xt + (4 * r + qk) * P12_XS + 2 * c);
+            const bool live = (n0 + 4 * r + qk < nrows) && colok;
+#pragma unroll
+            for (int p = 0; p < P2T; ++p) {
+                const double x = live ? v[p] : 0.0;
+                xn[p][r] = x; sx[p] += x; sxx += x * x;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < P2T; ++p)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) sxz[p][t] = MFMA(xn[p][s], zb[s][t], sxz[p][t]);
+        if (wave == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    sz[t] += zb[s][t];
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) szz[t][u] = MFMA(zb[s][t], zb[s][u], szz[t][u]);
+                }
+        }
+        const unsigned nn = n0 + 16 * PF;              // this register set is free again: the tile PF further on
+        fetch(nn < nrows ? nn : n0, xa, ma);
+    };
+    for (unsigned base = 0; base < nrows; base += 16 * PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (base + 16 * u < nrows) tile(base + 16 * u, xq[u], mq[u]);
+    }
+    // ---- partial sums of this chunk, laid out as k_pca_pass2's
+    double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
+#pragma unroll
+    for (int p = 0; p < P2T; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dim = 16 * P2T * wave + P2T * (4 * r + qk) + p;
+            if (dim < DP) {
+#pragma unroll
+                for (int t = 0; t < QT; ++t) P[a.SL.oSxz + (size_t)dim * QP + 16 * t + c] = sxz[p][t][r];
+            }
+        }
+#pragma unroll
+    for (int p = 0; p < P2T; ++p) {
+        double s = sx[p];
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        if (qk == 0 && colok) P[a.SL.osx + col0 + p] = s;
+    }
+    sxx = wsum(sxx);
+    if (lane == 0) P[a.SL.total + wave] = sxx;            // DT slots, one per wavefront here, the rest zero
+    if (wave == 0 && lane >= nw && lane < a.DT) P[a.SL.total + lane] = 0.0;
     if (wave == 0) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -480,11 +702,43 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
             if (tid < q) for (int j = 0; j < q; ++j) s += P[tid * q + j] * Sg[j];
             a.g0[tid] = beta * s;
         }
+        if (a.z_deferred) {
+            // the rows are not touched yet (k_pca_pass12 forms Z on its way through X); what Mu.update() needs of the new Z is
+            // sum_n z_n = Gz sum_n x_n - N g0 = beta Sigma_z (W^T sum x - N W^T <Mu>), linear in the sum of x kept from the last sweep
+            double* us = mus + 256;
+            __syncthreads();
+            // (this rank's rows: sx_local and N are local, the result is all-reduced like the sum pass 1 used to deliver)
+            if (tid < d) mus[tid] = a.sx_local[tid];
+            __syncthreads();
+            if (tid < q) {
+                double s = 0.0;
+                for (int k = 0; k < d; ++k) s += wst[k * q + tid] * mus[k];
+                us[tid] = s - (double)a.N * Sg[tid];
+            }
+            __syncthreads();
+            if (tid < QP) {
+                double s = 0.0;
+                if (tid < q) for (int j = 0; j < q; ++j) s += P[tid * q + j] * us[j];
+                a.aux[tid] = beta * s;
+            }
+            if (tid < DP) a.aux[QP + tid] = 0.0;         // no change of sum x
+        }
     } else if (a.mode == PCA_X0) {
         // Xs[0].update() alone (the crawl order puts it before Mu): aux = [sz (QP) | delta of sum x (DP)]
         double* dsx = a.aux + QP;
         if (tid < DP) dsx[tid] = 0.0;
         __syncthreads();
+        if (a.row_offset == 0 && a.z_deferred) {
+            // Zs[0].update() has not been materialised (k_pca_pass12 does it for the other rows): z_0 = Gz x_0 - g0 from the row as
+            // it stands, before it changes below; the pass keeps this value for row 0 (keep_z0)
+            const double xk = tid < d ? a.X[tid] : 0.0;             // thread = column k; the sums over k through bsum, one latent index at a time
+            for (int i = 0; i < QP; ++i) {
+                const double s = bsum((i < q && tid < d) ? a.Gz[gz_pos(i, tid, DP / 4)] * xk : 0.0, red);
+                if (tid == 0) a.Z[i] = i < q ? s - a.g0[i] : 0.0;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
         if (a.row_offset == 0 && a.nmiss[0] > 0) {
             const bool pin = a.pinned && !a.pinned[0];           // first update of a row still carrying its initial mean everywhere
             __syncthreads();
@@ -499,6 +753,8 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
             }
             if (tid == 0) { a.xvar[0] = 1.0 / beta; if (pin) a.pinned[0] = 1; }
         }
+        __syncthreads();
+        if (tid < DP) a.sx_local[tid] += dsx[tid];          // this rank's own sum of x follows its row
     } else if (a.mode == PCA_APPLY) {
         // after the all-reduce of aux: the new sum of z replaces the old one, the sum of x moves by the delta
         if (tid < QP) a.stats[a.SL.osz + tid] = a.aux[tid];
@@ -586,17 +842,19 @@ static PcaArgs pca_args(pyvb_pca* h) {
     a.X = h->X; a.M = h->M; a.xvar = h->xvar; a.nmiss = h->nmiss; a.Z = h->Z; a.Xdata = h->Xdata; a.pinned = h->pinned;
     a.W_mean = h->W_mean; a.W_var = h->W_var; a.Mu_mean = h->Mu_mean; a.Mu_var = h->Mu_var; a.Z_cov = h->Z_cov; a.qld_W = h->qld_W;
     a.W_pm = h->W_pm; a.W_pp = h->W_pp; a.Mu_pm = h->Mu_pm; a.Mu_pp = h->Mu_pp;
-    a.scal = h->scal; a.Gz = h->Gz; a.g0 = h->g0; a.part = h->part; a.stats = h->stats; a.aux = h->aux; a.elbo = h->elbo; a.status = h->status;
+    a.scal = h->scal; a.Gz = h->Gz; a.g0 = h->g0; a.sx_local = h->sx_local; a.part = h->part; a.stats = h->stats; a.aux = h->aux; a.elbo = h->elbo; a.status = h->status;
     a.N = h->N; a.N_total = h->N_total; a.chunk_rows = h->chunk_rows; a.lo_upd = 0; a.hi_upd = 0;
     a.n_part_missing = h->n_part_missing; a.n_none_rows = h->n_none_rows; a.row_offset = h->row_offset;
     a.d = h->d; a.q = h->q; a.DP = h->DP; a.QP = h->QP; a.DT = h->DT; a.QT = h->QT; a.nchunk = h->nchunk; a.mode = 0; a.SL = h->SL;
     a.res_cached = h->res_valid ? 1 : 0;
+    a.keep_z0 = 0; a.z_deferred = 0;
     return a;
 }
 
 int pca_launch_small(pyvb_pca* h, int mode) {
     PcaArgs a = pca_args(h); a.mode = mode;
-    if (mode == PCA_X0 || mode == PCA_APPLY) a.aux = h->aux + (size_t)4 * h->nchunk * h->QP;    // the [sz | delta sx] vector
+    a.z_deferred = ((mode == PCA_PREPZ || mode == PCA_X0) && h->z_pending) ? 1 : 0;
+    if (mode == PCA_X0 || mode == PCA_APPLY || mode == PCA_PREPZ) a.aux = h->aux + (size_t)4 * h->nchunk * h->QP;    // the [sz | delta sx] vector
     hipLaunchKernelGGL(k_pca_small, dim3(1), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
@@ -604,6 +862,7 @@ int pca_launch_small(pyvb_pca* h, int mode) {
 
 int pca_launch_pass1(pyvb_pca* h) {
     PcaArgs a = pca_args(h);
+    a.keep_z0 = h->z0_done ? 1 : 0;
     const size_t lds = (size_t)h->QT * (h->DP / 4) * 64 * sizeof(double);
     if (h->QT == 1) hipLaunchKernelGGL(k_pca_pass1<1>, dim3(h->nchunk), dim3(256), lds, h->stream, a);
     else hipLaunchKernelGGL(k_pca_pass1<2>, dim3(h->nchunk), dim3(256), lds, h->stream, a);
@@ -618,6 +877,21 @@ int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
     const bool pin = h->Xdata != nullptr;
     if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass2<1, true>), grid, block, 0, h->stream, a); else hipLaunchKernelGGL((k_pca_pass2<1, false>), grid, block, 0, h->stream, a); }
     else { if (pin) hipLaunchKernelGGL((k_pca_pass2<2, true>), grid, block, 0, h->stream, a); else hipLaunchKernelGGL((k_pca_pass2<2, false>), grid, block, 0, h->stream, a); }
+    hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return PYVB_OK;
+}
+
+// Z and X updates and the statistics in one sweep (k_pca_pass12); rows [lo_upd, hi_upd) of X are updated
+int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
+    PcaArgs a = pca_args(h); a.lo_upd = lo_upd; a.hi_upd = hi_upd;
+    a.keep_z0 = h->z0_done ? 1 : 0;
+    const unsigned nw = (h->DT + P2T - 1) / P2T;          // wavefronts per workgroup: 32 columns each
+    const size_t lds = ((size_t)nw * h->QT * 256 + (size_t)h->QT * 256 + (size_t)h->QT * 16 * 17 + (size_t)nw * 16 * P12_XS) * sizeof(double);
+    const dim3 grid(h->nchunk), block(64 * nw);
+    const bool pin = h->Xdata != nullptr;
+    if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass12<1, true>), grid, block, lds, h->stream, a); else hipLaunchKernelGGL((k_pca_pass12<1, false>), grid, block, lds, h->stream, a); }
+    else { if (pin) hipLaunchKernelGGL((k_pca_pass12<2, true>), grid, block, lds, h->stream, a); else hipLaunchKernelGGL((k_pca_pass12<2, false>), grid, block, lds, h->stream, a); }
     hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;

@@ -42,6 +42,8 @@ struct pyvb_pca {
     double *Gz, *g0;                     // Z-pass operands: Gz^T as MFMA B operands [QT][DP/4][64], g0 [QP]
     double *part; int nchunk; long chunk_rows;   // [nchunk][DT+1][stats.total] partial statistics
     double *stats;                       // [stats.total] reduced (global after the all-reduce)
+    double *sx_local;                    // [DP] sum of x over THIS rank's rows (what stats holds before the all-reduce), kept current by
+                                         // the X_0 step: the deferred Z update forms its sum of z from it
     double *aux;                         // [nchunk][QP] pass-1 partials, then [QP + DP]: new sum z | delta of sum x
     double *red2;                        // [PCA_RED][stats.total] second-stage partials of the reductions
     double *elbo;                        // [5]
@@ -50,12 +52,16 @@ struct pyvb_pca {
     long n_part_missing, n_none_rows, n_part_rows;   // global counts (from the mask)
     bool full_valid, lin_valid;          // all statistics current / at least sum x and sum z current
     bool res_valid;                      // scal[PS_RES] is the residual of the current W, Z, X, Mu (nothing but Beta updated since)
+    bool z_pending;                      // [z.update() for z in Zs] has been requested and its operands (Gz, g0, sum z) are set, but the
+                                         // rows of Z are not written yet: the next pass over X does it on its way (k_pca_pass12)
+    bool z0_done;                        // while z_pending: Xs[0].update() has run and stored z_0 itself
     pyvb_comm* comm; int rank, world;
 };
 
 int pca_launch_small(pyvb_pca* h, int mode);
 int pca_launch_pass1(pyvb_pca* h);
 int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd);
+int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd);
 int pca_launch_reduce(pyvb_pca* h, int what);
 int pca_launch_rowqld(pyvb_pca* h, double* out);      // out: device [N]
 enum { PCA_W = 0, PCA_PREPZ = 1, PCA_MU = 2, PCA_BETA = 3, PCA_ELBO = 4, PCA_X0 = 5, PCA_APPLY = 6 };
