@@ -129,9 +129,19 @@ def pca_workload(steps, warmup, with_cpu):
         cpu = {"value": (warmup + steps) / cpu_dt * n_s / N, "unit": "VB iterations/s at N=%d (scaled from the sample)" % N,
                "cores": os.cpu_count(), "kind": "port",
                "sample": "%d rows, %d iterations of oracle/pca_closed_form.py in %.1f s" % (n_s, warmup + steps, cpu_dt)}
-    # algorithmic bytes of an iteration: X is read by both passes, the byte mask by the second, Z written by the first and
-    # read by the second, the missing entries written back
-    alg = 2.0 * N * d * 8 + N * d + 2.0 * N * q * 8 + nmiss * 8
+    # algorithmic bytes of an iteration: X and the byte mask are read once (the Z and the X updates share one sweep over the rows,
+    # k_pca_pass12), Z is written once, the missing entries are written back.  (Two sweeps -- the reference's order taken
+    # literally, and this path before round 3 -- move X twice and Z three times: `algorithmic_bytes_two_sweeps`.)
+    alg = 1.0 * N * d * 8 + N * d + 1.0 * N * q * 8 + nmiss * 8
+    alg2 = 2.0 * N * d * 8 + N * d + 2.0 * N * q * 8 + nmiss * 8
+    traffic, tsrc = None, None
+    tpath = os.path.join(REPO, "profiles", "r03", "traffic_pca_pmc.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        hit = [v["hbm_bytes_per_launch"] for k, v in tj.items() if "k_pca_pass12" in k]
+        if hit:
+            traffic = hit[0]
+            tsrc = "profiles/r03/traffic_pca_pmc.json: k_pca_pass12, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (committed; not measured in this run)"
     step_s = dt / steps
     return {"workload": "VB-PCA N=%d d=%d q=%d, 10%% missing (BASELINE configs[4] on one GPU)" % (N, d, q),
             "metric": "VB-PCA iterations/sec", "value": steps / dt, "unit": "VB iterations/s", "steps": steps, "warmup": warmup,
@@ -139,8 +149,9 @@ def pca_workload(steps, warmup, with_cpu):
             "parity_checked_on": "a %d-row copy of the problem, %d iterations, same kernels" % (n_s, warmup + steps),
             "elbo_total": float(elbo.sum()),
             "roofline": {"bound": "hbm", "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "traffic": None,
-                         "kernel": "whole iteration (k_pca_pass1 + k_pca_pass2 + small kernels)"},
+                         "frac": alg / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "algorithmic_bytes_two_sweeps": alg2,
+                         "traffic": traffic, "traffic_source": tsrc,
+                         "kernel": "whole iteration (k_pca_pass12 + reductions + small kernels)"},
             "cpu_baseline": cpu}
 
 

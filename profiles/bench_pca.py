@@ -47,9 +47,9 @@ def main():
     rel = lambda x, y: float(np.abs(x - y).max() / np.abs(y).max())
     parity = max(rel(got["W_mean"], sst["W_mean"]), rel(got["Z"], sst["Z"]), rel(got["X"], sst["X"]), float(np.abs(ge - ref).max() / np.abs(ref).sum()))
     nmiss = float((~init["obs"]).sum())
-    # algorithmic bytes of an iteration: X is read by both passes, the byte mask by the second, Z written by the first and read by
-    # the second, the missing entries written back
-    alg = 2.0 * N * d * 8 + N * d + 2.0 * N * q * 8 + nmiss * 8
+    # algorithmic bytes of an iteration (as bench.py's workloads entry): X and the byte mask read once -- the Z and the X updates
+    # share one sweep over the rows, k_pca_pass12 --, Z written once, the missing entries written back
+    alg = 1.0 * N * d * 8 + N * d + 1.0 * N * q * 8 + nmiss * 8
     step_s = dt / a.steps
     out = {"metric": "VB-PCA iterations/sec (N=1e6 rows x 256, q=16, 10% missing); rel-err vs NumPy", "value": a.steps / dt, "unit": "VB iterations/s",
            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -58,8 +58,8 @@ def main():
                       "rel_err_vs_numpy": parity, "parity_checked_on": "a %d-row copy of the problem, %d iterations, same kernels" % (n_s, a.warmup + a.steps),
                       "elbo_total": float(elbo.sum()), "beta": float(st["beta_a"] / st["beta_b"])},
            "roofline": {"bound": "hbm", "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "traffic_source": "profiles/r02/traffic_pca_pmc.json holds the PMC bytes of the two passes (not measured in this run)",
-                        "kernel": "whole iteration (k_pca_pass1 + k_pca_pass2 + small kernels)", "algorithmic_bytes_per_iteration": alg},
+                        "traffic": None, "traffic_source": "profiles/r03/traffic_pca_pmc.json holds the PMC bytes of the sweep (not measured in this run)",
+                        "kernel": "whole iteration (k_pca_pass12 + reductions + small kernels)", "algorithmic_bytes_per_iteration": alg},
            "cpu_baseline": None if a.no_cpu_baseline else {"value": (a.warmup + a.steps) / cpu_dt * n_s / N, "unit": "VB iterations/s at N=%d (scaled from the sample)" % N,
                                                            "cores": os.cpu_count(), "kind": "port",
                                                            "sample": "%d rows, %d iterations of oracle/pca_closed_form.py in %.1f s" % (n_s, a.warmup + a.steps, cpu_dt)}}

@@ -21,7 +21,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -d $OUT/pca_$C -o t --output-format csv -- python3 $ROOT/profiles/pca_probe.py 1000000 256 16 3 > $OUT/pca_$C.log 2>&1
   mkdir -p $OUT/pcatr/$C && cp $OUT/pca_$C/t_counter_collection.csv $OUT/pcatr/$C/
 done
-python3 $ROOT/profiles/traffic_summary.py $OUT/pcatr k_pca_pass1 k_pca_pass2 k_pca_small k_pca_reduce > $OUT/traffic_pca_pmc.json
+python3 $ROOT/profiles/traffic_summary.py $OUT/pcatr k_pca_pass12 k_pca_pass1 k_pca_pass2 k_pca_small k_pca_reduce > $OUT/traffic_pca_pmc.json
 python3 $ROOT/profiles/generic_probe.py > $OUT/generic_probe.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/small_pmc -o s --output-format csv -- python3 $ROOT/profiles/headline_probe.py 3 > $OUT/small_pmc.log 2>&1
 python3 $ROOT/profiles/pmc_summary.py $OUT/small_pmc/s_counter_collection.csv $OUT/small_pmc/s_kernel_trace.csv > $OUT/small_kernels_sq.txt

@@ -10,6 +10,16 @@
 #define ENTER(h) do { ARGCHK(h, "handle is NULL"); HIPCHK(hipSetDevice((h)->device)); } while (0)
 
 
+// digamma for x > 0 (recurrence up to 10, then the asymptotic series), as the device code had it
+static double digamma_host(double x) {
+    if (!(x > 0.0)) return NAN;
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    const double ser = f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))));
+    return r + std::log(x) - 0.5 / x - ser;
+}
+
 static int alloc_d(double** p, size_t n) {
     HIPCHK(hipMalloc((void**)p, n * sizeof(double)));
     HIPCHK(hipMemset(*p, 0, n * sizeof(double)));
@@ -116,6 +126,7 @@ int pyvb_pca_set_priors(pyvb_pca* h, const double* W_pm, const double* W_pp, con
     HIPCHK(hipMemcpy(sc, h->scal, sizeof(sc), hipMemcpyDeviceToHost));
     sc[PS_BETA_A0] = beta_a0; sc[PS_BETA_B0] = beta_b0;
     sc[PS_BETA_A] = beta_a0 + 0.5 * (double)h->d * (double)h->N_total;      // Gamma.update_a, nodes_todo.py:125-128
+    sc[PS_LGAMMA_A0] = std::lgamma(beta_a0); sc[PS_LGAMMA_A] = std::lgamma(sc[PS_BETA_A]); sc[PS_DIGAMMA_A] = digamma_host(sc[PS_BETA_A]);
     sc[PS_QLD_Z] = sc[PS_QLD_X] = sc[PS_QLD_MU] = NAN;
     HIPCHK(hipMemcpy(h->scal, sc, sizeof(sc), hipMemcpyHostToDevice));
     std::vector<double> nanq((size_t)h->q, (double)NAN);        // no column has been updated on this handle yet
@@ -307,7 +318,6 @@ static int full_stats(pyvb_pca* h, long lo_upd, long hi_upd) {
         if (rc) return rc;
     } else if ((rc = pca_launch_pass2(h, lo_upd, hi_upd))) return rc;
     if ((rc = pca_launch_reduce(h, 0))) return rc;
-    HIPCHK(hipMemcpyAsync(h->sx_local, h->stats + h->SL.osx, h->DP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     if (h->comm && (rc = pyvb_allreduce_f64(h->comm, h->stats, h->SL.total, h->stream))) return rc;
     h->full_valid = h->lin_valid = true;
     if (hi_upd > lo_upd) h->res_valid = false;          // rows changed: the cached residual of the last Beta update is stale
@@ -419,6 +429,22 @@ int pyvb_pca_iterate(pyvb_pca* h, int niters) {
     ARGCHK(niters >= 0, "niters must be >= 0");
     int rc;
     for (int it = 0; it < niters; ++it) {
+        if (!h->comm) {
+            // Without a communicator nothing sits between the small steps of the crawl order but their own data: they run as three
+            // launches (W, Z-prepare | X_0, Mu | Beta, bound) around the one sweep over the rows; same code, same order, same flags
+            // as the calls of the general path below.
+            if ((rc = ensure_full(h))) return rc;                       // update_W
+            h->z_pending = true; h->z0_done = false;                    // update_Z, deferred (lin_valid holds after ensure_full)
+            if ((rc = pca_launch_small(h, PCA_RUN_HEAD))) { h->z_pending = false; return rc; }
+            h->full_valid = false; h->res_valid = false;
+            if ((rc = pca_launch_small(h, PCA_RUN_MID))) return rc;     // x0_step, update_Mu
+            h->z0_done = h->row_offset == 0;                            // the kernel stored z_0 if this handle holds global row 0
+            if ((rc = x_rows(h, h->row_offset == 0 ? 1 : 0, h->N))) return rc;
+            if ((rc = ensure_full(h))) return rc;                       // N == 1: no row left for x_rows, the sweep still has to run
+            if ((rc = pca_launch_small(h, PCA_RUN_TAIL))) return rc;    // update_Beta, elbo
+            h->res_valid = true;
+            continue;
+        }
         if ((rc = pyvb_pca_update_W(h))) return rc;
         if ((rc = pyvb_pca_update_Z(h))) return rc;
         const long first = h->row_offset == 0 ? 1 : 0;         // global row 0 lives on the rank with offset 0

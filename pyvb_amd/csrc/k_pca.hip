@@ -13,6 +13,7 @@
 // Small single-workgroup kernels do the q x q / d-vector work (W columns, Sigma_z, Mu, Beta, lower bound).
 #include "pca.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 #define LN2PI 1.8378770664093453
@@ -23,12 +24,13 @@ struct PcaArgs {
     double *W_mean, *W_var, *Mu_mean, *Mu_var, *Z_cov, *qld_W;
     const double *W_pm, *W_pp, *Mu_pm, *Mu_pp;
     double* scal; double* Gz; double* g0; double* sx_local;
-    double* part; double* stats; double* aux; double* elbo; int* status;
+    double* part; double* stats; double* aux; double* aux_tail; double* elbo; int* status;     // aux_tail: the [sum z | delta of sum x] vector
     long N, N_total, chunk_rows, lo_upd, hi_upd, n_part_missing, n_none_rows, row_offset;
     int d, q, DP, QP, DT, QT, nchunk, mode;
     int res_cached;     // PCA_ELBO: scal[PS_RES] holds the residual already
     int keep_z0;        // Z of global row 0 is final already (k_pca_pass12, k_pca_pass1)
     int z_deferred;     // PCA_PREPZ: also form sum z analytically;  PCA_X0: Z of row 0 is formed here
+    int x0_prep;        // PCA_X0: first set the sum-z half of aux_tail: 1 from the statistics, 2 zero (a rank that does not own row 0); 0: the host has
     PcaStatsLayout SL;
 };
 
@@ -282,19 +284,25 @@ __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
 // keep_z0: global row 0 has had its own update since Z was defined (Xs[0].update() comes before Mu in the crawl order): its z
 // was stored by that step and is taken from Z instead of being recomputed from the changed row.
 // ---------------------------------------------------------------------------------------------------
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wavefront's outstanding global loads and
+// stores (s_waitcnt vmcnt(0)): in k_pca_pass12 that would wait for the tiles fetched ahead and for the write-back at every step.
+// The wavefronts of that kernel exchange data through LDS only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define P12_XS 36       // row stride (doubles) of the transposition buffer: 32 columns + pad, 32-byte aligned rows
 template <int QT, bool PIN>     // PIN as in k_pca_pass2
 __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     extern __shared__ double lds12[];
+    constexpr int RT = QT == 1 ? 2 : 1;         // tiles per step (register budget: 256 at two wavefronts per SIMD)
+    constexpr int PF = 2 * RT;                  // register sets of X tiles: the tiles of this step and of the next
     const int nw = blockDim.x >> 6;
-    double* zp = lds12;                                 // [nw][QT][4][64] accumulator dumps of the partial products
-    double* zf = zp + (size_t)nw * QT * 256;            // [QT][4][64] Z of the 16 rows, accumulator layout
-    double* zT = zf + QT * 256;                         // [QP][17] the same, latent index major (the operand of the prediction)
-    double* xt = zT + QT * 16 * 17 + (size_t)(threadIdx.x >> 6) * 16 * P12_XS;      // [16][P12_XS] per wavefront
+    double* zp = lds12;                                 // [RT][nw][QT][4][64] accumulator dumps of the partial products
+    double* zf = zp + (size_t)RT * nw * QT * 256;       // [RT][QT][4][64] Z of the step's rows, accumulator layout
+    double* zT = zf + RT * QT * 256;                    // [RT][QP][17] the same, latent index major (the operand of the prediction)
+    double* xt = zT + RT * QT * 16 * 17 + (size_t)(threadIdx.x >> 6) * RT * 16 * P12_XS;      // [RT][16][P12_XS] per wavefront
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, qk = lane >> 4;
     const int DP = a.DP, QP = a.QP, d = a.d, q = a.q, DS = DP / 4;
     constexpr int QS = 4 * QT;
-    constexpr int PF = QT == 1 ? 4 : 2;         // tiles of X in flight per wavefront (register budget: 256 at two wavefronts per SIMD)
     const long r0 = (long)blockIdx.x * a.chunk_rows;
     const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
     // ---- constant operands of this wavefront's two column tiles j = 2 wave + jj
@@ -353,103 +361,121 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     };
 #pragma unroll
     for (int u = 0; u < PF; ++u) fetch(16u * u < nrows ? 16u * u : 0u, xq[u], mq[u]);
-    auto tile = [&](unsigned n0, d4 (&xa)[2], unsigned (&ma)[2]) {
+    // A step takes RT tiles through the four stages between two barriers.  Measured with cycle stamps per tile (one tile per step, d = 256,
+    // q = 16): stage 1 560, stage 2 790 (four of the eight wavefronts), stage 3 1900-2300, stage 4 1100-1500 cycles, against 3 x 1024
+    // for the 48 MFMAs the two wavefronts of a SIMD issue: the sweep runs at the pace of its dependent chains (MFMA -> select -> LDS
+    // -> MFMA), not of HBM; the write-back of the imputed entries (34 % of the 32-byte sectors) costs 0.22 of the 0.94 ms.
+    auto step = [&](unsigned nbase, auto U0) {
+        constexpr int u0 = decltype(U0)::value;
         // ---- 1. this wavefront's part of Z
-        d4 zacc[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            zacc[t] = d4{0, 0, 0, 0};
+        for (int rt = 0; rt < RT; ++rt) {
+            d4 zacc[QT];
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+            for (int t = 0; t < QT; ++t) {
+                zacc[t] = d4{0, 0, 0, 0};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) zacc[t] = MFMA(xa[jj][e], gz[jj][e][t], zacc[t]);
+                for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) zp[((size_t)(wave * QT + t) * 4 + r) * 64 + lane] = zacc[t][r];
+                    for (int e = 0; e < 4; ++e) zacc[t] = MFMA(xq[u0 + rt][jj][e], gz[jj][e][t], zacc[t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zp[((size_t)((rt * nw + wave) * QT + t) * 4 + r) * 64 + lane] = zacc[t][r];
+            }
         }
-        __syncthreads();
-        // ---- 2. sum of the parts: thread = (t, r, lane) element of the accumulator layout
-        for (int el = tid; el < QT * 256; el += blockDim.x) {
-            const int t = el >> 8, r = (el >> 6) & 3, ln = el & 63, cc = ln & 15, qq = ln >> 4;
+        lds_barrier();
+        // ---- 2. sum of the parts: thread = (rt, t, r, lane) element of the accumulator layout
+        for (int el = tid; el < RT * QT * 256; el += blockDim.x) {
+            const int rt = el / (QT * 256), e2 = el % (QT * 256);
+            const int t = e2 >> 8, r = (e2 >> 6) & 3, ln = e2 & 63, cc = ln & 15, qq = ln >> 4;
             double s = -(QT == 1 || t == 0 ? g0r[0] : g0r[QT - 1]);
-            for (int w2 = 0; w2 < nw; ++w2) s += zp[((size_t)(w2 * QT + t) * 4 + r) * 64 + ln];
-            const unsigned row = n0 + 4 * r + qq;
+            double pz[8];                               // all parts requested at once (a dependent loop costs eight LDS round trips)
+#pragma unroll
+            for (int w2 = 0; w2 < 8; ++w2) pz[w2] = zp[((size_t)((rt * nw + (w2 < nw ? w2 : 0)) * QT + t) * 4 + r) * 64 + ln];
+#pragma unroll
+            for (int w2 = 0; w2 < 8; ++w2) s += w2 < nw ? pz[w2] : 0.0;
+            const unsigned row = nbase + 16 * rt + 4 * r + qq;
             if (row < nrows) {
                 if (z0_here && row == 0) s = Zc[16 * t + cc];
                 else Zc[(size_t)row * QP + 16 * t + cc] = s;
             }
             zf[el] = row < nrows ? s : 0.0;
-            zT[(16 * t + cc) * 17 + 4 * r + qq] = s;
+            zT[(size_t)rt * QT * 16 * 17 + (16 * t + cc) * 17 + 4 * r + qq] = s;
         }
-        __syncthreads();
-        double za[QS], zb[4][QT];
+        lds_barrier();
 #pragma unroll
-        for (int s = 0; s < QS; ++s) za[s] = zT[(4 * s + qk) * 17 + c];
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned n0 = nbase + 16 * rt;
+            d4 (&xa)[2] = xq[u0 + rt];
+            unsigned (&ma)[2] = mq[u0 + rt];
+            double za[QS], zb[4][QT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < QT; ++t) zb[s][t] = zf[(size_t)t * 256 + s * 64 + lane];
-        // ---- 3. prediction, imputation, write-back
-        const unsigned rowl = n0 + c;
-        const bool rowupd = rowl < nrows && rowl >= lo && rowl < hi;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            d4 pred = mu4[jj];
-#pragma unroll
-            for (int s = 0; s < QS; ++s) pred = MFMA(wa[jj][s], za[s], pred);
-            d4 v = xa[jj];
-            bool any = false;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (rowupd && ((ma[jj] >> (8 * e)) & 0xffu) == 0) { v[e] = pred[e]; any = true; }
-            if (PIN && rowupd && tok[jj] && !a.pinned[r0 + rowl]) {          // first update of a row that still carries its initial mean
-                const d4 dat = *reinterpret_cast<const d4*>(a.Xdata + (size_t)(r0 + rowl) * DP + 32 * wave + 16 * jj + 4 * qk);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)                                  // everywhere: the observed entries take their data
-                    if (((ma[jj] >> (8 * e)) & 0xffu) != 0) v[e] = dat[e];
-                any = true;
-            }
-            if (any && tok[jj]) *reinterpret_cast<d4*>(Xc + (size_t)rowl * DP + 32 * wave + 16 * jj + 4 * qk) = v;
-            *reinterpret_cast<d4*>(xt + c * P12_XS + 16 * jj + 4 * qk) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- 4. statistics on the transposed tile: element r of tile p = row n0 + 4 r + qk, column col0 + p
-        d4 xn[P2T];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const d2 v = *reinterpret_cast<const d2*>(xt + (4 * r + qk) * P12_XS + 2 * c);
-            const bool live = (n0 + 4 * r + qk < nrows) && colok;
-#pragma unroll
-            for (int p = 0; p < P2T; ++p) {
-                const double x = live ? v[p] : 0.0;
-                xn[p][r] = x; sx[p] += x; sxx += x * x;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int p = 0; p < P2T; ++p)
+            for (int s = 0; s < QS; ++s) za[s] = zT[(size_t)rt * QT * 16 * 17 + (4 * s + qk) * 17 + c];
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int t = 0; t < QT; ++t) sxz[p][t] = MFMA(xn[p][s], zb[s][t], sxz[p][t]);
-        if (wave == 0) {
+                for (int t = 0; t < QT; ++t) zb[s][t] = zf[(size_t)(rt * QT + t) * 256 + s * 64 + lane];
+            // ---- 3. prediction, imputation, write-back
+            const unsigned rowl = n0 + c;
+            const bool rowupd = rowl < nrows && rowl >= lo && rowl < hi;
+            double* const xtr = xt + rt * 16 * P12_XS;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int jj = 0; jj < 2; ++jj) {
+                d4 pred = mu4[jj];
 #pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    sz[t] += zb[s][t];
+                for (int s = 0; s < QS; ++s) pred = MFMA(wa[jj][s], za[s], pred);
+                d4 v = xa[jj];
+                bool any = false;
 #pragma unroll
-                    for (int u = 0; u < QT; ++u) szz[t][u] = MFMA(zb[s][t], zb[s][u], szz[t][u]);
+                for (int e = 0; e < 4; ++e)
+                    if (rowupd && ((ma[jj] >> (8 * e)) & 0xffu) == 0) { v[e] = pred[e]; any = true; }
+                if (PIN && rowupd && tok[jj] && !a.pinned[r0 + rowl]) {          // first update of a row that still carries its initial mean
+                    const d4 dat = *reinterpret_cast<const d4*>(a.Xdata + (size_t)(r0 + rowl) * DP + 32 * wave + 16 * jj + 4 * qk);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)                                  // everywhere: the observed entries take their data
+                        if (((ma[jj] >> (8 * e)) & 0xffu) != 0) v[e] = dat[e];
+                    any = true;
                 }
+                if (any && tok[jj]) *reinterpret_cast<d4*>(Xc + (size_t)rowl * DP + 32 * wave + 16 * jj + 4 * qk) = v;
+                *reinterpret_cast<d4*>(xtr + c * P12_XS + 16 * jj + 4 * qk) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- 4. statistics on the transposed tile: element r of tile p = row n0 + 4 r + qk, column col0 + p
+            d4 xn[P2T];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const d2 v = *reinterpret_cast<const d2*>(xtr + (4 * r + qk) * P12_XS + 2 * c);
+                const bool live = (n0 + 4 * r + qk < nrows) && colok;
+#pragma unroll
+                for (int p = 0; p < P2T; ++p) {
+                    const double x = live ? v[p] : 0.0;
+                    xn[p][r] = x; sx[p] += x; sxx += x * x;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < P2T; ++p)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) sxz[p][t] = MFMA(xn[p][s], zb[s][t], sxz[p][t]);
+            if (wave == 0) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        sz[t] += zb[s][t];
+#pragma unroll
+                        for (int u = 0; u < QT; ++u) szz[t][u] = MFMA(zb[s][t], zb[s][u], szz[t][u]);
+                    }
+            }
+            const unsigned nn = n0 + 16 * PF;              // this register set is free again: the tile PF further on
+            fetch(nn < nrows ? nn : n0, xa, ma);
         }
-        const unsigned nn = n0 + 16 * PF;              // this register set is free again: the tile PF further on
-        fetch(nn < nrows ? nn : n0, xa, ma);
     };
     for (unsigned base = 0; base < nrows; base += 16 * PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (base + 16 * u < nrows) tile(base + 16 * u, xq[u], mq[u]);
+        step(base, std::integral_constant<int, 0>{});
+        if (base + 16 * RT < nrows) step(base + 16 * RT, std::integral_constant<int, RT>{});
     }
     // ---- partial sums of this chunk, laid out as k_pca_pass2's
     double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
@@ -522,6 +548,7 @@ __global__ void __launch_bounds__(256) k_pca_reduce(PcaArgs a, int what, int sta
         double s = 0.0;
         for (int y = 0; y < PCA_RED; ++y) s += red2[(size_t)y * n + idx];
         if (what == 1) a.aux[(size_t)4 * a.nchunk * a.QP + idx] = s; else a.stats[idx] = s;
+        if (what == 0 && idx >= a.SL.osx && idx < a.SL.osx + (size_t)a.DP) a.sx_local[idx - a.SL.osx] = s;      // this rank's own sum of x (before the all-reduce)
         return;
     }
     const int y = blockIdx.y;
@@ -556,14 +583,6 @@ __device__ static double bsum(double v, double* red) {      // block-wide sum, 2
     return s;
 }
 
-__device__ static double digamma_pos(double x) {
-    double r = 0.0;
-    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
-    const double f = 1.0 / (x * x);
-    const double ser = f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))));
-    return r + log(x) - 0.5 / x - ser;
-}
-
 // <W^T W>[i][j] for independent Gaussian columns (node.py:213-227 with an isotropic child precision) -> wtw [q][q] in LDS.
 // <W> is staged into wst [d][q] first (one coalesced sweep instead of d dependent trips to L2 per thread) and stays there.
 __device__ static void wtw_lds(const PcaArgs& a, double* wtw, double* wst) {
@@ -578,11 +597,21 @@ __device__ static void wtw_lds(const PcaArgs& a, double* wtw, double* wst) {
         wtw[idx] = s;
     }
     __syncthreads();
-    for (int i = wave; i < q; i += 4) {                 // + sum_k var(W[k][i]) on the diagonal, a wavefront per column
-        double s = 0.0;
-        for (int k = lane; k < d; k += 64) s += a.W_var[(size_t)i * d + k];
-        s = wsum(s);
-        if (lane == 0) wtw[i * q + i] += s;
+    // + sum_k var(W[k][i]) on the diagonal, a wavefront per column (i = wave, wave + 4, ..: up to eight columns, d <= 256: four
+    // entries per lane); the loads of all of them are issued before the first sum (one trip to L2 instead of one per column)
+    double wv[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = wave + 4 * u, k = lane + 64 * v;
+            wv[u][v] = (i < q && k < d) ? a.W_var[(size_t)i * d + k] : 0.0;
+        }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = wave + 4 * u;
+        const double sv = wsum((wv[u][0] + wv[u][1]) + (wv[u][2] + wv[u][3]));
+        if (lane == 0 && i < q) wtw[i * q + i] += sv;
     }
     __syncthreads();
 }
@@ -609,123 +638,127 @@ __device__ static double residual(const PcaArgs& a, const double* wtw, const dou
     return S[a.SL.osxx] + S[a.SL.osxv] + tot;
 }
 
-__global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
-    __shared__ double sm[64 * 64 + 64 * 64 + 64], red[4], wst[256 * 32];     // wst: <W> [d][q] staged by wtw_lds
+// One instantiation per mode: these kernels run once per iteration on one CU, straight through, so their cost is the number of
+// instruction-cache lines they touch and the round trips to L2 they wait for (measured: the W update took 43 us as a fully
+// unrolled 32 x 32 register kernel, most of it instruction fetch); loops stay rolled, per-thread vectors live in LDS.
+template <int MODE>
+__device__ __forceinline__ void pca_small_body(const PcaArgs& a, double* sm, double* red, double* wst) {
     const int tid = threadIdx.x, d = a.d, q = a.q, QP = a.QP, DP = a.DP;
     const double* S = a.stats;
     const double beta = a.scal[PS_BETA_A] / a.scal[PS_BETA_B];
     const double N = (double)a.N_total;
-    if (a.mode == PCA_W) {
+    if constexpr (MODE == PCA_W) {
         // [w.update() for w in Ws]: rows of W decouple (isotropic beta, diagonal priors); thread = row k
         // message chain hstack -> Mult(W, z_n) -> Addition(., Mu) -> X_n: (beta I, beta (x_n - <Mu>))
         double* szz = sm;                                   // Szz = sum z z^T + N Sigma_z  [q][q]
         for (int idx = tid; idx < q * q; idx += 256) szz[idx] = S[a.SL.oSzz + (size_t)(idx / q) * QP + idx % q] + N * a.Z_cov[idx];
         __syncthreads();
         const int k = tid;
-        double w[32];                                       // q <= 32; constant indices keep the row in registers
+        // thread = row k; its row of <W> (wl), and per block of 16 columns the prior precisions -> new variances (pv) and the linear
+        // terms -> log precisions (hl), in LDS columns of its own: the chain over the columns is a rolled loop without a global access
+        double* wl = wst;                                   // [32][256]
+        double* pv = sm + 32 * 32;                          // [16][256]
+        double* hl = pv + 16 * 256;                         // [16][256]
+        double* lred = hl + 16 * 256;                       // [4][32] wavefront sums of the log precisions
+        const double muk = k < d ? a.Mu_mean[k] : 0.0;
+#pragma unroll 8
+        for (int i = 0; i < q; ++i) wl[i * 256 + tid] = k < d ? a.W_mean[(size_t)k * q + i] : 0.0;
+        for (int i0 = 0; i0 < q; i0 += 16) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) w[i] = (k < d && i < q) ? a.W_mean[(size_t)k * q + (i < q ? i : 0)] : 0.0;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if (i < q) {                                    // block-uniform
-                double lp = 0.0;
-                if (k < d) {
+            for (int ii = 0; ii < 16; ++ii) {
+                const int i = i0 + ii;
+                if (i < q && k < d) {
                     const double pp = a.W_pp[(size_t)i * d + k];
-                    const double prec = pp + beta * szz[i * q + i];
-                    double acc = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 32; ++j)
-                        if (j != i && j < q) acc += szz[i * q + j] * w[j];
-                    const double h = S[a.SL.oSxz + (size_t)k * QP + i] - a.Mu_mean[k] * S[a.SL.osz + i];
-                    w[i] = (pp * a.W_pm[(size_t)k * q + i] + beta * (h - acc)) / prec;
-                    a.W_var[(size_t)i * d + k] = 1.0 / prec;
-                    lp = 0.5 * log(prec);
+                    pv[ii * 256 + tid] = pp;
+                    hl[ii * 256 + tid] = pp * a.W_pm[(size_t)k * q + i] + beta * (S[a.SL.oSxz + (size_t)k * QP + i] - muk * S[a.SL.osz + i]);
                 }
-                lp = bsum(lp, red);
-                if (tid == 0) a.qld_W[i] = 0.5 / lp;         // gaussian.py:120 (quirk Q1)
+            }
+            if (k < d) {
+                for (int ii = 0; ii < 16 && i0 + ii < q; ++ii) {
+                    const int i = i0 + ii;
+                    const double* srow = szz + i * q;
+                    double acc = 0.0;
+#pragma unroll 4
+                    for (int j = 0; j < q; ++j) acc += (j != i ? srow[j] : 0.0) * wl[j * 256 + tid];
+                    const double prec = pv[ii * 256 + tid] + beta * srow[i];
+                    wl[i * 256 + tid] = (hl[ii * 256 + tid] - beta * acc) / prec;
+                    pv[ii * 256 + tid] = 1.0 / prec;
+                    hl[ii * 256 + tid] = 0.5 * log(prec);
+                }
+            }
+            for (int ii = 0; ii < 16 && i0 + ii < q; ++ii) {
+                const int i = i0 + ii;
+                if (k < d) { a.W_mean[(size_t)k * q + i] = wl[i * 256 + tid]; a.W_var[(size_t)i * d + k] = pv[ii * 256 + tid]; }
+                const double v = wsum(k < d ? hl[ii * 256 + tid] : 0.0);
+                if ((tid & 63) == 0) lred[(tid >> 6) * 32 + i] = v;
             }
         }
-        if (k < d) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i)
-                if (i < q) a.W_mean[(size_t)k * q + i] = w[i];
-        }
-    } else if (a.mode == PCA_PREPZ) {
+        __syncthreads();
+        if (tid < q) a.qld_W[tid] = 0.5 / (((lred[tid] + lred[32 + tid]) + lred[64 + tid]) + lred[96 + tid]);      // gaussian.py:120 (quirk Q1)
+    } else if constexpr (MODE == PCA_PREPZ) {
         // posterior of the Z_n: precision I + beta <W^T W>, shared by all n; Gz = beta Sigma_z <W>^T
         double* P = sm; double* Sg = sm + 64 * 64;
         wtw_lds(a, Sg, wst);
+        double* Pn = sm + 32 * 32;                          // the second of the two buffers the elimination alternates between
         for (int idx = tid; idx < q * q; idx += 256) P[idx] = ((idx / q == idx % q) ? 1.0 : 0.0) + beta * Sg[idx];
         __syncthreads();
-        // Gauss-Jordan inverse in place (SPD, no pivoting); log det from the pivots
+        // Gauss-Jordan inverse (SPD, no pivoting), out of one buffer into the other: one barrier per pivot; log det from the pivots
         double logdet = 0.0;
         for (int p = 0; p < q; ++p) {
             const double piv = P[p * q + p];
             if (tid == 0 && !(piv > 0.0)) atomicOr(a.status, 1);
             logdet += log(piv);
             const double dinv = 1.0 / piv;
-            __syncthreads();
-            double nv[16];
-            int cnt = 0;
-            for (int idx = tid; idx < q * q; idx += 256, ++cnt) {
+            for (int idx = tid; idx < q * q; idx += 256) {
                 const int i = idx / q, j = idx % q;
                 const double cij = P[i * q + p], rpj = P[p * q + j];
-                nv[cnt] = (i == p) ? ((j == p) ? dinv : rpj * dinv) : ((j == p) ? -cij * dinv : P[idx] - cij * rpj * dinv);
+                Pn[idx] = (i == p) ? ((j == p) ? dinv : rpj * dinv) : ((j == p) ? -cij * dinv : P[idx] - cij * rpj * dinv);
             }
             __syncthreads();
-            cnt = 0;
-            for (int idx = tid; idx < q * q; idx += 256, ++cnt) P[idx] = nv[cnt];
-            __syncthreads();
+            double* tsw = P; P = Pn; Pn = tsw;
         }
         for (int idx = tid; idx < q * q; idx += 256) a.Z_cov[idx] = P[idx];
         if (tid == 0) a.scal[PS_QLD_Z] = 0.5 / (0.5 * logdet);
-        // Gz[i][k] = beta sum_j Sigma_z[i][j] W[k][j], stored as pass 1's B operands; g0 = Gz <Mu>
+        // Gz[i][k] = beta sum_j Sigma_z[i][j] W[k][j], stored as pass 1's B operands (thread = position in the block: padded
+        // positions get their zero in the same pass; Sigma_z is read through its transpose -- it is symmetric -- so that the lanes of a
+        // wavefront, which differ in i, read consecutive words, and share the row of <W>);  g0 = Gz <Mu>
         const int DS = DP / 4;
-        for (int idx = tid; idx < a.QT * DS * 64; idx += 256) a.Gz[idx] = 0.0;
-        __syncthreads();
-        for (int idx = tid; idx < q * d; idx += 256) {
-            const int i = idx / d, k = idx % d;
-            double s = 0.0;
-            for (int j = 0; j < q; ++j) s += P[i * q + j] * wst[k * q + j];
-            a.Gz[gz_pos(i, k, DS)] = beta * s;
+        for (int pos = tid; pos < a.QT * DS * 64; pos += 256) {
+            const int t = pos / (DS * 64), sk = (pos >> 6) % DS, ln = pos & 63;
+            const int i = 16 * t + (ln & 15), k = 16 * (sk >> 2) + 4 * (ln >> 4) + (sk & 3);
+            double sgz = 0.0;
+            if (i < q && k < d)
+                for (int j = 0; j < q; ++j) sgz += P[j * q + i] * wst[k * q + j];
+            a.Gz[pos] = beta * sgz;
         }
-        double* mus = Sg + 64;                              // <Mu> staged; Sg[0..q) then holds t_j = sum_k W[k][j] <Mu>_k
-        if (tid < d) mus[tid] = a.Mu_mean[tid];
+        // t_j = sum_k W[k][j] <Mu>_k (first wavefront) and, for the deferred update, u_j = sum_k W[k][j] (sum x)_k (second wavefront):
+        // what Mu.update() needs of the new Z is sum_n z_n = Gz sum_n x_n - N g0 = beta Sigma_z (u - N t), linear in the sum of x kept
+        // from the last sweep (this rank's rows: sx_local and N are local, the result is all-reduced like the sum pass 1 delivered)
+        double* mus = Sg + 64;                              // <Mu> staged
+        double* sxl = mus + 256;                            // sum x staged
+        double* tu = sxl + 256;                             // t [32], u [32]
+        if (tid < d) { mus[tid] = a.Mu_mean[tid]; sxl[tid] = a.z_deferred ? a.sx_local[tid] : 0.0; }
         __syncthreads();
-        if (tid < q) {
-            double s = 0.0;
-            for (int k = 0; k < d; ++k) s += wst[k * q + tid] * mus[k];
-            Sg[tid] = s;
+        if ((tid & 63) < q && tid < 128) {
+            const double* vec = tid < 64 ? mus : sxl;
+            const int j = tid & 63;
+            double sv = 0.0;
+            for (int k = 0; k < d; ++k) sv += wst[k * q + j] * vec[k];
+            tu[(tid >> 6) * 32 + j] = sv;
         }
         __syncthreads();
         if (tid < QP) {
-            double s = 0.0;
-            if (tid < q) for (int j = 0; j < q; ++j) s += P[tid * q + j] * Sg[j];
-            a.g0[tid] = beta * s;
+            double sg = 0.0, su = 0.0;
+            if (tid < q)
+                for (int j = 0; j < q; ++j) { sg += P[tid * q + j] * tu[j]; su += P[tid * q + j] * (tu[32 + j] - (double)a.N * tu[j]); }
+            a.g0[tid] = beta * sg;
+            if (a.z_deferred) a.aux_tail[tid] = beta * su;
         }
-        if (a.z_deferred) {
-            // the rows are not touched yet (k_pca_pass12 forms Z on its way through X); what Mu.update() needs of the new Z is
-            // sum_n z_n = Gz sum_n x_n - N g0 = beta Sigma_z (W^T sum x - N W^T <Mu>), linear in the sum of x kept from the last sweep
-            double* us = mus + 256;
-            __syncthreads();
-            // (this rank's rows: sx_local and N are local, the result is all-reduced like the sum pass 1 used to deliver)
-            if (tid < d) mus[tid] = a.sx_local[tid];
-            __syncthreads();
-            if (tid < q) {
-                double s = 0.0;
-                for (int k = 0; k < d; ++k) s += wst[k * q + tid] * mus[k];
-                us[tid] = s - (double)a.N * Sg[tid];
-            }
-            __syncthreads();
-            if (tid < QP) {
-                double s = 0.0;
-                if (tid < q) for (int j = 0; j < q; ++j) s += P[tid * q + j] * us[j];
-                a.aux[tid] = beta * s;
-            }
-            if (tid < DP) a.aux[QP + tid] = 0.0;         // no change of sum x
-        }
-    } else if (a.mode == PCA_X0) {
+        if (a.z_deferred && tid < DP) a.aux_tail[QP + tid] = 0.0;     // no change of sum x
+    } else if constexpr (MODE == PCA_X0) {
         // Xs[0].update() alone (the crawl order puts it before Mu): aux = [sz (QP) | delta of sum x (DP)]
-        double* dsx = a.aux + QP;
+        double* dsx = a.aux_tail + QP;
+        if (a.x0_prep && tid < QP) a.aux_tail[tid] = a.x0_prep == 1 ? S[a.SL.osz + tid] : 0.0;     // the sum of z travels once, from the owner of row 0
         if (tid < DP) dsx[tid] = 0.0;
         __syncthreads();
         if (a.row_offset == 0 && a.z_deferred) {
@@ -755,11 +788,11 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         }
         __syncthreads();
         if (tid < DP) a.sx_local[tid] += dsx[tid];          // this rank's own sum of x follows its row
-    } else if (a.mode == PCA_APPLY) {
+    } else if constexpr (MODE == PCA_APPLY) {
         // after the all-reduce of aux: the new sum of z replaces the old one, the sum of x moves by the delta
-        if (tid < QP) a.stats[a.SL.osz + tid] = a.aux[tid];
-        if (tid < DP) a.stats[a.SL.osx + tid] += a.aux[QP + tid];
-    } else if (a.mode == PCA_MU) {
+        if (tid < QP) a.stats[a.SL.osz + tid] = a.aux_tail[tid];
+        if (tid < DP) a.stats[a.SL.osx + tid] += a.aux_tail[QP + tid];
+    } else if constexpr (MODE == PCA_MU) {
         // Mu.update(): N Addition children, each sends (beta I, beta (x_n - <W><z_n>))
         double lp = 0.0;
         if (tid < d) {
@@ -773,12 +806,12 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         }
         lp = bsum(lp, red);
         if (tid == 0) a.scal[PS_QLD_MU] = 0.5 / lp;
-    } else if (a.mode == PCA_BETA) {
+    } else if constexpr (MODE == PCA_BETA) {
         // Beta.update(): Gamma, traces (nodes_todo.py:130-138)
         wtw_lds(a, sm, wst);
         const double res = residual(a, sm, wst, red);
         if (tid == 0) { a.scal[PS_BETA_B] = a.scal[PS_BETA_B0] + 0.5 * res; a.scal[PS_RES] = res; }
-    } else if (a.mode == PCA_ELBO) {
+    } else if constexpr (MODE == PCA_ELBO) {
         double res;
         if (a.res_cached) {
             res = a.scal[PS_RES];
@@ -797,20 +830,16 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         if (tid < q) tr = S[a.SL.oSzz + (size_t)tid * QP + tid] + N * a.Z_cov[tid * q + tid];
         tr = bsum(tr, red);
         const double LZ = N * (-0.5 * q * LN2PI) - 0.5 * tr + N * (0.5 * q * LN2PI + 0.5 * a.scal[PS_QLD_Z] + 0.5 * q);
-        // W columns and Mu against their Constant parents
-        // one column after the other, thread = row (d <= 256): log and trace terms summed over the block
+        // W columns and Mu against their Constant parents: thread = row (d <= 256) adds its terms of all columns, one block sum
         double lw = 0.0;
-        for (int i = 0; i < q; ++i) {
-            double lndet = 0.0, t2 = 0.0;
-            if (tid < d) {
-                const int k = tid;
+        if (tid < d) {
+            const int k = tid;
+            for (int i = 0; i < q; ++i) {
                 const double pp = a.W_pp[(size_t)i * d + k], w = a.W_mean[(size_t)k * q + i], pm = a.W_pm[(size_t)k * q + i];
-                lndet = log(pp);
-                t2 = pp * (w * w + a.W_var[(size_t)i * d + k] + pm * pm - 2.0 * w * pm);
+                lw += 0.5 * log(pp) - 0.5 * pp * (w * w + a.W_var[(size_t)i * d + k] + pm * pm - 2.0 * w * pm);
             }
-            const double tot = bsum(0.5 * lndet - 0.5 * t2, red);
-            if (tid == 0) lw += -0.5 * d * LN2PI + tot + 0.5 * d * LN2PI + 0.5 * a.qld_W[i] + 0.5 * d;
         }
+        if (tid < q) lw += 0.5 * a.qld_W[tid] + 0.5 * d;        // (- d/2 ln 2 pi of the prior term + d/2 ln 2 pi of the entropy cancel)
         const double LW = bsum(lw, red);
         double lm = 0.0;
         if (tid < d) {
@@ -820,12 +849,21 @@ __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
         const double LM = bsum(lm, red) - 0.5 * d * LN2PI + 0.5 * d * LN2PI + 0.5 * a.scal[PS_QLD_MU] + 0.5 * d;
         if (tid == 0) {
             const double a0 = a.scal[PS_BETA_A0], b0 = a.scal[PS_BETA_B0];
-            const double Elnx = digamma_pos(qa) - log(qb);
-            double LB = (a0 - 1.0) * Elnx - lgamma(a0) + a0 * log(b0) - b0 * beta;
-            LB -= (qa - 1.0) * Elnx - lgamma(qa) + qa * log(qb) - qb * beta;
+            const double Elnx = a.scal[PS_DIGAMMA_A] - log(qb);
+            double LB = (a0 - 1.0) * Elnx - a.scal[PS_LGAMMA_A0] + a0 * log(b0) - b0 * beta;
+            LB -= (qa - 1.0) * Elnx - a.scal[PS_LGAMMA_A] + qa * log(qb) - qb * beta;
             a.elbo[0] = LW; a.elbo[1] = LZ; a.elbo[2] = LX; a.elbo[3] = LM; a.elbo[4] = LB;
         }
     }
+}
+
+// The small steps of an iteration come in runs (W, Z-prepare | X_0, apply, Mu | Beta, bound): a run is one launch, its steps
+// separated by a barrier and a fence (the steps talk through global memory; they are the same code that runs alone).
+template <int... MODES>
+__global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
+    __shared__ double sm[64 * 64 + 64 * 64 + 64 + 1088], red[4], wst[256 * 32];     // wst: <W> [d][q] staged by wtw_lds
+    int first = 1;
+    ((first ? (void)(first = 0) : (__threadfence(), __syncthreads()), pca_small_body<MODES>(a, sm, red, wst)), ...);
 }
 
 // q_ln_det (gaussian.py:120, quirk Q1) of every X_n that has no observed entry -- a latent node with qprec = I / var_n --
@@ -842,20 +880,31 @@ static PcaArgs pca_args(pyvb_pca* h) {
     a.X = h->X; a.M = h->M; a.xvar = h->xvar; a.nmiss = h->nmiss; a.Z = h->Z; a.Xdata = h->Xdata; a.pinned = h->pinned;
     a.W_mean = h->W_mean; a.W_var = h->W_var; a.Mu_mean = h->Mu_mean; a.Mu_var = h->Mu_var; a.Z_cov = h->Z_cov; a.qld_W = h->qld_W;
     a.W_pm = h->W_pm; a.W_pp = h->W_pp; a.Mu_pm = h->Mu_pm; a.Mu_pp = h->Mu_pp;
-    a.scal = h->scal; a.Gz = h->Gz; a.g0 = h->g0; a.sx_local = h->sx_local; a.part = h->part; a.stats = h->stats; a.aux = h->aux; a.elbo = h->elbo; a.status = h->status;
+    a.scal = h->scal; a.Gz = h->Gz; a.g0 = h->g0; a.sx_local = h->sx_local; a.part = h->part; a.stats = h->stats; a.aux = h->aux; a.aux_tail = h->aux + (size_t)4 * h->nchunk * h->QP; a.elbo = h->elbo; a.status = h->status;
     a.N = h->N; a.N_total = h->N_total; a.chunk_rows = h->chunk_rows; a.lo_upd = 0; a.hi_upd = 0;
     a.n_part_missing = h->n_part_missing; a.n_none_rows = h->n_none_rows; a.row_offset = h->row_offset;
     a.d = h->d; a.q = h->q; a.DP = h->DP; a.QP = h->QP; a.DT = h->DT; a.QT = h->QT; a.nchunk = h->nchunk; a.mode = 0; a.SL = h->SL;
     a.res_cached = h->res_valid ? 1 : 0;
-    a.keep_z0 = 0; a.z_deferred = 0;
+    a.keep_z0 = 0; a.z_deferred = 0; a.x0_prep = 0;
     return a;
 }
 
 int pca_launch_small(pyvb_pca* h, int mode) {
     PcaArgs a = pca_args(h); a.mode = mode;
-    a.z_deferred = ((mode == PCA_PREPZ || mode == PCA_X0) && h->z_pending) ? 1 : 0;
-    if (mode == PCA_X0 || mode == PCA_APPLY || mode == PCA_PREPZ) a.aux = h->aux + (size_t)4 * h->nchunk * h->QP;    // the [sz | delta sx] vector
-    hipLaunchKernelGGL(k_pca_small, dim3(1), dim3(256), 0, h->stream, a);
+    a.z_deferred = h->z_pending ? 1 : 0;
+    if (mode == PCA_RUN_MID) a.x0_prep = 1;             // no communicator: this rank owns row 0
+    if (mode == PCA_RUN_TAIL) a.res_cached = 1;         // the bound follows the Beta update of the same launch
+    switch (mode) {
+#define PCA_SMALL(M, ...) case M: hipLaunchKernelGGL((k_pca_small<__VA_ARGS__>), dim3(1), dim3(256), 0, h->stream, a); break
+        PCA_SMALL(PCA_W, PCA_W); PCA_SMALL(PCA_PREPZ, PCA_PREPZ); PCA_SMALL(PCA_MU, PCA_MU); PCA_SMALL(PCA_BETA, PCA_BETA);
+        PCA_SMALL(PCA_ELBO, PCA_ELBO); PCA_SMALL(PCA_X0, PCA_X0); PCA_SMALL(PCA_APPLY, PCA_APPLY);
+        // runs of pyvb_pca_iterate without a communicator (with one, an all-reduce sits between the steps)
+        PCA_SMALL(PCA_RUN_HEAD, PCA_W, PCA_PREPZ, PCA_APPLY);
+        PCA_SMALL(PCA_RUN_MID, PCA_X0, PCA_APPLY, PCA_MU);
+        PCA_SMALL(PCA_RUN_TAIL, PCA_BETA, PCA_ELBO);
+#undef PCA_SMALL
+        default: pyvb_set_error("no such small kernel"); return PYVB_E_ARG;
+    }
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
@@ -887,7 +936,8 @@ int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
     PcaArgs a = pca_args(h); a.lo_upd = lo_upd; a.hi_upd = hi_upd;
     a.keep_z0 = h->z0_done ? 1 : 0;
     const unsigned nw = (h->DT + P2T - 1) / P2T;          // wavefronts per workgroup: 32 columns each
-    const size_t lds = ((size_t)nw * h->QT * 256 + (size_t)h->QT * 256 + (size_t)h->QT * 16 * 17 + (size_t)nw * 16 * P12_XS) * sizeof(double);
+    const size_t rt = h->QT == 1 ? 2 : 1;                 // k_pca_pass12: RT
+    const size_t lds = rt * ((size_t)nw * h->QT * 256 + (size_t)h->QT * 256 + (size_t)h->QT * 16 * 17 + (size_t)nw * 16 * P12_XS) * sizeof(double);
     const dim3 grid(h->nchunk), block(64 * nw);
     const bool pin = h->Xdata != nullptr;
     if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass12<1, true>), grid, block, lds, h->stream, a); else hipLaunchKernelGGL((k_pca_pass12<1, false>), grid, block, lds, h->stream, a); }

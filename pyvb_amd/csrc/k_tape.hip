@@ -7,6 +7,7 @@
 // The matrices of this path are tiny (dimensions of single nodes); the interpreter favours generality over speed.
 #include "common.h"
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 enum {
@@ -42,6 +43,10 @@ enum {
 #define TAPE_CHUNK 512          // records staged at a time
 #define TAPE_LDS_CAP 12288      // doubles of arena a block may keep in LDS (96 KB)
 #define TAPE_MAX_SEGS 4096
+#ifndef TAPE_BUNDLE
+#define TAPE_BUNDLE 8            // records per bundle = wavefronts of a k_tape_cached workgroup
+#endif
+#define TAPE_CTHREADS (64 * TAPE_BUNDLE)
 
 struct TapeArgs { double* arena; size_t arena_n; const int* ops; int nops; int* status; };
 
@@ -68,64 +73,103 @@ typedef __attribute__((address_space(3))) double lds_double;
 template <bool WIN> struct TapePtr { typedef double* type; };
 template <> struct TapePtr<true> { typedef lds_double* type; };
 
-template <bool WIN>
-__device__ static void tape_exec(const TapeArgs& t, const int* recs, int count, double* red, typename TapePtr<WIN>::type win) {
+// NT: threads of the workgroup.  NT == 64 (one wavefront; the host picks it for launches whose records all have at most 64
+// elements, WIN only) needs no s_barrier between records: the LDS operations of a wavefront execute in order, a fence keeps the
+// compiler from moving them.  What a record of a node-sized graph costs is its chain of dependent steps -- fetch the record,
+// form the addresses, fetch the operands, store -- so: the record is fetched as two 16-byte words one record ahead, and the
+// row / column of an element comes from a float reciprocal with a fix-up instead of two integer divisions (about 80 instructions).
+typedef int __attribute__((ext_vector_type(4))) tape_i4;
+__device__ __forceinline__ void tape_divmod(int idx, int n, float rn, int& i, int& j) {
+    i = (int)(((float)idx + 0.5f) * rn);
+    j = idx - i * n;
+    if (j < 0) { --i; j += n; } else if (j >= n) { ++i; j -= n; }
+}
+
+template <bool WIN, int NT>
+__device__ static void tape_exec(const TapeArgs& t, const int* recs, int count, double* red, typename TapePtr<WIN>::type win, const int tid) {
     typedef typename TapePtr<WIN>::type P;
     double* A = t.arena;
-    const int tid = threadIdx.x;
     auto at = [&](int off) -> P { if constexpr (WIN) return win + (off & ~T_LDS); else return A + off; };
+    auto sync = [&]() {
+        if constexpr (NT == 64 && WIN) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else __syncthreads();
+    };
+    const tape_i4* r4 = reinterpret_cast<const tape_i4*>(recs);
+    tape_i4 nlo = r4[0], nhi = r4[1];
     for (int pc = 0; pc < count; ++pc) {
-        const int* o = recs + 8 * pc;
+        const tape_i4 lo = nlo, hi = nhi;
+        if (pc + 1 < count) { nlo = r4[2 * pc + 2]; nhi = r4[2 * pc + 3]; }
+        const int o[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const int op = o[0], m = o[4], n = o[5], flags = o[7];
+        const float rn = __builtin_amdgcn_rcpf((float)(n > 0 ? n : 1));
         P dst = at(o[1]);
         const P a = at(o[2]);
         const P b = o[3] < 0 ? at(0) : at(o[3]);
         switch (op) {
         case T_COPY2D:
-            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[(idx / n) * o[3] + idx % n] = a[(idx / n) * o[6] + idx % n];
+            for (int idx = tid; idx < m * n; idx += NT) { int i, j; tape_divmod(idx, n, rn, i, j); dst[i * o[3] + j] = a[i * o[6] + j]; }
             break;
         case T_FILL:
-            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[(idx / n) * o[3] + idx % n] = ((flags & 1) && idx / n == idx % n) ? 1.0 : 0.0;
+            for (int idx = tid; idx < m * n; idx += NT) { int i, j; tape_divmod(idx, n, rn, i, j); dst[i * o[3] + j] = ((flags & 1) && i == j) ? 1.0 : 0.0; }
             break;
         case T_AXPBY: {
             const double al = *at(o[6]);
-            if (o[3] < 0) { for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[idx] = al * a[idx]; }
-            else { const double be = *at(flags); for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[idx] = al * a[idx] + be * b[idx]; }
+            if (o[3] < 0) { for (int idx = tid; idx < m * n; idx += NT) dst[idx] = al * a[idx]; }
+            else { const double be = *at(flags); for (int idx = tid; idx < m * n; idx += NT) dst[idx] = al * a[idx] + be * b[idx]; }
             break; }
         case T_GEMM: {
             const int k = o[6];
-            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) {
-                const int i = idx / n, j = idx % n;
+            for (int idx = tid; idx < m * n; idx += NT) {
+                int i, j; tape_divmod(idx, n, rn, i, j);
+                // strides instead of a choice per term, and eight terms fetched at a time (added in order): the sum over the children
+                // of a node with thousands of them is one such product with a row of ones, a load latency per term otherwise
+                const int as = (flags & 1) ? m : 1, bs = (flags & 2) ? 1 : n;
+                const P ap = a + ((flags & 1) ? i : i * k), bp = b + ((flags & 2) ? j * k : j);
                 double s = 0.0;
-                for (int l = 0; l < k; ++l) s += ((flags & 1) ? a[l * m + i] : a[i * k + l]) * ((flags & 2) ? b[j * k + l] : b[l * n + j]);
+                int l = 0;
+                for (; l + 8 <= k; l += 8) {
+                    double av[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { av[u] = ap[(l + u) * as]; bv[u] = bp[(l + u) * bs]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += av[u] * bv[u];
+                }
+                for (; l < k; ++l) s += ap[l * as] * bp[l * bs];
                 if (flags & 8) s = -s;
                 dst[idx] = (flags & 4) ? dst[idx] + s : s;
             }
             break; }
         case T_SCALE: {
             const double s = *b;
-            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[idx] = (flags & 1) ? a[idx] / s : a[idx] * s;
+            for (int idx = tid; idx < m * n; idx += NT) dst[idx] = (flags & 1) ? a[idx] / s : a[idx] * s;
             break; }
         case T_TRACE: case T_DOT: {
             double s = 0.0;
-            if (op == T_TRACE) { for (int i = tid; i < m; i += TAPE_THREADS) s += a[i * m + i]; }
-            else { for (int idx = tid; idx < m * n; idx += TAPE_THREADS) s += a[idx] * b[idx]; }
-            // fixed tree: shuffles inside a wavefront, then the four wavefronts in order (one thread adding up 256 values was
+            if (op == T_TRACE) { for (int i = tid; i < m; i += NT) s += a[i * m + i]; }
+            else { for (int idx = tid; idx < m * n; idx += NT) s += a[idx] * b[idx]; }
+            // fixed tree: shuffles inside a wavefront, then the wavefronts in order (one thread adding up 256 values was
             // 7 us per record)
 #pragma unroll
             for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);
-            if ((tid & 63) == 0) red[tid >> 6] = s;
-            __syncthreads();
-            if (tid == 0) {
-                double tot = 0.0;
+            if constexpr (NT == 64) {
+                if (tid == 0) dst[0] = (flags & 4) ? dst[0] + s : s;
+            } else {
+                if ((tid & 63) == 0) red[tid >> 6] = s;
+                __syncthreads();
+                if (tid == 0) {
+                    double tot = 0.0;
 #pragma unroll
-                for (int w = 0; w < TAPE_THREADS / 64; ++w) tot += red[w];
-                dst[0] = (flags & 4) ? dst[0] + tot : tot;
+                    for (int w = 0; w < NT / 64; ++w) tot += red[w];
+                    dst[0] = (flags & 4) ? dst[0] + tot : tot;
+                }
             }
             break; }
         case T_DIAG:
-            if (flags & 1) { for (int idx = tid; idx < m * m; idx += TAPE_THREADS) dst[idx] = (idx / m == idx % m) ? a[idx / m] : 0.0; }
-            else { for (int i = tid; i < m; i += TAPE_THREADS) dst[i] = a[i * m + i]; }
+            if (flags & 1) { const float rm = __builtin_amdgcn_rcpf((float)(m > 0 ? m : 1)); for (int idx = tid; idx < m * m; idx += NT) { int i, j; tape_divmod(idx, m, rm, i, j); dst[idx] = (i == j) ? a[i] : 0.0; } }
+            else { for (int i = tid; i < m; i += NT) dst[i] = a[i * m + i]; }
             break;
         case T_CHOLINV: {
             // L (lower, row major) in scratch, column by column; then X = L^{-1} by forward substitution, one thread per
@@ -133,8 +177,8 @@ __device__ static void tape_exec(const TapeArgs& t, const int* recs, int count, 
             P L = at(o[6]);
             P X = L + m * m;
             P out2 = at(o[3]);
-            for (int idx = tid; idx < m * m; idx += TAPE_THREADS) L[idx] = a[idx];
-            __syncthreads();
+            for (int idx = tid; idx < m * m; idx += NT) L[idx] = a[idx];
+            sync();
             bool bad = false;
             for (int j = 0; j < m; ++j) {
                 if (tid == 0) {
@@ -142,16 +186,17 @@ __device__ static void tape_exec(const TapeArgs& t, const int* recs, int count, 
                     if (!(piv > 0.0)) { atomicOr(t.status, 1); L[j * m + j] = nan(""); }
                     else L[j * m + j] = sqrt(piv);
                 }
-                __syncthreads();
+                sync();
                 const double d = L[j * m + j];
-                for (int i = j + 1 + tid; i < m; i += TAPE_THREADS) L[i * m + j] /= d;
-                __syncthreads();
+                for (int i = j + 1 + tid; i < m; i += NT) L[i * m + j] /= d;
+                sync();
                 const int rem = m - j - 1;                      // trailing update, lower triangle
-                for (int idx = tid; idx < rem * rem; idx += TAPE_THREADS) {
-                    const int i = j + 1 + idx / rem, c = j + 1 + idx % rem;
+                const float rr = __builtin_amdgcn_rcpf((float)(rem > 0 ? rem : 1));
+                for (int idx = tid; idx < rem * rem; idx += NT) {
+                    int i, c; tape_divmod(idx, rem, rr, i, c); i += j + 1; c += j + 1;
                     if (c <= i) L[i * m + c] -= L[i * m + j] * L[c * m + j];
                 }
-                __syncthreads();
+                sync();
             }
             (void)bad;
             if (tid == 0) {
@@ -160,23 +205,24 @@ __device__ static void tape_exec(const TapeArgs& t, const int* recs, int count, 
                 out2[0] = 0.5 / s;          // gaussian.py:120: .5 / np.log(np.prod(np.diag(chol)))
                 out2[1] = s;
             }
-            for (int c = tid; c < m; c += TAPE_THREADS) {       // X[:, c] = L^{-1} e_c
+            for (int c = tid; c < m; c += NT) {       // X[:, c] = L^{-1} e_c
                 for (int i = 0; i < m; ++i) {
                     double s = (i == c) ? 1.0 : 0.0;
                     for (int l = c; l < i; ++l) s -= L[i * m + l] * X[l * m + c];
                     X[i * m + c] = (i < c) ? 0.0 : s / L[i * m + i];
                 }
             }
-            __syncthreads();
-            for (int idx = tid; idx < m * m; idx += TAPE_THREADS) {
-                const int i = idx / m, j = idx % m;
+            sync();
+            const float rm = __builtin_amdgcn_rcpf((float)(m > 0 ? m : 1));
+            for (int idx = tid; idx < m * m; idx += NT) {
+                int i, j; tape_divmod(idx, m, rm, i, j);
                 double s = 0.0;
                 for (int l = (i > j ? i : j); l < m; ++l) s += X[l * m + i] * X[l * m + j];
                 dst[idx] = s;
             }
             break; }
         case T_UNARY:
-            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) {
+            for (int idx = tid; idx < m * n; idx += NT) {
                 const double x = a[idx];
                 double y;
                 switch (flags) {
@@ -191,31 +237,31 @@ __device__ static void tape_exec(const TapeArgs& t, const int* recs, int count, 
             }
             break;
         case T_GATHER:          // the indices are data: checked here (status bit 1), everything else in pyvb_graph_tape_create
-            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) {
+            for (int idx = tid; idx < m * n; idx += NT) {
                 const long pos = (long)o[2] + (long)A[o[3] + idx / n] * o[6] + (long)A[flags + idx % n];
                 if (pos < 0 || (size_t)pos >= t.arena_n) { atomicOr(t.status, 2); continue; }
                 dst[idx] = A[pos];
             }
             break;
         case T_SCATTER:
-            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) {
+            for (int idx = tid; idx < m * n; idx += NT) {
                 const long pos = (long)o[1] + (long)A[o[3] + idx / n] * o[6] + (long)A[(flags & ~T_ACC) + idx % n];
                 if (pos < 0 || (size_t)pos >= t.arena_n) { atomicOr(t.status, 2); continue; }
                 A[pos] = (flags & T_ACC) ? A[pos] + a[idx] : a[idx];
             }
             break;
         case T_MUL:
-            for (int idx = tid; idx < m * n; idx += TAPE_THREADS) dst[idx] = a[idx] * b[idx];
+            for (int idx = tid; idx < m * n; idx += NT) dst[idx] = a[idx] * b[idx];
             break;
         default: break;
         }
-        __syncthreads();
+        sync();
     }
 }
 
 __global__ void __launch_bounds__(TAPE_THREADS) k_tape(TapeArgs t) {
     __shared__ double red[TAPE_THREADS];
-    tape_exec<false>(t, t.ops, t.nops, red, nullptr);
+    tape_exec<false, TAPE_THREADS>(t, t.ops, t.nops, red, nullptr, threadIdx.x);
 }
 
 // A PROGRAM over a tape: launches in order, each of them a set of record ranges ("blocks") that touch disjoint state and so
@@ -223,57 +269,77 @@ __global__ void __launch_bounds__(TAPE_THREADS) k_tape(TapeArgs t) {
 // PCA-like graph, its X_n).  blocks: [first record, count] per workgroup of this launch.
 __global__ void __launch_bounds__(TAPE_THREADS) k_tape_blocks(TapeArgs t, const int* blocks) {
     __shared__ double red[TAPE_THREADS];
-    tape_exec<false>(t, t.ops + 8 * (size_t)blocks[2 * blockIdx.x], blocks[2 * blockIdx.x + 1], red, nullptr);
+    tape_exec<false, TAPE_THREADS>(t, t.ops + 8 * (size_t)blocks[2 * blockIdx.x], blocks[2 * blockIdx.x + 1], red, nullptr, threadIdx.x);
 }
 
-// The same with the block's working set in LDS.  meta[block][8] = {first record, count, first segment, number of segments, window
-// doubles, ...}; segs[seg][4] = {arena offset, length, window offset, written}; t.ops holds the RESOLVED records (cached
-// offsets rewritten and tagged T_LDS).  Dynamic LDS: the window, then TAPE_CHUNK staged records.
-__global__ void __launch_bounds__(TAPE_THREADS) k_tape_cached(TapeArgs t, const int* meta, const int* segs) {
+// The same with the working set in LDS.  A block is cut into WINDOWS, consecutive runs of records whose extents fit the LDS budget
+// together (a chain of node updates does not fit as a whole: the LDS example at T = 200 touches 20 000 doubles): the workgroup
+// takes them in order -- load the window's segments, run its records out of LDS, write the written segments back -- so what one
+// window leaves for the next travels through the arena.  bmeta[block][2] = {first window, number of windows};
+// meta[window][8] = {first record, count, first segment, number of segments (0: the records address the arena), window doubles};
+// segs[seg][4] = {arena offset, length, window offset, written}; t.ops holds the RESOLVED records (cached offsets rewritten and
+// tagged T_LDS).  Dynamic LDS: the window, then TAPE_CHUNK staged records.
+// meta[window][5] = 1: a BUNDLED window.  Its records all have at most 64 elements and have been scheduled by the host into
+// bundles of four that do not touch each other's extents (slots without a record hold T_NOP): wavefront w of the workgroup
+// interprets record 4 b + w of bundle b on its own (tape_exec<true, 64>: no barrier inside), then the workgroup meets.  A
+// record of such a graph costs 300-700 ns whatever it does (profiles/tape_record_cost.py: a chain of LDS round trips and taken
+// branches, about 70 instructions); independent records -- the messages of different children, the next node's messages
+// while this node's covariance is inverted -- now overlap on the four SIMDs.
+__global__ void __launch_bounds__(TAPE_CTHREADS) k_tape_cached(TapeArgs t, const int* bmeta, const int* meta, const int* segs) {
     extern __shared__ double win[];
-    __shared__ double red[TAPE_THREADS];
-    const int* me = meta + 8 * blockIdx.x;
-    const int first = me[0], count = me[1], s0 = me[2], ns = me[3], wd = me[4];
+    constexpr int NT = TAPE_CTHREADS;
+    __shared__ double red[NT];
     const int tid = threadIdx.x;
-    // long segments by all threads together, short ones (most: a node's mean, a scalar) one per thread
-    for (int s = 0; s < ns; ++s) {
-        const int* sg = segs + 4 * (s0 + s);
-        if (sg[1] < 64) continue;
-        const double* src = t.arena + sg[0];
-        double* dst = win + sg[2];
-        for (int idx = tid; idx < sg[1]; idx += TAPE_THREADS) dst[idx] = src[idx];
-    }
-    for (int s = tid; s < ns; s += TAPE_THREADS) {
-        const int* sg = segs + 4 * (s0 + s);
-        if (sg[1] >= 64) continue;
-        const double* src = t.arena + sg[0];
-        double* dst = win + sg[2];
-        for (int idx = 0; idx < sg[1]; ++idx) dst[idx] = src[idx];
-    }
-    int* staged = reinterpret_cast<int*>(win + wd);
-    for (int c0 = 0; c0 < count; c0 += TAPE_CHUNK) {
-        const int nc = count - c0 < TAPE_CHUNK ? count - c0 : TAPE_CHUNK;
+    const int w0 = bmeta[2 * blockIdx.x], nwin = bmeta[2 * blockIdx.x + 1];
+    for (int w = w0; w < w0 + nwin; ++w) {
+        const int* me = meta + 8 * w;
+        const int first = me[0], count = me[1], s0 = me[2], ns = me[3], wd = me[4], bundled = me[5];
+        // long segments by all threads together, short ones (most: a node's mean, a scalar) one per thread
+        for (int s = 0; s < ns; ++s) {
+            const int* sg = segs + 4 * (s0 + s);
+            if (sg[1] < 64) continue;
+            const double* src = t.arena + sg[0];
+            double* dst = win + sg[2];
+            for (int idx = tid; idx < sg[1]; idx += NT) dst[idx] = src[idx];
+        }
+        for (int s = tid; s < ns; s += NT) {
+            const int* sg = segs + 4 * (s0 + s);
+            if (sg[1] >= 64) continue;
+            const double* src = t.arena + sg[0];
+            double* dst = win + sg[2];
+            for (int idx = 0; idx < sg[1]; ++idx) dst[idx] = src[idx];
+        }
+        int* staged = reinterpret_cast<int*>(win + ((wd + 1) & ~1));         // 16-byte aligned: records are fetched as vectors
+        for (int c0 = 0; c0 < count; c0 += TAPE_CHUNK) {
+            const int nc = count - c0 < TAPE_CHUNK ? count - c0 : TAPE_CHUNK;
+            __syncthreads();
+            const int* src = t.ops + 8 * (size_t)(first + c0);
+            for (int idx = tid; idx < 8 * nc; idx += NT) staged[idx] = src[idx];
+            __syncthreads();
+            if (bundled) {
+                for (int b0 = 0; b0 < nc; b0 += TAPE_BUNDLE) {          // TAPE_CHUNK is a multiple of TAPE_BUNDLE: a bundle never straddles two chunks
+                    tape_exec<true, 64>(t, staged + 8 * (b0 + (tid >> 6)), 1, red, (lds_double*)win, tid & 63);
+                    __syncthreads();
+                }
+            } else if (ns > 0) tape_exec<true, NT>(t, staged, nc, red, (lds_double*)win, tid);
+            else tape_exec<false, NT>(t, staged, nc, red, nullptr, tid);
+        }
         __syncthreads();
-        const int* src = t.ops + 8 * (size_t)(first + c0);
-        for (int idx = tid; idx < 8 * nc; idx += TAPE_THREADS) staged[idx] = src[idx];
-        __syncthreads();
-        if (ns > 0) tape_exec<true>(t, staged, nc, red, (lds_double*)win);
-        else tape_exec<false>(t, staged, nc, red, nullptr);
-    }
-    __syncthreads();
-    for (int s = 0; s < ns; ++s) {
-        const int* sg = segs + 4 * (s0 + s);
-        if (!sg[3] || sg[1] < 64) continue;
-        double* dst = t.arena + sg[0];
-        const double* src = win + sg[2];
-        for (int idx = tid; idx < sg[1]; idx += TAPE_THREADS) dst[idx] = src[idx];
-    }
-    for (int s = tid; s < ns; s += TAPE_THREADS) {
-        const int* sg = segs + 4 * (s0 + s);
-        if (!sg[3] || sg[1] >= 64) continue;
-        double* dst = t.arena + sg[0];
-        const double* src = win + sg[2];
-        for (int idx = 0; idx < sg[1]; ++idx) dst[idx] = src[idx];
+        for (int s = 0; s < ns; ++s) {
+            const int* sg = segs + 4 * (s0 + s);
+            if (!sg[3] || sg[1] < 64) continue;
+            double* dst = t.arena + sg[0];
+            const double* src = win + sg[2];
+            for (int idx = tid; idx < sg[1]; idx += NT) dst[idx] = src[idx];
+        }
+        for (int s = tid; s < ns; s += NT) {
+            const int* sg = segs + 4 * (s0 + s);
+            if (!sg[3] || sg[1] >= 64) continue;
+            double* dst = t.arena + sg[0];
+            const double* src = win + sg[2];
+            for (int idx = 0; idx < sg[1]; ++idx) dst[idx] = src[idx];
+        }
+        if (w + 1 < w0 + nwin) { __threadfence(); __syncthreads(); }        // the next window reads what this one has written back
     }
 }
 
@@ -289,6 +355,7 @@ struct pyvb_graph {
     std::vector<std::vector<int>> host_ops;
     std::vector<int*> c_ops, c_meta, c_segs;
     std::vector<std::vector<size_t>> c_lds;
+    std::vector<int> c_nblocks;                      // per tape: blocks in the window form (c_meta = block table [nb][2], then the window table)
 };
 
 #define ARGCHK(cond, msg) do { if (!(cond)) { pyvb_set_error("%s", msg); return PYVB_E_ARG; } } while (0)
@@ -421,73 +488,167 @@ static void tape_cache_free(pyvb_graph* g, int id) {
 
 // Build the window form of tape `id` for the given blocks ([first, count] each) and launches ([first block, number]).
 // Nothing is cached when the arena does not leave bit 30 of an offset free.
+struct TapeSeg { long off, end; bool write; int lds; };
+// the extents of records [first, first + count) merged into segments (overlapping or adjacent only: a gap may be another
+// block's state); false if a record's addresses are data (gather / scatter)
+static bool tape_segments(const std::vector<int>& ops, int first, int count, std::vector<TapeSeg>& sg, long& total) {
+    std::vector<TapeExtent> ext;
+    for (int r = first; r < first + count; ++r)
+        if (!tape_extents(&ops[8 * (size_t)r], ext)) return false;
+    std::sort(ext.begin(), ext.end(), [](const TapeExtent& x, const TapeExtent& y) { return x.off < y.off; });
+    sg.clear(); total = 0;
+    for (const TapeExtent& e : ext) {
+        const long end = e.off + (long)e.len;
+        if (!sg.empty() && e.off <= sg.back().end) {
+            if (end > sg.back().end) sg.back().end = end;
+            sg.back().write = sg.back().write || e.write;
+        } else sg.push_back(TapeSeg{e.off, end, e.write, -1});
+    }
+    for (const TapeSeg& q : sg) total += ((q.end - q.off) + 1) & ~1L;
+    return true;
+}
+
+// Records [first, first + count) of `ops` (resolved: window offsets) scheduled into bundles of four mutually independent records,
+// appended to `out` (T_NOP in the free slots).  A record depends on every earlier one that touches one of its extents unless both
+// only read it; it goes into the first bundle after all of its dependencies that has a free slot (list scheduling: any order that
+// respects the dependencies computes what the tape computes).  Extents are taken from the unresolved records `raw`.
+#define TAPE_BUNDLE_MAX 2048        // records scheduled together (the dependency search is quadratic)
+static void tape_bundle(const std::vector<int>& raw, const std::vector<int>& ops, int first, int count, std::vector<int>& out) {
+    std::vector<std::vector<TapeExtent>> ext((size_t)count);
+    for (int r = 0; r < count; ++r) tape_extents(&raw[8 * (size_t)(first + r)], ext[r]);
+    std::vector<int> bundle((size_t)count, 0), fill;
+    for (int r = 0; r < count; ++r) {
+        int earliest = 0;
+        for (int q = r - 1; q >= 0; --q) {
+            if (bundle[q] < earliest) continue;             // cannot raise the bound
+            bool hazard = false;
+            for (const TapeExtent& x : ext[r]) {
+                for (const TapeExtent& y : ext[q])
+                    if ((x.write || y.write) && x.off < y.off + (long)y.len && y.off < x.off + (long)x.len) { hazard = true; break; }
+                if (hazard) break;
+            }
+            if (hazard) earliest = bundle[q] + 1;
+        }
+        int b = earliest;
+        while (b < (int)fill.size() && fill[b] >= TAPE_BUNDLE) ++b;
+        if (b >= (int)fill.size()) fill.resize((size_t)b + 1, 0);
+        bundle[r] = b; ++fill[b];
+    }
+    const size_t base = out.size();
+    out.resize(base + fill.size() * 8 * TAPE_BUNDLE, 0);                 // T_NOP == 0
+    std::vector<int> slot(fill.size(), 0);
+    for (int r = 0; r < count; ++r) {
+        int* dst = &out[base + ((size_t)bundle[r] * TAPE_BUNDLE + slot[bundle[r]]++) * 8];
+        for (int k = 0; k < 8; ++k) dst[k] = ops[8 * (size_t)(first + r) + k];
+    }
+}
+
 static int tape_cache_build(pyvb_graph* g, int id, const std::vector<int>& blocks, const std::vector<int>& launches) {
     tape_cache_free(g, id);
     if (g->arena_n >= (size_t)T_LDS) return PYVB_OK;
-    std::vector<int> ops = g->host_ops[id];
+    const std::vector<int>& raw = g->host_ops[id];
+    std::vector<int> ops = raw, cops;                       // ops: resolved in place; cops: what the device gets, window by window
     const int nb = (int)blocks.size() / 2;
-    std::vector<int> meta((size_t)nb * 8, 0), segs;
+    std::vector<int> bmeta((size_t)nb * 2, 0), meta, segs;
+    std::vector<size_t> block_lds((size_t)nb, 0);
+    std::vector<TapeSeg> sg, best;
     std::vector<TapeExtent> ext;
-    struct Seg { long off, end; int touches; bool write; int lds; };
+    bool any = false;
     for (int b = 0; b < nb; ++b) {
         const int first = blocks[2 * b], count = blocks[2 * b + 1];
-        meta[8 * b] = first; meta[8 * b + 1] = count; meta[8 * b + 2] = (int)segs.size() / 4;
-        ext.clear();
-        bool ok = count >= 3;                               // a window costs a load and a write-back: not for a record or two
-        for (int r = first; ok && r < first + count; ++r) ok = tape_extents(&ops[8 * (size_t)r], ext);
-        if (!ok) continue;
-        // merge the extents into segments
-        std::vector<Seg> sg;
-        {
-            std::vector<TapeExtent> e2 = ext;
-            std::sort(e2.begin(), e2.end(), [](const TapeExtent& x, const TapeExtent& y) { return x.off < y.off; });
-            for (const TapeExtent& e : e2) {
-                const long end = e.off + (long)e.len;
-                if (!sg.empty() && e.off <= sg.back().end) {      // overlapping or adjacent only: a gap may be another block's state
-                    if (end > sg.back().end) sg.back().end = end;
-                    sg.back().touches += 1; sg.back().write = sg.back().write || e.write;
-                } else sg.push_back(Seg{e.off, end, 1, e.write, -1});
+        bmeta[2 * b] = (int)meta.size() / 8;
+        int r = first;
+        while (r < first + count) {
+            // the longest run of records from r whose segments fit: grown geometrically, then bisected
+            int len = 0; long used = 0;
+            {
+                int lo = 0, hi = 1;             // lo fits (0 = nothing tried), hi is the next candidate
+                long tot = 0;
+                const int left = first + count - r;
+                while (true) {
+                    const int c = hi < left ? hi : left;
+                    if (tape_segments(raw, r, c, sg, tot) && tot <= TAPE_LDS_CAP && (int)sg.size() <= TAPE_MAX_SEGS) {
+                        lo = c; best = sg; used = tot;
+                        if (c == left) break;
+                        hi = c * 2;
+                    } else { hi = c; break; }
+                }
+                while (hi - lo > 1 && lo < left) {          // lo fits, hi does not
+                    const int mid = (lo + hi) / 2;
+                    if (tape_segments(raw, r, mid, sg, tot) && tot <= TAPE_LDS_CAP && (int)sg.size() <= TAPE_MAX_SEGS) { lo = mid; best = sg; used = tot; }
+                    else hi = mid;
+                }
+                len = lo;
             }
-        }
-        // the most used ones first, while they fit
-        std::vector<int> order(sg.size());
-        for (size_t i = 0; i < sg.size(); ++i) order[i] = (int)i;
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return sg[x].touches != sg[y].touches ? sg[x].touches > sg[y].touches : sg[x].off < sg[y].off; });
-        long used = 0; int nsel = 0;
-        for (int i : order) {
-            const long len = sg[i].end - sg[i].off;
-            if (nsel >= TAPE_MAX_SEGS || used + len > TAPE_LDS_CAP) { nsel = -1; break; }
-            sg[i].lds = (int)used; used += (len + 1) & ~1L; ++nsel;
-        }
-        if (nsel <= 0) continue;            // all of the block's working set, or nothing: the interpreter then knows its pointers
-        for (const Seg& q : sg)
-            if (q.lds >= 0) { segs.push_back((int)q.off); segs.push_back((int)(q.end - q.off)); segs.push_back(q.lds); segs.push_back(q.write ? 1 : 0); }
-        meta[8 * b + 3] = nsel; meta[8 * b + 4] = (int)used;
-        // rewrite the offsets that fall into a cached segment
-        for (int r = first; r < first + count; ++r) {
-            ext.clear();
-            tape_extents(&ops[8 * (size_t)r], ext);
-            for (const TapeExtent& e : ext) {
-                size_t lo = 0, hi = sg.size();              // the segment that holds e.off: last one starting at or before it
-                while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (sg[mid].off <= e.off) lo = mid; else hi = mid; }
-                if (sg[lo].lds >= 0) ops[8 * (size_t)r + e.field] = T_LDS | (sg[lo].lds + (int)(e.off - sg[lo].off));
+            if (len < 3) {
+                // a record whose addresses are data (gather / scatter), one that does not fit by itself, or a run too short to pay
+                // for a load and a write-back: on the arena.  Runs of such records are kept together.
+                const int c = len > 0 ? len : 1;
+                const size_t last = meta.size() - 8;
+                const int at = (int)(cops.size() / 8);
+                cops.insert(cops.end(), raw.begin() + 8 * (size_t)r, raw.begin() + 8 * (size_t)(r + c));
+                if ((int)meta.size() / 8 > bmeta[2 * b] && meta[last + 3] == 0 && meta[last] + meta[last + 1] == at) meta[last + 1] += c;
+                else {
+                    const size_t mw = meta.size();
+                    meta.resize(mw + 8, 0);
+                    meta[mw] = at; meta[mw + 1] = c; meta[mw + 2] = (int)segs.size() / 4;
+                }
+                r += c;
+                continue;
             }
+            const size_t mw = meta.size();
+            meta.resize(mw + 8, 0);
+            long pos = 0;
+            for (TapeSeg& q : best) { q.lds = (int)pos; pos += ((q.end - q.off) + 1) & ~1L; }
+            // rewrite the offsets: every extent of these records lies in one of the window's segments
+            long widest = 0;
+            for (int rr = r; rr < r + len; ++rr) {
+                ext.clear();
+                tape_extents(&raw[8 * (size_t)rr], ext);
+                for (const TapeExtent& e : ext) {
+                    size_t lo = 0, hi = best.size();        // the segment that holds e.off: last one starting at or before it
+                    while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (best[mid].off <= e.off) lo = mid; else hi = mid; }
+                    ops[8 * (size_t)rr + e.field] = T_LDS | (best[lo].lds + (int)(e.off - best[lo].off));
+                }
+                const int* o = &raw[8 * (size_t)rr];
+                const long mm = (long)o[4] * o[4], mn = (long)o[4] * o[5];
+                widest = std::max(widest, (o[0] == T_CHOLINV || o[0] == T_DIAG || o[0] == T_TRACE) ? mm : mn);
+            }
+            const int at = (int)(cops.size() / 8);
+            const bool bundled = widest <= 64;
+            if (bundled) {                  // a long window is scheduled piece by piece (the search is quadratic in the piece)
+                for (int p0 = 0; p0 < len; p0 += TAPE_BUNDLE_MAX) tape_bundle(raw, ops, r + p0, std::min(TAPE_BUNDLE_MAX, len - p0), cops);
+            }
+            else cops.insert(cops.end(), ops.begin() + 8 * (size_t)r, ops.begin() + 8 * (size_t)(r + len));
+            meta[mw] = at; meta[mw + 1] = (int)(cops.size() / 8) - at; meta[mw + 2] = (int)segs.size() / 4; meta[mw + 3] = (int)best.size();
+            meta[mw + 4] = (int)used; meta[mw + 5] = bundled ? 1 : 0;
+            for (const TapeSeg& q : best) { segs.push_back((int)q.off); segs.push_back((int)(q.end - q.off)); segs.push_back(q.lds); segs.push_back(q.write ? 1 : 0); }
+            block_lds[b] = std::max(block_lds[b], (size_t)used);
+            any = true;
+            r += len;
         }
+        bmeta[2 * b + 1] = (int)meta.size() / 8 - bmeta[2 * b];
     }
-    bool any = false;
-    for (int b = 0; b < nb; ++b) any = any || meta[8 * b + 3] > 0;
+    if (getenv("PYVB_TAPE_STATS")) {
+        int nwin = (int)meta.size() / 8, nb_ = 0, nlds = 0; long recs = 0, slots = 0, wdoubles = 0;
+        for (int w = 0; w < nwin; ++w) { if (meta[8 * w + 5]) { ++nb_; slots += meta[8 * w + 1]; } if (meta[8 * w + 3]) { ++nlds; wdoubles += meta[8 * w + 4]; } recs += meta[8 * w + 1]; }
+        fprintf(stderr, "tape %d: %zu records in %d blocks -> %d windows (%d in LDS, %ld doubles; %d bundled: %ld slots = %ld bundles), %ld device records\n",
+                id, raw.size() / 8, nb, nwin, nlds, wdoubles, nb_, slots, slots / TAPE_BUNDLE, recs);
+    }
     if (!any) return PYVB_OK;
     if (segs.empty()) segs.assign(4, 0);
-    HIPCHK(hipMalloc((void**)&g->c_ops[id], ops.size() * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&g->c_meta[id], meta.size() * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&g->c_ops[id], cops.size() * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&g->c_meta[id], (bmeta.size() + meta.size()) * sizeof(int)));
     HIPCHK(hipMalloc((void**)&g->c_segs[id], segs.size() * sizeof(int)));
-    HIPCHK(hipMemcpy(g->c_ops[id], ops.data(), ops.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g->c_meta[id], meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->c_ops[id], cops.data(), cops.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->c_meta[id], bmeta.data(), bmeta.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->c_meta[id] + bmeta.size(), meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(g->c_segs[id], segs.data(), segs.size() * sizeof(int), hipMemcpyHostToDevice));
+    g->c_nblocks[id] = nb;
     for (size_t l = 0; l + 1 < launches.size(); l += 2) {
         size_t need = 0;
-        for (int b = launches[l]; b < launches[l] + launches[l + 1]; ++b) need = std::max(need, (size_t)meta[8 * b + 4]);
-        g->c_lds[id].push_back((need + (size_t)TAPE_CHUNK * 4) * sizeof(double));
+        for (int b = launches[l]; b < launches[l] + launches[l + 1]; ++b) need = std::max(need, block_lds[b]);
+        g->c_lds[id].push_back((need + 2 + (size_t)TAPE_CHUNK * 4) * sizeof(double));
     }
     return PYVB_OK;
 }
@@ -510,7 +671,7 @@ int pyvb_graph_tape_create(pyvb_graph* g, const int* ops, int nops, int* tape_id
     g->tapes.push_back(d); g->tape_len.push_back(nops);
     g->prog_blocks.push_back(nullptr); g->prog_launches.emplace_back();
     g->host_ops.emplace_back(ops, ops + (size_t)nops * 8);
-    g->c_ops.push_back(nullptr); g->c_meta.push_back(nullptr); g->c_segs.push_back(nullptr); g->c_lds.emplace_back();
+    g->c_ops.push_back(nullptr); g->c_meta.push_back(nullptr); g->c_segs.push_back(nullptr); g->c_lds.emplace_back(); g->c_nblocks.push_back(0);
     *tape_id = (int)g->tapes.size() - 1;
     return tape_cache_build(g, *tape_id, std::vector<int>{0, nops}, std::vector<int>{0, 1});     // one block, one launch
 }
@@ -553,16 +714,16 @@ int pyvb_graph_tape_run(pyvb_graph* g, int tape_id) {
         // the window form: one workgroup per block, its working set in LDS
         static bool attr_set = false;
         if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_tape_cached, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((TAPE_LDS_CAP + TAPE_CHUNK * 4) * sizeof(double))));
+            const int cap = (int)((TAPE_LDS_CAP + 2 + TAPE_CHUNK * 4) * sizeof(double));
+            HIPCHK(hipFuncSetAttribute((const void*)k_tape_cached, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
             attr_set = true;
         }
         t.ops = g->c_ops[tape_id];
         static const std::vector<int> single{0, 1};
         const std::vector<int>& L = g->prog_blocks[tape_id] ? g->prog_launches[tape_id] : single;
         for (size_t l = 0; l + 1 < L.size(); l += 2)
-            hipLaunchKernelGGL(k_tape_cached, dim3(L[l + 1]), dim3(TAPE_THREADS), g->c_lds[tape_id][l / 2], g->stream, t,
-                               g->c_meta[tape_id] + 8 * L[l], g->c_segs[tape_id]);
+            hipLaunchKernelGGL(k_tape_cached, dim3(L[l + 1]), dim3(TAPE_CTHREADS), g->c_lds[tape_id][l / 2], g->stream, t,
+                               g->c_meta[tape_id] + 2 * L[l], g->c_meta[tape_id] + 2 * g->c_nblocks[tape_id], g->c_segs[tape_id]);
     } else if (g->prog_blocks[tape_id]) {
         const std::vector<int>& L = g->prog_launches[tape_id];
         for (size_t l = 0; l + 1 < L.size(); l += 2)

@@ -25,7 +25,8 @@ static inline PcaStatsLayout pca_stats_layout(int DP, int QP) {
 #define PCA_RED 128     // slices of the chunk partials summed in parallel (stage 0 of k_pca_reduce)
 
 // device scalars
-enum { PS_BETA_A = 0, PS_BETA_B, PS_QLD_Z, PS_QLD_X /* unused: latent rows keep their own, statistics slot sql */, PS_QLD_MU, PS_BETA_A0, PS_BETA_B0, PS_RES, PS_COUNT = 16 };   // PS_RES: the residual of the last Beta update (see res_valid)
+enum { PS_BETA_A = 0, PS_BETA_B, PS_QLD_Z, PS_QLD_X /* unused: latent rows keep their own, statistics slot sql */, PS_QLD_MU, PS_BETA_A0, PS_BETA_B0, PS_RES,
+       PS_LGAMMA_A0, PS_LGAMMA_A, PS_DIGAMMA_A /* of the two shape parameters, which never change after set_priors: formed on the host */, PS_COUNT = 16 };   // PS_RES: the residual of the last Beta update (see res_valid)
 
 struct pyvb_pca {
     int device; long N, N_total, row_offset; int d, q, DP, QP, DT, QT;
@@ -64,4 +65,5 @@ int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd);
 int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd);
 int pca_launch_reduce(pyvb_pca* h, int what);
 int pca_launch_rowqld(pyvb_pca* h, double* out);      // out: device [N]
-enum { PCA_W = 0, PCA_PREPZ = 1, PCA_MU = 2, PCA_BETA = 3, PCA_ELBO = 4, PCA_X0 = 5, PCA_APPLY = 6 };
+enum { PCA_W = 0, PCA_PREPZ = 1, PCA_MU = 2, PCA_BETA = 3, PCA_ELBO = 4, PCA_X0 = 5, PCA_APPLY = 6,
+       PCA_RUN_HEAD = 16, PCA_RUN_MID = 17, PCA_RUN_TAIL = 18 };     // runs of steps in one launch (k_pca.hip: pca_launch_small)
