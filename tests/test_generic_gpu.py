@@ -502,3 +502,66 @@ def test_long_tapes_are_staged_in_chunks_and_windows_that_do_not_fit_fall_back()
     got, ref = _run_both(t, plan, [(s.off, S), (rows.off, np.array([4.0, 1.0])), (cols.off, np.array([0.0, 2.0, 3.0]))], plan.temp_high + 64)
     _close(got[out.off:out.off + 6], ref[out.off:out.off + 6], "gather inside a tape", 1e-12)
     _close(ref[out.off:out.off + 6].reshape(2, 3), 4.0 * (S @ S.T)[[4, 1]][:, [0, 2, 3]], "against numpy", 1e-12)
+
+
+def test_records_scheduled_into_bundles_compute_what_the_tape_order_computes():
+    """k_tape.hip schedules the records of a window whose operands are node-sized into bundles of mutually independent records,
+    a wavefront each (tape_bundle): any order that respects the read / write dependencies must give the tape's result.  Random
+    tapes of small records on a crowded arena -- plenty of RAW, WAR and WAW hazards, accumulating records, reductions, a
+    Cholesky inverse now and then, a few gathers that interrupt the windows -- against the numpy interpreter, which runs the
+    records in tape order.  The last case is a chain whose working set is larger than one window: it is cut into several."""
+    from pyvb_amd import generic as G
+    from oracle import tape_ref as R
+    rng = np.random.default_rng(11)
+    for case in range(12):
+        size = 4096 if case < 11 else 40000
+        nslot = 24 if case < 11 else 4000
+        base = 64
+        shapes = [(2, 2), (3, 3), (2, 1), (3, 1), (1, 1), (4, 4)]
+        slots = []                              # (offset, m, n): matrices laid out back to back, so neighbours never overlap
+        off = base
+        for k in range(nslot):
+            m, n = shapes[int(rng.integers(len(shapes)))]
+            slots.append((off, m, n)); off += m * n
+        assert off + 64 < size
+        by_shape = {}
+        for sl in slots:
+            by_shape.setdefault((sl[1], sl[2]), []).append(sl)
+        scal = [o for o, m, n in slots if (m, n) == (1, 1)] or [base]
+        ops = []
+        nrec = 700 if case < 11 else 6000
+        idx_rows, idx_cols = size - 40, size - 30
+        for r in range(nrec):
+            kind = int(rng.integers(9))
+            (m, n) = shapes[int(rng.integers(len(shapes)))]
+            cand = by_shape.get((m, n), [])
+            if len(cand) < 3:
+                continue
+            pick = lambda: cand[int(rng.integers(len(cand)))][0] if case < 11 else cand[min(len(cand) - 1, (r * len(cand)) // nrec + int(rng.integers(3)))][0]
+            d_, a_, b_ = pick(), pick(), pick()
+            if kind == 0 and d_ != a_: ops.append([G.T_COPY2D, d_, a_, n, m, n, n, 0])
+            elif kind == 1 and len({d_, a_, b_}) == 3: ops.append([G.T_AXPBY, d_, a_, b_, m, n, int(rng.choice(scal)), int(rng.choice(scal))])
+            elif kind == 2 and m == n and len({d_, a_, b_}) == 3: ops.append([G.T_GEMM, d_, a_, b_, m, n, m, int(rng.integers(8)) & 7])
+            elif kind == 3 and len({d_, a_, b_}) == 3: ops.append([G.T_MUL, d_, a_, b_, m, n, 0, 0])
+            elif kind == 4 and d_ != a_: ops.append([G.T_UNARY, d_, a_, 0, m, n, 0, 4])
+            elif kind == 5 and m == n: ops.append([G.T_TRACE, int(rng.choice(scal)), a_, 0, m, m, 0, int(rng.integers(2)) * 4])
+            elif kind == 6 and len({a_, b_}) == 2: ops.append([G.T_DOT, int(rng.choice(scal)), a_, b_, m, n, 0, 0])
+            elif kind == 7 and d_ != a_: ops.append([G.T_FILL, d_, 0, n, m, n, 0, int(rng.integers(2))])
+            elif kind == 8 and case % 3 == 2 and r % 50 == 49 and m == n and m >= 2:
+                ops.append([G.T_GATHER, d_, a_, idx_rows, m, n, n, idx_cols])
+        ops = np.asarray(ops, dtype=np.int32)
+        arena = np.zeros(size)
+        arena[base:off] = rng.uniform(-0.9, 0.9, off - base)        # |values| < 1: products and sums of a few hundred records stay finite
+        arena[idx_rows:idx_rows + 4] = [1, 0, 2, 1]; arena[idx_cols:idx_cols + 4] = [0, 1, 1, 0]
+        # keep magnitudes in check: the tape is random, a chain of products may blow up -- rescale through a dry run
+        ref = arena.copy()
+        R.run(ref, ops)
+        if not np.all(np.isfinite(ref)) or np.abs(ref).max() > 1e100:
+            continue
+        ex = G.DeviceExecutor(size)
+        ex.write(0, arena)
+        ex.run(ex.tape(ops))
+        got = ex.read(0, size)
+        ex.close()
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(got - ref).max() <= 1e-11 * scale, "case %d: %g" % (case, np.abs(got - ref).max() / scale)

@@ -83,6 +83,37 @@ def test_stagewise_vs_oracle(N, d, q):
     b.close()
 
 
+@pytest.mark.parametrize("order", ["Z r", "Z X0 r", "Z Z r", "Z X0 Mu Xpart r X r", "Z W r X r", "Z X0 Z X r", "Z Beta r", "Z X0 Mu X Beta W Z elbo X0 r X r"])
+def test_a_deferred_z_update_is_carried_out_by_whatever_comes_next(order):
+    """pyvb_pca_update_Z only prepares the update (posterior covariance, gains, the sum of z from the sum of x); the rows of Z are
+    written by the next sweep over X, or by the first call that reads or replaces them.  Every continuation must give what the
+    reference's order of node updates gives: checked against the oracle after each read ("r")."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    from pyvb_amd.pca import PCABatch
+    N, d, q = 150, 40, 5
+    init, pri = G.pca_problem(N, d, q, seed=99)
+    st = P.make_state(init, pri, N, d, q)
+    b = PCABatch.from_problem(init, pri)
+    P.update_W(st, pri); b.update_W()
+    for op in order.split():
+        if op == "Z": P.update_Z(st, pri); b.update_Z()
+        elif op == "X0": P.update_X(st, pri, 0, 1); b.update_X(0, 1)
+        elif op == "Mu": P.update_Mu(st, pri); b.update_Mu()
+        elif op == "Xpart": P.update_X(st, pri, 20, 97); b.update_X(20, 97)
+        elif op == "X": P.update_X(st, pri, 1, N); b.update_X(1, N)
+        elif op == "W": P.update_W(st, pri); b.update_W()
+        elif op == "Beta": P.update_Beta(st, pri); b.update_Beta()
+        elif op == "elbo":
+            ref, got = P.elbo_parts(st, pri), b.elbo()
+            assert np.all(np.abs(got - ref) <= RTOL * np.abs(ref).sum()), (got, ref)
+        else:
+            _compare(b, st, order + ": ")
+    _compare(b, st, order + " (end): ")
+    b.close()
+
+
 def test_iterate_equals_individual_calls():
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
