@@ -215,7 +215,12 @@ int pyvb_pca_get_state(pyvb_pca* h, double* X, double* X_rowvar, double* W_mean,
  * update()).  qld_W [q]; qld_Z, qld_Mu one double each (all Z_n share one); qld_X [N]: rows without any observed entry,
  * NaN for the others.  Any pointer may be NULL. */
 int pyvb_pca_get_qld(pyvb_pca* h, double* qld_W, double* qld_Z, double* qld_Mu, double* qld_X);
-/* [w.update() for w in Ws]; [z.update() for z in Zs]; Xs[lo:hi] updates; Mu.update(); Beta.update() */
+/* [w.update() for w in Ws]; [z.update() for z in Zs]; Xs[lo:hi] updates; Mu.update(); Beta.update()
+ * (gaussian.py:102-134, nodes_todo.py:130-138).  Results are what the reference's order of node updates gives, call by call; the work
+ * behind pyvb_pca_update_Z is scheduled lazily: the call forms the shared posterior covariance of the Z_n, the gains and the sum of
+ * the new means (which is linear in the sum of x), and the rows of Z are written by the next pass over the rows -- normally the
+ * pyvb_pca_update_X that follows, which then reads X once for both updates -- or by the first call that reads or replaces Z, X or
+ * the parameters (pyvb_pca_get_state, the setters). */
 int pyvb_pca_update_W(pyvb_pca* h);
 int pyvb_pca_update_Z(pyvb_pca* h);
 int pyvb_pca_update_X(pyvb_pca* h, long lo, long hi);
