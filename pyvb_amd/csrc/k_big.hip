@@ -380,13 +380,19 @@ __global__ void __launch_bounds__(512) k_stats_big(BigStatsArgs a) {
     const int t0 = ch * a.chunk_len;
     const int t1 = (t0 + a.chunk_len < T) ? t0 + a.chunk_len : T;
     double* P = a.part + ((size_t)n * a.nchunk + ch) * a.L.stats_total;
+    // Column tiles in ROTATED order: operand j of this wavefront is tile (w + j) mod 8.  Operand 0 is then its own row tile -- the A
+    // operand of Sxx -- and the symmetric Sxx needs only j = 0..3, plus j = 4 on the wavefronts 0..3: every unordered pair of tiles
+    // {a, b} is formed exactly once, by the wavefront from which the other tile is at most 4 (3 for w >= 4) steps ahead, and written
+    // to both places.  20-21 MFMAs per k-step instead of 24.
     int xoff[BDT];
 #pragma unroll
-    for (int m = 0; m < BDT; ++m) xoff[m] = xpos(16 * m + r);
+    for (int j = 0; j < BDT; ++j) xoff[j] = xpos(16 * ((w + j) & 7) + r);
     const int ydim = 16 * w + r;
-    d4 sxx[BDT], sx1[BDT], syx[BDT];
+    d4 sxx[5], sx1[BDT], syx[BDT];
 #pragma unroll
-    for (int k = 0; k < BDT; ++k) { sxx[k] = d4{0.0, 0.0, 0.0, 0.0}; sx1[k] = sxx[k]; syx[k] = sxx[k]; }
+    for (int k = 0; k < BDT; ++k) { sx1[k] = d4{0.0, 0.0, 0.0, 0.0}; syx[k] = sx1[k]; }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sxx[k] = d4{0.0, 0.0, 0.0, 0.0};
     double bv[2][BDT], x1v[2], yv[2];
     auto fetch = [&](int tb, int h) {
         const int t = tb + q;
@@ -395,20 +401,18 @@ __global__ void __launch_bounds__(512) k_stats_big(BigStatsArgs a) {
         const double* yb = t < t1 ? Y + (size_t)t * K : Z;
 #pragma unroll
         for (int k = 0; k < BDT; ++k) bv[h][k] = xb[xoff[k]];
-        x1v[h] = x1[xoff[w]];
+        x1v[h] = x1[xoff[0]];
         yv[h] = ydim < K ? yb[ydim] : 0.0;
     };
     auto step = [&](int h) {
-        // row tile w of mu_t is column tile w of the B operands: picked by a compile-time chain (w is wave-uniform)
-        double xa = bv[h][0];
-#pragma unroll
-        for (int k = 1; k < BDT; ++k) xa = (w == k) ? bv[h][k] : xa;
+        const double xa = bv[h][0];
 #pragma unroll
         for (int k = 0; k < BDT; ++k) {
-            sxx[k] = MFMA(xa, bv[h][k], sxx[k]);
+            if (k < 4) sxx[k] = MFMA(xa, bv[h][k], sxx[k]);
             sx1[k] = MFMA(x1v[h], bv[h][k], sx1[k]);
             syx[k] = MFMA(yv[h], bv[h][k], syx[k]);
         }
+        if (w < 4) sxx[4] = MFMA(xa, bv[h][4], sxx[4]);
     };
     fetch(t0, 0);
     for (int tb = t0; tb < t1; tb += 8) {
@@ -418,14 +422,20 @@ __global__ void __launch_bounds__(512) k_stats_big(BigStatsArgs a) {
         step(1);
     }
 #pragma unroll
-    for (int k = 0; k < BDT; ++k)
+    for (int k = 0; k < BDT; ++k) {
+        const int ct = (w + k) & 7;             // the column tile operand k stands for
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const size_t pos = (size_t)(16 * w + 4 * e + q) * BDP + 16 * k + r;
-            P[a.L.oSxx + pos] = sxx[k][e];
+            const size_t pos = (size_t)(16 * w + 4 * e + q) * BDP + 16 * ct + r;
             P[a.L.oSx1x + pos] = sx1[k][e];
             P[a.L.oSyx + pos] = syx[k][e];
+            if (k < 4 || (k == 4 && w < 4)) {
+                const double v = sxx[k < 5 ? k : 0][e];
+                P[a.L.oSxx + pos] = v;
+                if (k > 0) P[a.L.oSxx + (size_t)(16 * ct + r) * BDP + 16 * w + 4 * e + q] = v;      // the mirrored tile
+            }
         }
+    }
 }
 
 int launch_stats_big(pyvb_lds* h) {
@@ -749,15 +759,26 @@ __device__ __forceinline__ double bsum128(double v, double* red) {
     return red[0] + red[1];
 }
 
-// k_cols.hip for up to 128 rows: thread = row, columns in order (Gauss-Seidel); fuse bit 0: residuals of the noise node,
-// bit 1: and its update
-__global__ void __launch_bounds__(128) k_cols_big(ParamArgs a) {
+// k_cols.hip for up to 128 rows, columns in order (Gauss-Seidel); fuse bit 0: residuals of the noise node, bit 1: and its update.
+// The rows of the matrix decouple (diagonal noise, diagonal column priors): a row belongs to TWO neighbouring lanes, each with one
+// half of it (64 columns) in registers; a column's update is a dot product of the row with a row of G -- the two halves meet in
+// one cross-lane add -- and a write of one register, which for a run-time column index is a chain of 64 selects on the lane that
+// owns that half.  G sits in LDS (128 KB, read-only after the start), so the column loop has no barrier at all; what a column needs
+// from global memory (its prior, the linear term, a known entry) is fetched two columns ahead; the block sums of a column (the log
+// determinant of its precision, its number of known entries) are wavefront sums left in LDS and added up after the loop.
+// (The first version kept the matrix as [col][row] in LDS, one thread per row: two wavefronts per CU, five barriers and four
+// dependent global loads per column -- 7.4 ms at N = 1024, D = K = 128.)
+#define CB_H 64         // columns per lane
+__global__ void __launch_bounds__(256) k_cols_big(ParamArgs a) {
     extern __shared__ double lds[];
-    double* Mb = lds;                   // [col][row], 128 x 128
-    double* gv = Mb + BDP * BDP;        // [128] row i of G
-    double* red = gv + BDP;             // [2]
+    double* Gl = lds;                       // [128][128] zero padded
+    double* plp = Gl + BDP * BDP;           // [4 wavefronts][128 columns] sums of log precision
+    double* pkn = plp + 4 * BDP;            // [4][128] numbers of known entries
+    double* gd = pkn + 4 * BDP;             // [128] the diagonal of G
+    double* red = gd + BDP;                 // [4]
     const int WHICH = a.which0 + blockIdx.y, n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
     const int rows = WHICH == 0 ? D : K;
+    const int row = tid >> 1, half = tid & 1, lane = tid & 63, wave = tid >> 6;
     double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
     double* V = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
     double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
@@ -767,75 +788,109 @@ __global__ void __launch_bounds__(128) k_cols_big(ParamArgs a) {
     const double* mo = a.mom + (size_t)n * mom_total(D, K);
     const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
     const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
-    const bool live = tid < rows;
-    const int lr = live ? tid : 0;
-    for (int idx = tid; idx < BDP * BDP; idx += 128) {
-        const int col = idx >> 7, row = idx & 127;
-        Mb[idx] = (row < rows && col < D) ? M[(size_t)row * D + col] : 0.0;
-    }
-    const double lam = live ? (WHICH == 0 ? a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid]
-                                          : a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid]) : 0.0;
+    const bool live = row < rows;
+    const int lr = live ? row : 0;
+    for (int idx = tid; idx < BDP * BDP; idx += 256) {
+        const int i = idx >> 7, j = idx & 127;
+        Gl[idx] = (i < D && j < D && i != j) ? G[(size_t)i * D + j] : 0.0;            // without the diagonal: a column's own entry does
+    }                                                                                   // not enter its update; gd holds it
+    if (tid < BDP) gd[tid] = tid < D ? G[(size_t)tid * D + tid] : 0.0;
+    double Mr[CB_H];                        // columns 64 half .. 64 half + 63 of this row
+#pragma unroll
+    for (int j = 0; j < CB_H; ++j) { const int col = CB_H * half + j; Mr[j] = (live && col < D) ? M[(size_t)lr * D + col] : 0.0; }
+    const double lam = live ? (WHICH == 0 ? a.Q_a[(size_t)n * D + lr] / a.Q_b[(size_t)n * D + lr]
+                                          : a.R_a[(size_t)n * K + lr] / a.R_b[(size_t)n * K + lr]) : 0.0;
     __syncthreads();
-    for (int i = a.c0; i < a.c1; ++i) {
-        gv[tid] = tid < D ? G[(size_t)i * D + tid] : 0.0;
-        __syncthreads();
+    // the dot product of this row with row i of G without its diagonal entry: this lane's half, then the neighbour's
+    auto rowdot = [&](int i) {
+        const double* gr = Gl + i * BDP + CB_H * half;
         double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll 8
-        for (int j = 0; j < BDP; j += 2) {
-            acc0 = __builtin_fma(Mb[j * BDP + tid], (j != i) ? gv[j] : 0.0, acc0);
-            acc1 = __builtin_fma(Mb[(j + 1) * BDP + tid], (j + 1 != i) ? gv[j + 1] : 0.0, acc1);
+#pragma unroll
+        for (int j = 0; j < CB_H; j += 2) {
+            const d2 g = *reinterpret_cast<const d2*>(gr + j);
+            acc0 = __builtin_fma(Mr[j], g[0], acc0);
+            acc1 = __builtin_fma(Mr[j + 1], g[1], acc1);
         }
-        const double p0 = pp[(size_t)i * rows + lr];
-        const double prec = p0 + lam * gv[i];                                           // qprec  gaussian.py:117
+        const double s = acc0 + acc1;
+        return s + __shfl_xor(s, 1, 64);
+    };
+    struct ColIn { double p0, pmv, hv, ob; };
+    auto fetch = [&](int i) {
+        ColIn c;
+        const int ic = i < D ? i : D - 1;
+        c.p0 = pp[(size_t)ic * rows + lr]; c.pmv = pm[(size_t)lr * D + ic]; c.hv = H[(size_t)lr * D + ic]; c.ob = obs[(size_t)lr * D + ic];
+        return c;
+    };
+    ColIn c0 = fetch(a.c0), c1 = fetch(a.c0 + 1);
+    for (int i = a.c0; i < a.c1; ++i) {
+        const ColIn cur = c0;
+        c0 = c1; c1 = fetch(i + 2);
+        const double dot = rowdot(i);
+        const double gii = gd[i];
+        const double prec = cur.p0 + lam * gii;                                         // qprec  gaussian.py:117
         double var = 1.0 / prec;                                                        // qcov   gaussian.py:118-119
-        double val = (p0 * pm[(size_t)lr * D + i] + lam * (H[(size_t)lr * D + i] - (acc0 + acc1))) * var;   // qmu :122-123
+        double val = (cur.p0 * cur.pmv + lam * (cur.hv - dot)) * var;                   // qmu :122-123
         // known entries (Gaussian.observe on a column, LDS_knowns_in_A.py:73-74): conditioning a diagonal Gaussian on them
         // (gaussian.py:125-134) pins those entries and leaves the others alone; a column whose entries are all known is
         // never changed (gaussian.py:109-110)
-        const double ob = obs[(size_t)lr * D + i];
-        const bool known = live && (ob == ob);
-        if (known) { val = ob; var = 0.0; }
-        const double lp = bsum128(live ? log(prec) : 0.0, red);                         // also the barrier before Mb / gv change
-        const int nknown = (int)bsum128(known ? 1.0 : 0.0, red);
-        if (live) { Mb[i * BDP + tid] = val; V[(size_t)i * rows + tid] = var; }
-        if (tid == 0 && nknown < rows) qld[i] = 0.5 / (0.5 * lp);                       // quirk Q1, gaussian.py:120: of the whole precision
+        const bool known = live && (cur.ob == cur.ob);
+        if (known) { val = cur.ob; var = 0.0; }
+        const bool mine = live && half == 0;
+        const double lp = wave_sum(mine ? log(prec) : 0.0);
+        const double nk = wave_sum((mine && known) ? 1.0 : 0.0);
+        if (lane == 0) { plp[wave * BDP + i] = lp; pkn[wave * BDP + i] = nk; }
+        if (mine) V[(size_t)i * rows + row] = var;
+        if (live && half == (i >> 6)) {
+            const int jj = i & (CB_H - 1);
+#pragma unroll
+            for (int j = 0; j < CB_H; ++j) Mr[j] = (j == jj) ? val : Mr[j];
+        }
     }
     __syncthreads();
-    if (a.c0 < a.c1) {
-        for (int idx = tid; idx < rows * D; idx += 128) {
-            const int row = idx / D, col = idx % D;
-            if (col >= a.c0 && col < a.c1) M[idx] = Mb[col * BDP + row];
-        }
+    if (tid >= a.c0 && tid < a.c1 && tid < BDP) {
+        const double lp = ((plp[tid] + plp[BDP + tid]) + plp[2 * BDP + tid]) + plp[3 * BDP + tid];
+        const double nk = ((pkn[tid] + pkn[BDP + tid]) + pkn[2 * BDP + tid]) + pkn[3 * BDP + tid];
+        if ((int)nk < rows) qld[tid] = 0.5 / (0.5 * lp);                                // quirk Q1, gaussian.py:120: of the whole precision
+    }
+    if (a.c0 < a.c1 && live) {
+#pragma unroll
+        for (int j = 0; j < CB_H; ++j) { const int col = CB_H * half + j; if (col >= a.c0 && col < a.c1 && col < D) M[(size_t)row * D + col] = Mr[j]; }
     }
     if (a.fuse & 1) {
         // res[k] = 1/2 own[k] + 1/2 (sum_ij M[k,i] G[i,j] M[k,j] + sum_i var_i[k] G[i,i]) - sum_i H[k,i] M[k,i]   (node.py:260-271)
         double e = 0.0, hm = 0.0;
+        auto fetch2 = [&](int i, double& vv, double& hh) { const int ic = i < D ? i : D - 1; vv = V[(size_t)ic * rows + lr]; hh = H[(size_t)lr * D + ic]; };
+        __syncthreads();                    // this workgroup's variances of all columns are in memory (written by the lanes with half == 0)
+        double v0, h0, v1, h1;
+        fetch2(0, v0, h0); fetch2(1, v1, h1);
         for (int i = 0; i < D; ++i) {
-            __syncthreads();
-            gv[tid] = tid < D ? G[(size_t)i * D + tid] : 0.0;
-            __syncthreads();
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < BDP; j += 2) {
-                s0 = __builtin_fma(Mb[j * BDP + tid], gv[j], s0);
-                s1 = __builtin_fma(Mb[(j + 1) * BDP + tid], gv[j + 1], s1);
-            }
-            const double mi = Mb[i * BDP + tid];
-            e += mi * (s0 + s1) + V[(size_t)i * rows + lr] * gv[i];
-            hm += H[(size_t)lr * D + i] * mi;
+            const double vi = v0, hi = h0;
+            v0 = v1; h0 = h1; fetch2(i + 2, v1, h1);
+            const int jj = i & (CB_H - 1);
+            double mi = 0.0;
+#pragma unroll
+            for (int j = 0; j < CB_H; ++j) mi = (j == jj) ? Mr[j] : mi;
+            mi = __shfl(mi, (lane & ~1) | (i >> 6), 64);                                // from the lane that owns column i of this row
+            const double s = rowdot(i) + mi * gd[i];
+            e += mi * s + vi * gd[i];
+            hm += hi * mi;
         }
         const double own = WHICH == 0 ? mo[MOM_DP(D, K) + lr] : a.Syy[(size_t)n * K + lr];
         double r = 0.5 * own + 0.5 * e - hm;
-        if (live) (WHICH == 0 ? a.resQ : a.resR)[(size_t)n * rows + tid] = r;
+        const bool mine = live && half == 0;
+        if (mine) (WHICH == 0 ? a.resQ : a.resR)[(size_t)n * rows + row] = r;
         if (a.fuse & 2) {
             const double* b0 = WHICH == 0 ? a.pri.Q_b0 : a.pri.R_b0;
             double* qb = (WHICH == 0 ? a.Q_b : a.R_b) + (size_t)n * rows;
-            r = live ? r : 0.0;
             if (a.noise == PYVB_NOISE_GAMMA) {
-                r = bsum128(r, red);
-                if (live) qb[tid] = b0[0] + r;
-            } else if (live) {
-                qb[tid] = b0[tid] + r;
+                double t = wave_sum(mine ? r : 0.0);
+                __syncthreads();
+                if (lane == 0) red[wave] = t;
+                __syncthreads();
+                t = ((red[0] + red[1]) + red[2]) + red[3];
+                if (mine) qb[row] = b0[0] + t;
+            } else if (mine) {
+                qb[row] = b0[row] + r;
             }
         }
     }
@@ -844,14 +899,14 @@ __global__ void __launch_bounds__(128) k_cols_big(ParamArgs a) {
 int launch_cols_big(pyvb_lds* h, int which, int c0, int c1, int fuse) {
     ParamArgs a = make_args(h);
     a.c0 = c0; a.c1 = c1; a.which0 = which == 1 ? 1 : 0; a.fuse = fuse;
-    const size_t lds = ((size_t)BDP * BDP + BDP + 8) * sizeof(double);
+    const size_t lds = ((size_t)BDP * BDP + 9 * BDP + 8) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)k_cols_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     TimedLaunch tl(h, PYVB_K_PARAMS);
-    hipLaunchKernelGGL(k_cols_big, dim3(h->N, which == 2 ? 2 : 1), dim3(128), lds, h->stream, a);
+    hipLaunchKernelGGL(k_cols_big, dim3(h->N, which == 2 ? 2 : 1), dim3(256), lds, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
