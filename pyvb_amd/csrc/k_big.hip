@@ -18,6 +18,8 @@
 // Diagonal-Gamma and Gamma noise, fully observed outputs (known entries of A / C are served): the other variants stay on the
 // 64-wide kernels (larger graphs of those kinds run node by node on the generic plan).
 #include "params.h"
+#include <cstdio>
+#include <cstdlib>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 #define BDP 128     // padded dimension
@@ -462,41 +464,61 @@ struct BigPrepArgs {
 };
 
 // C = A * B, 128 x 128 x 128 on the matrix cores; wavefront w owns row tiles w and w + 4; a_at(i, k), b_at(k, j) fetch
-// operand elements, store(i, j, v) consumes results
+// operand elements, store(i, j, v) consumes results.  A row tile's 32 A operands are fetched at once; a column tile is ONE chain
+// of 32 dependent MFMAs into one accumulator (at one wavefront per SIMD a chain runs at 70 cycles per MFMA, eight accumulators
+// taken in turn at twice that), its 32 B operands fetched while the chain before it runs.  (Operands fetched where they were
+// used, eight accumulators in turn: 620 cycles per MFMA with operands in global memory, 170 with both in LDS -- cycle stamps.)
+// b_at should walk memory along j for neighbouring lanes (row-major B): its loads are 16 lanes x 8 contiguous bytes.
 template <class FA, class FB, class FS>
 __device__ __forceinline__ void mm128(int wave, int lane, FA a_at, FB b_at, FS store) {
     const int r = lane & 15, q = lane >> 4;
     for (int m = wave; m < BDT; m += 4) {
-        d4 acc[BDT];
+        double av[BDS], bA[BDS], bB[BDS];
 #pragma unroll
-        for (int nn = 0; nn < BDT; ++nn) acc[nn] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-        for (int s = 0; s < BDS; ++s) {
-            const double av = a_at(16 * m + r, 4 * s + q);
+        for (int s = 0; s < BDS; ++s) av[s] = a_at(16 * m + r, 4 * s + q);
+        auto fetch = [&](double (&bv)[BDS], int nn) {
+            const int nc = nn < BDT ? nn : BDT - 1;
 #pragma unroll
-            for (int nn = 0; nn < BDT; ++nn) acc[nn] = MFMA(av, b_at(4 * s + q, 16 * nn + r), acc[nn]);
+            for (int s = 0; s < BDS; ++s) bv[s] = b_at(4 * s + q, 16 * nc + r);
+        };
+        auto chain = [&](const double (&bv)[BDS], int nn) {
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < BDS; ++s) acc = MFMA(av[s], bv[s], acc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store(16 * m + 4 * e + q, 16 * nn + r, acc[e]);
+        };
+        fetch(bA, 0);
+#pragma unroll 1
+        for (int nn = 0; nn < BDT; nn += 2) {
+            fetch(bB, nn + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            chain(bA, nn);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(bA, nn + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            chain(bB, nn + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int nn = 0; nn < BDT; ++nn)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) store(16 * m + 4 * e + q, 16 * nn + r, acc[nn][e]);
     }
 }
 
-// W <- W * W in place (LDS, stride BLD): both row tiles of every wavefront into registers, a barrier, then out
+// W <- W * W in place (LDS, stride BLD): both row tiles of every wavefront into registers (chains as in mm128), a barrier, then out
 __device__ static void square128(double* W, int wave, int lane) {
     const int r = lane & 15, q = lane >> 4;
     d4 acc[2][BDT];
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
         const int m = wave + 4 * h2;
+        double av[BDS];
 #pragma unroll
-        for (int nn = 0; nn < BDT; ++nn) acc[h2][nn] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-        for (int s = 0; s < BDS; ++s) {
-            const double av = W[(16 * m + r) * BLD + 4 * s + q];
+        for (int s = 0; s < BDS; ++s) av[s] = W[(16 * m + r) * BLD + 4 * s + q];
 #pragma unroll
-            for (int nn = 0; nn < BDT; ++nn) acc[h2][nn] = MFMA(av, W[(4 * s + q) * BLD + 16 * nn + r], acc[h2][nn]);
+        for (int nn = 0; nn < BDT; ++nn) {          // B operands straight from LDS: the compiler keeps a few reads ahead of the chain
+            d4 c = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < BDS; ++s) c = MFMA(av[s], W[(4 * s + q) * BLD + 16 * nn + r], c);
+            acc[h2][nn] = c;
         }
     }
     __syncthreads();
@@ -646,10 +668,20 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     }
     __syncthreads();
     // <C^T R C> -> S1;  <C^T R C> + <A^T Q A> -> Pm        (node.py:213-227)
-    mm128(wave, lane, [&](int i, int k) { return C_at(k, i) * rbar[k]; }, [&](int k, int j) { return C_at(k, j); },
+    // The means are staged, zero padded, in the LDS work matrix first: both operands of a product are then LDS reads without
+    // bounds logic (fetching them from the arrays inside the product: 424k cycles per product, 3x this).
+    double* S2 = S1 + BDP * BDP;
+    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = C_at(k, j); }
+    __syncthreads();
+    mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i] * rbar[k]; }, [&](int k, int j) { return Pm[k * BLD + j]; },
           [&](int i, int j, double v) { S1[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? rowp[i] : 0.0) : 0.0; });
-    mm128(wave, lane, [&](int i, int k) { return A_at(k, i) * qbar[k]; }, [&](int k, int j) { return A_at(k, j); },
-          [&](int i, int j, double v) { Pm[i * BLD + j] = (i < D && j < D) ? S1[(size_t)i * BDP + j] + v + (i == j ? colp[i] : 0.0) : 0.0; });
+    __syncthreads();
+    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = A_at(k, j); }
+    __syncthreads();
+    mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i] * qbar[k]; }, [&](int k, int j) { return Pm[k * BLD + j]; },
+          [&](int i, int j, double v) { S2[(size_t)i * BDP + j] = (i < D && j < D) ? S1[(size_t)i * BDP + j] + v + (i == j ? colp[i] : 0.0) : 0.0; });
+    __syncthreads();
+    for (int idx = tid; idx < BDP * BDP; idx += 256) Pm[(idx >> 7) * BLD + (idx & 127)] = S2[idx];
     __syncthreads();
 
     // the three posterior precisions (gaussian.py:117), inverted one after the other (qcov, :118-119; q_ln_det, :120)
@@ -703,11 +735,21 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
         g[L.ow0 + tid] = s;
     }
     // gains of the interior class: F = Sigma <Q><A>, B = Sigma <A>^T<Q>, G = Sigma <C>^T<R>
-    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return qbar[k] * A_at(k, j); },
+    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; S2[idx] = qbar[k] * A_at(k, j); }
+    __syncthreads();
+    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return S2[(size_t)k * BDP + j]; },
           [&](int i, int j, double v) { const bool in = i < D && j < D; g[L.oFn + pos_nat(i, j, BDS)] = in ? v : 0.0; S1[(size_t)i * BDP + j] = in ? v : 0.0; });
-    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return A_at(j, k) * qbar[j]; },
+    __syncthreads();
+    // the B operands of the next two products are transposes of row-major matrices: written out once, transposed and scaled,
+    // so that the products read them along rows like the others (a lane per matrix row would touch a cache line per element)
+    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int j = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + j] = A_at(j, k) * qbar[j]; }
+    __syncthreads();
+    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return S2[(size_t)k * BDP + j]; },
           [&](int i, int j, double v) { g[L.oBn + pos_nat(i, j, BDS)] = (i < D && j < D) ? v : 0.0; });
-    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int l) { return C_at(l, k) * rbar[l]; },
+    __syncthreads();
+    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int l = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + l] = C_at(l, k) * rbar[l]; }
+    __syncthreads();
+    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int l) { return S2[(size_t)k * BDP + l]; },
           [&](int i, int l, double v) { g[L.oGp + pos_perm(i, l, BDS)] = (i < D && l < K) ? v : 0.0; });
     __syncthreads();
     // warm-up lengths: powers of F, and of B^T (inf-norm of powers of B^T = 1-norm of powers of B)
