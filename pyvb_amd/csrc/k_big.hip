@@ -2,21 +2,25 @@
 // The reference has no size limit (gaussian.py:43-46); the kernels of k_sweep.hip / k_prep.hip / k_stats.hip / k_cols.hip keep one
 // 64 x 64 matrix per wavefront in registers and stop at 64.  Here a replicate is a WORKGROUP of four wavefronts:
 //
-//   k_sweep_big   wavefront w owns the row tiles 2w, 2w+1 (32 rows) of the recurrence matrices R, I as MFMA A operands in
-//                 registers (2 x 64 doubles per lane) and of G in LDS (32 KB per wavefront); the state of the 16 time segments
-//                 (128 x 16, the MFMA B operand) is exchanged through LDS once per step: every wavefront writes the two
-//                 accumulator tiles it has just formed -- accumulator layout = B-operand layout, as in k_sweep.hip -- and
-//                 reads the other six.  Same segmentation of the time axis, same warm-up from k_prep's contraction bound,
-//                 same boundary nodes, same c_t cache between the forward sweep and the backward one behind it (no fused Sxx).
-//   k_prep_big    one work matrix in LDS (128 x 130 doubles), intermediates in a per-replicate global scratch; the three
-//                 precisions inverted one after the other by the whole workgroup (8 x 8 tile per thread).
-//   k_stats_big   Sxx, Sx1x, Syx in one pass per (replicate, chunk): a wavefront holds row tile w of all three (3 x 8 tiles).
-//   k_cols_big    thread = row of the matrix; the Gauss-Seidel pass over the columns runs column by column (the rows decouple
-//                 under diagonal noise and diagonal column priors), <M> as [col][row] in LDS.
+//   k_gy_big      G y_t of every interior node as a batched product of its own (16 time steps = the 16 MFMA columns), into the
+//                 c_t buffer: the sequential kernel is left with two products per step and no operand in LDS but the state.
+//   k_sweep_big   wavefront w owns the row tiles 2w, 2w+1 (32 rows) of the two recurrence matrices as MFMA A operands in
+//                 registers (2 x 64 doubles per lane each); the state of the 16 time segments (128 x 16, the MFMA B operand)
+//                 lives in two LDS buffers: every step each wavefront writes the two accumulator tiles it has just formed --
+//                 accumulator layout = B-operand layout, as in k_sweep.hip -- into one and reads all eight from the other.
+//                 Same segmentation of the time axis, same warm-up from k_prep's contraction bound, same boundary nodes, same
+//                 c_t cache between the forward sweep and the backward one behind it (no fused Sxx).
+//   k_prep_big    one work matrix in LDS (128 x 130 doubles), intermediates in a per-replicate global scratch; products as chains
+//                 of dependent MFMAs on staged operands; the three precisions inverted one after the other by the whole
+//                 workgroup (8 x 8 tile per thread).
+//   k_stats_big   Sxx, Sx1x, Syx in one pass per (replicate, chunk): a wavefront holds row tile w of all three, its column
+//                 tiles in rotated order so that the symmetric Sxx is formed once per pair of tiles.
+//   k_cols_big    a row of the matrix = two lanes with half of it each in registers; the Gauss-Seidel pass over the columns runs
+//                 column by column without a barrier (the rows decouple under diagonal noise and diagonal column priors), G in LDS.
 // Reference methods as in the small kernels: Gaussian.update gaussian.py:102-123, Multiplication.pass_up_m1_m2 node.py:182-232,
 // hstack.pass_up_m1_m2 nodes_todo.py:43-62, Gamma / DiagonalGamma.update nodes_todo.py:130-138, :187-190.
-// Diagonal-Gamma and Gamma noise, fully observed outputs (known entries of A / C are served): the other variants stay on the
-// 64-wide kernels (larger graphs of those kinds run node by node on the generic plan).
+// Diagonal-Gamma and Gamma noise, known entries of A / C, outputs with NaN (k_missing.hip, two entries per lane) and single X_t
+// updates are served; Wishart noise stays on the 64-wide kernels (a larger graph of that kind runs node by node on the generic plan).
 #include "params.h"
 #include <cstdio>
 #include <cstdlib>
@@ -792,15 +796,6 @@ int launch_prep_big(pyvb_lds* h) {
 // ======================================================================================================================
 // columns of A and C, residuals, noise update
 // ======================================================================================================================
-// sum over the (up to) 128 threads of the workgroup; red: 2 doubles of LDS
-__device__ __forceinline__ double bsum128(double v, double* red) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1];
-}
-
 // k_cols.hip for up to 128 rows, columns in order (Gauss-Seidel); fuse bit 0: residuals of the noise node, bit 1: and its update.
 // The rows of the matrix decouple (diagonal noise, diagonal column priors): a row belongs to TWO neighbouring lanes, each with one
 // half of it (64 columns) in registers; a column's update is a dot product of the row with a row of G -- the two halves meet in

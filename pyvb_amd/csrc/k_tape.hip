@@ -32,13 +32,15 @@ enum {
 //
 // Operands in LDS.  A record of the plain tape addresses the arena in global memory, and a record costs three dependent
 // round trips to it (the record itself, its operands, the drain of its stores before the barrier): about 3 us whatever
-// the arithmetic.  When a tape is uploaded the host therefore works out, per block of records that one workgroup
-// interprets, which arena extents the block touches (the same per-opcode table that validates the records), merges them
-// into segments and, if all of them fit the LDS budget, has the workgroup load them once, run the records out of LDS -- the
-// offsets are rewritten to LDS positions and carry T_LDS; the interpreter is instantiated with LDS pointers for such a block
-// -- and write the segments it has written back at the end.  (A block whose working set does not fit stays on global memory.)  Blocks of one launch touch disjoint state (the program's
-// contract), so the write-back cannot collide; blocks with gather / scatter records, whose addresses are data, are left
-// on global memory.  The records of a block are staged in LDS too, in chunks.
+// the arithmetic.  When a tape is uploaded the host therefore works out which arena extents the records touch (the same
+// per-opcode table that validates them) and cuts every block of records that one workgroup interprets into WINDOWS: the longest
+// runs of consecutive records whose extents, merged into segments, fit the LDS budget.  The workgroup takes a block's windows
+// in order: load the segments, run the records out of LDS -- their offsets are rewritten to LDS positions and carry T_LDS; the
+// interpreter is instantiated with LDS pointers for them --, write the segments it has written back.  Blocks of one launch touch
+// disjoint state (the program's contract), so the write-backs cannot collide; records with gather / scatter, whose addresses are
+// data, and runs too short to pay for a window stay on the arena.  The records of a window are staged in LDS too, in chunks.
+// Inside a window whose records are all node-sized the host also SCHEDULES them: bundles of TAPE_BUNDLE mutually independent
+// records, a wavefront each (tape_bundle, k_tape_cached).
 #define T_LDS 0x40000000        // in an offset field of a resolved record: position in the workgroup's LDS window, not in the arena
 #define TAPE_CHUNK 512          // records staged at a time
 #define TAPE_LDS_CAP 12288      // doubles of arena a block may keep in LDS (96 KB)
