@@ -338,11 +338,11 @@ def main():
         # it reads c_t and runs one; the statistics are three full 128-wide products
         P = 128
         work = {
-            "sweep_fwd": {"kernel": "k_sweep_big<3>(BigSweepArgs)", "executed_flops": nt * 4 * P * P,
+            "sweep_fwd": {"kernel": "k_sweep_big<3, 2>(BigSweepArgs)", "executed_flops": nt * 4 * P * P,
                           "algorithmic_flops": nt * 4 * D * D, "algorithmic_bytes": nt * 8 * (4 * P)},
-            "gy": {"kernel": "k_gy_big(BigGyArgs)", "executed_flops": nt * 2 * P * P,
+            "gy": {"kernel": "k_gy_big<true>(BigGyArgs)", "executed_flops": nt * 2 * P * P,
                    "algorithmic_flops": nt * 2 * D * K, "algorithmic_bytes": nt * 8 * (K + P)},
-            "sweep_bwd": {"kernel": "k_sweep_big<2>(BigSweepArgs)", "executed_flops": nt * 2 * P * P,
+            "sweep_bwd": {"kernel": "k_sweep_big<2, 2>(BigSweepArgs)", "executed_flops": nt * 2 * P * P,
                           "algorithmic_flops": nt * (4 * D * D + 2 * D * K), "algorithmic_bytes": nt * 8 * (2 * P)},
             "stats": {"kernel": "k_stats_big(BigStatsArgs)", "executed_flops": nt * 6 * P * P,
                       "algorithmic_flops": nt * (4 * D * D + 2 * D * K + 2 * K), "algorithmic_bytes": 0.0},
