@@ -407,14 +407,11 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
             const unsigned n0 = nbase + 16 * rt;
             d4 (&xa)[2] = xq[u0 + rt];
             unsigned (&ma)[2] = mq[u0 + rt];
-            double za[QS], zb[4][QT];
+            double za[QS];
 #pragma unroll
             for (int s = 0; s < QS; ++s) za[s] = zT[(size_t)rt * QT * 16 * 17 + (4 * s + qk) * 17 + c];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < QT; ++t) zb[s][t] = zf[(size_t)(rt * QT + t) * 256 + s * 64 + lane];
-            // ---- 3. prediction, imputation, write-back
+            // ---- 3. prediction, imputation, write-back (all tiles of the step, then stage 4 for all of them: the chains of
+            // different tiles are independent and fill each other's waits)
             const unsigned rowl = n0 + c;
             const bool rowupd = rowl < nrows && rowl >= lo && rowl < hi;
             double* const xtr = xt + rt * 16 * P12_XS;
@@ -438,9 +435,21 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
                 if (any && tok[jj]) *reinterpret_cast<d4*>(Xc + (size_t)rowl * DP + 32 * wave + 16 * jj + 4 * qk) = v;
                 *reinterpret_cast<d4*>(xtr + c * P12_XS + 16 * jj + 4 * qk) = v;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned n0 = nbase + 16 * rt;
+            d4 (&xa)[2] = xq[u0 + rt];
+            unsigned (&ma)[2] = mq[u0 + rt];
+            double* const xtr = xt + rt * 16 * P12_XS;
+            double zb[4][QT];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) zb[s][t] = zf[(size_t)(rt * QT + t) * 256 + s * 64 + lane];
             // ---- 4. statistics on the transposed tile: element r of tile p = row n0 + 4 r + qk, column col0 + p
             d4 xn[P2T];
 #pragma unroll
