@@ -211,31 +211,57 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
         const int tsafe = fwd ? 1 : T - 2;
         auto active = [&](int j) { int tt = cL + j; return j >= jc && j < Lseg && tt < Tint; };
         double* const trash = a.trash + (size_t)n * 512;
-        // Operands of a step -- this wavefront's rows of U and the old neighbour mean -- are loaded one step ahead, each set into
-        // the registers the step has just finished with.  Loads are unconditional: an inactive column reads a valid row (tsafe)
-        // and its result is discarded by the select.
-        auto load_o = [&](d4 (&mo)[BDT], int j) {
-            const double* op = Xo + (size_t)((active(j) ? tbase + sgn * j : tsafe) + sgn) * BDP;
+        // Operands of a step from global memory.  (a) This wavefront's rows of U (G y_t, or c_t for the cached backward sweep): three
+        // register sets, a row is requested two steps before it is used.  (b) The old neighbour mu_{t+dir}: the same 128 x 16 block
+        // for all four wavefronts -- each fetches the two row tiles it also owns of the state (a quarter of the block) and puts
+        // them into a ring of three LDS stages (B-operand order, like the state), requested three steps before the product that
+        // reads them.  Loads are unconditional: an inactive column reads a valid row (tsafe) and its result is discarded by the
+        // select.  (Every wavefront fetching the whole neighbour block into registers a step ahead, and U one step ahead: the
+        // forward sweep lost a quarter of its time to late loads and to the barrier skew they cause -- 16.3 ms at N = 1024;
+        // without the loads 14.6, without the barrier 14.6, without either and without the stores 12.3.)
+        auto row_of = [&](int j) { return active(j) ? tbase + sgn * j : tsafe; };
+        double* const ring = vs + BDP;                  // [3][BDS][64]
+        d4 gq[NTW];                                     // this wavefront's share of a neighbour block on its way to LDS
+        auto load_o = [&](int j) {
+            const double* op = Xo + (size_t)(row_of(j) + sgn) * BDP;
 #pragma unroll
-            for (int m = 0; m < BDT; ++m) mo[m] = *reinterpret_cast<const d4*>(op + (m * 4 + q) * 4);
+            for (int mm = 0; mm < NTW; ++mm) gq[mm] = *reinterpret_cast<const d4*>(op + ((NTW * w + mm) * 4 + q) * 4);
+        };
+        auto put_o = [&](int j) {                       // stage of step j: ((j - jstart) mod 3)
+            double* st = ring + ((j - jstart) % 3) * (BDS * 64);
+#pragma unroll
+            for (int mm = 0; mm < NTW; ++mm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[(4 * (NTW * w + mm) + r) * 64 + lane] = gq[mm][r];
         };
         double* const Un = a.U + (size_t)n * T * BDP;
-        d4 cv[NTW];
-        auto load_c = [&](int j) {
-            const double* cp = Un + (size_t)(active(j) ? tbase + sgn * j : tsafe) * BDP;
+        d4 cvA[NTW], cvB[NTW], cvC[NTW];
+        auto load_c = [&](d4 (&cv)[NTW], int j) {
+            const double* cp = Un + (size_t)row_of(j) * BDP;
 #pragma unroll
             for (int mm = 0; mm < NTW; ++mm) cv[mm] = *reinterpret_cast<const d4*>(cp + ((NTW * w + mm) * 4 + q) * 4);
         };
-        // the old neighbour's rows sit in two register sets: the set of step j + 1 is requested before the products of step j
-        d4 moA[BDT], moB[BDT];
-        auto step = [&](int j, const double* xr, double* xw, const d4 (&mo)[BDT], d4 (&mo_next)[BDT]) {
+        // The product with the old neighbour, I mu_{t+dir}, does not depend on the state: the one of step j + 1 is formed at the
+        // END of step j, between this wavefront's state writes and the barrier.
+        d4 accI[NTW];
+        auto iprod = [&](int j) {
+            const double* st = ring + ((j - jstart) % 3) * (BDS * 64);
+#pragma unroll
+            for (int mm = 0; mm < NTW; ++mm) {
+                accI[mm] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < BDS; ++s) accI[mm] = MFMA(ip[mm][s], st[s * 64 + lane], accI[mm]);
+            }
+        };
+        // cv: U rows of step j; cv_fill: the set that takes the rows of step j + 2
+        auto step = [&](int j, const double* xr, double* xw, const d4 (&cv)[NTW], d4 (&cv_fill)[NTW]) {
             const bool act = active(j);
             d4 acc[NTW];
 #pragma unroll
             for (int mm = 0; mm < NTW; ++mm) acc[mm] = cv[mm];
             __builtin_amdgcn_sched_barrier(0);
-            load_c(j + 1);
-            if constexpr (MODE != 2 && NTW == 2) load_o(mo_next, j + 1);         // two register sets: requested before the products
+            if constexpr (MODE != 2) { put_o(j + 2); load_o(j + 3); }       // the share fetched a step ago goes to LDS, the next one is requested
+            else load_c(cv_fill, j + 3);
             __builtin_amdgcn_sched_barrier(0);
             // R mu_{t-dir} (new): the segments' state
 #pragma unroll
@@ -248,17 +274,12 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
 #pragma unroll
                     for (int mm = 0; mm < NTW; ++mm) *reinterpret_cast<d4*>(ur + ((NTW * w + mm) * 4 + q) * 4) = acc[mm];
                 }
-                // I mu_{t+dir} (old)
 #pragma unroll
-                for (int mm = 0; mm < NTW; ++mm)
-#pragma unroll
-                    for (int s = 0; s < BDS; ++s) acc[mm] = MFMA(ip[mm][s], mo[s >> 2][s & 3], acc[mm]);
-                if constexpr (NTW == 1) {       // one set (256 registers at two wavefronts per SIMD): refilled as soon as it is consumed
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_o(mo_next, j + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int mm = 0; mm < NTW; ++mm) acc[mm] += accI[mm];           // I mu_{t+dir} (old), formed at the end of the step before
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MODE != 2) load_c(cv_fill, j + 3);             // after the store above: a column in its warm-up may read a row another column owns, never the
+            __builtin_amdgcn_sched_barrier(0);  // other way round in the same step (see MODE 3 at the top)
             // this wavefront's rows of the new state: kept where the column is active, then shared
             double* out = (act && j >= 0) ? Xn + (size_t)(tbase + sgn * j) * BDP : trash;
 #pragma unroll
@@ -271,18 +292,42 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xw[(4 * m + r) * 64 + lane] = nx[r];
             }
-            __syncthreads();            // the new state is complete; the buffer just read is free for the next step's writes
+            if constexpr (MODE != 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                iprod(j + 1);
+            }
+            // the new state is complete; the buffer just read is free for the next step's writes.  An LDS-only barrier: the
+            // wavefronts talk through LDS alone, and __syncthreads() would also wait for this wavefront's outstanding global loads
+            // and stores (s_waitcnt vmcnt(0)) -- the rows requested three steps ahead and the rows just stored -- at every step.
+            // (The one global hand-over, a warm-up column reading a U row its neighbour overwrites ~Lseg steps later, is ordered by
+            // the use of the loaded value before a barrier that precedes the store.)
+            if constexpr (MODE == 2) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
-        load_c(jstart);
-        if constexpr (MODE != 2) load_o(moA, jstart);
-        double* const xb1 = xb0 + BDS * 64;
-        int j = jstart;
-        for (; j + 1 < Lseg; j += 2) {
-            if constexpr (NTW == 2) { step(j, xb0, xb1, moA, moB); step(j + 1, xb1, xb0, moB, moA); }
-            else { step(j, xb0, xb1, moA, moA); step(j + 1, xb1, xb0, moA, moA); }
+        // prologue: U rows of the first three steps; neighbour blocks of the first two steps in LDS, the third on its way
+        load_c(cvA, jstart); load_c(cvB, jstart + 1); load_c(cvC, jstart + 2);
+        if constexpr (MODE != 2) {
+            load_o(jstart); put_o(jstart); load_o(jstart + 1); put_o(jstart + 1); load_o(jstart + 2);
+            __syncthreads();
+            iprod(jstart);
         }
+        double* const xb1 = xb0 + BDS * 64;
         const double* xfin = xb0;
-        if (j < Lseg) { if constexpr (NTW == 2) step(j, xb0, xb1, moA, moB); else step(j, xb0, xb1, moA, moA); xfin = xb1; }
+        // the U sets rotate with period 3, the state buffers with period 2
+        // (six steps per turn: both rotations come round, every buffer and register set is a compile-time choice)
+        int j = jstart;
+        for (; j < Lseg; j += 6) {
+            step(j, xb0, xb1, cvA, cvA); xfin = xb1;
+            if (j + 1 >= Lseg) break;
+            step(j + 1, xb1, xb0, cvB, cvB); xfin = xb0;
+            if (j + 2 >= Lseg) break;
+            step(j + 2, xb0, xb1, cvC, cvC); xfin = xb1;
+            if (j + 3 >= Lseg) break;
+            step(j + 3, xb1, xb0, cvA, cvA); xfin = xb0;
+            if (j + 4 >= Lseg) break;
+            step(j + 4, xb0, xb1, cvB, cvB); xfin = xb1;
+            if (j + 5 >= Lseg) break;
+            step(j + 5, xb1, xb0, cvC, cvC); xfin = xb0;
+        }
         // the column that holds the last interior node hands its state to the closing boundary step
         const int clast = (Tint - 1) / Lseg;
         if (w == 0 && c == clast) {
@@ -305,9 +350,9 @@ int launch_sweep_big(pyvb_lds* h, int direction) {
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
     a.A_mean = h->A_mean; a.C_mean = h->C_mean; a.trash = h->trash; a.U = h->U;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
-    const size_t lds = ((size_t)2 * BDS * 64 + 2 * BDP) * sizeof(double);
     // a backward sweep right behind a forward one (h->u_valid) reads c_t; anything else starts from G y_t
     const bool cached = direction == PYVB_BACKWARD && h->u_valid;
+    const size_t lds = ((size_t)2 * BDS * 64 + 2 * BDP + (cached ? 0 : 3 * BDS * 64)) * sizeof(double);        // MODE 3: + the neighbour ring
     if (!cached && h->T > 2) {
         BigGyArgs ga;
         ga.Y = h->Y; ga.gains = h->gains; ga.U = h->U; ga.trash = h->trash;
