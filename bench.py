@@ -155,6 +155,62 @@ def pca_workload(steps, warmup, with_cpu):
             "cpu_baseline": cpu}
 
 
+def d128_workload(steps, warmup, with_cpu):
+    """The headline's loop in the second shape class of the fused kernels (64 < max(D, K) <= 128; the reference has no size limit,
+    gaussian.py:43-46), appended to the headline line as workloads.lds_d128: T = 10^4, D = K = 128, 1024 replicates, measured like
+    the headline (inputs resident before the timed region, `steps` iterations after `warmup`).  Parity and CPU baseline on a
+    short copy of the problem (T = 40, two replicates, three iterations through the same kernels and through the oracle): an
+    oracle iteration at T = 10^4 takes 5 s per replicate at this size."""
+    from pyvb_amd.lds import LDSBatch
+    T, D, K, N = 10000, 128, 128, 1024
+    Y, st0, pri = make_inputs(T, D, K, N, seed=777)
+    b = LDSBatch.from_problem(Y, st0, pri)
+    del Y
+    b.iterate(warmup); b.sync()
+    t0 = time.perf_counter()
+    b.iterate(steps); b.sync()
+    dt = time.perf_counter() - t0
+    elbo = b.elbo()
+    b.close()
+    Ts, Ns, its = 40, 2, 3
+    Ys, ss, ps = make_inputs(Ts, D, K, Ns, seed=778)
+    sb = LDSBatch.from_problem(Ys, ss, ps); sb.iterate(its); gX = sb.get_state(("X",))["X"]; ge = sb.elbo(); sb.close()
+    parity, cpu = None, None
+    if with_cpu:
+        from oracle import lds_closed_form as O        # checker and CPU baseline only
+        st = O.expand_state(ss, ps, Ts)
+        t1 = time.perf_counter()
+        for _ in range(its):
+            ref = O.iterate(st, ps, Ys)
+        t_short = (time.perf_counter() - t1) / its / Ns        # seconds per replicate and iteration at T = Ts
+        parity = max(float(np.abs(gX - st["X"]).max() / np.abs(st["X"]).max()), float(np.max(np.abs(ge.sum(1) - ref.sum(1)) / np.abs(ref.sum(1)))))
+        # the oracle's iteration is a + b T (the parameter updates do not depend on T, and dominate at this size): a second,
+        # longer sample fixes b; the baseline is the model at T = 10^4
+        Tl = 400
+        Yl, sl, pl = make_inputs(Tl, D, K, 1, seed=779)
+        stl = O.expand_state(sl, pl, Tl)
+        t1 = time.perf_counter()
+        O.iterate(stl, pl, Yl)
+        t_long = time.perf_counter() - t1
+        bT = max(t_long - t_short, 0.0) / (Tl - Ts)
+        t_full = t_short + bT * (T - Ts)
+        cpu = {"value": 1.0 / (t_full * N), "unit": "VB iterations/s per 1024 replicates (model a + b T fitted to two samples, linear in replicates)",
+               "cores": os.cpu_count(), "kind": "port",
+               "sample": "oracle/lds_closed_form.py: %.2f s per replicate-iteration at T=%d (%d replicates x %d iterations), %.2f s at T=%d (1 x 1) -> %.2f s at T=%d" % (t_short, Ts, Ns, its, t_long, Tl, t_full, T)}
+    nt = float(N) * T
+    alg = nt * (8 * D * D + 4 * D * K) + nt * (4 * D * D + 2 * D * K + 2 * K)      # SURVEY 8(d): two sweeps + all statistics, as the headline's roofline.iteration
+    step_s = dt / steps
+    return {"workload": "LDS T=%d D=%d K=%d, %d replicates (second shape class of the fused kernels)" % (T, D, K, N),
+            "metric": "VB iterations/sec per 1024 replicates", "value": steps / dt, "unit": "VB iterations/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": step_s * 1e3, "dtype": "f64", "rel_err_vs_numpy": parity,
+            "parity_checked_on": "a T=%d, %d-replicate problem of the same shape class, %d iterations, same kernels" % (Ts, Ns, its),
+            "elbo_total": float(elbo.sum()),
+            "roofline": {"bound": "mfma", "achieved": alg / step_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": alg / step_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops": alg, "traffic": None,
+                         "kernel": "whole iteration (k_gy_big, k_sweep_big, k_stats_big, k_prep_big, k_cols_big)"},
+            "cpu_baseline": cpu}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: this process -- which has not touched the GPU (pyvb_amd is imported
     only further down, in the ranks) -- starts N fresh child processes of this script, one per GPU, with the environment a
@@ -440,7 +496,8 @@ def main():
         b = None
         if world == 1 and not args.no_workloads and (N, T, D, K) == (1024, 10000, 64, 64):
             # the other GPU-sized configuration of BASELINE.json, after the headline's timed region and with its memory released
-            out["workloads"] = {"pca_config5": pca_workload(args.steps, args.warmup, not args.no_cpu_baseline)}
+            out["workloads"] = {"pca_config5": pca_workload(args.steps, args.warmup, not args.no_cpu_baseline),
+                                "lds_d128": d128_workload(args.steps, args.warmup, not args.no_cpu_baseline)}
         print(json.dumps(out), flush=True)
     if b is not None:
         b.close()
