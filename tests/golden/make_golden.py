@@ -497,6 +497,10 @@ CASES = [
     # Wishart noise together with known entries of A / C, and with outputs that hold NaN: the FIRST update
     ("wishart_knowns_d3k4_t30", 30, 3, 4, "wishart", (1,), 20253, True, True),
     ("wishart_missing_d3k4_t24", 24, 3, 4, "wishart", (1,), 20254, True, False, True),
+    # the second shape class with few states and many outputs (cheap in the reference: its cost is in D): known entries of A / C
+    # and outputs that hold NaN on the 128-wide kernels (k_cols_big with 70 rows, the output kernels with two entries per lane)
+    ("knowns_d3k70_t20", 20, 3, 70, "diagonal_gamma", (1, 2), 20255, False, True),
+    ("missing_d3k70_t12", 12, 3, 70, "diagonal_gamma", (1, 2), 20256, False, False, True),
 ]
 
 
