@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(512) k_stats_big(BigStatsArgs a) {
     for (int k = 0; k < BDT; ++k) { sx1[k] = d4{0.0, 0.0, 0.0, 0.0}; syx[k] = sx1[k]; }
 #pragma unroll
     for (int k = 0; k < 5; ++k) sxx[k] = d4{0.0, 0.0, 0.0, 0.0};
-    double bv[2][BDT], x1v[2], yv[2];
+    double bv[3][BDT], x1v[3], yv[3];     // three operand sets: a k-step's rows are requested two k-steps (about 2.4 us) before their MFMAs
     auto fetch = [&](int tb, int h) {
         const int t = tb + q;
         const double* xb = t < t1 ? X + (size_t)t * BDP : Z;                          // rows beyond the chunk read as zeros
@@ -475,12 +475,14 @@ __global__ void __launch_bounds__(512) k_stats_big(BigStatsArgs a) {
         }
         if (w < 4) sxx[4] = MFMA(xa, bv[h][4], sxx[4]);
     };
-    fetch(t0, 0);
-    for (int tb = t0; tb < t1; tb += 8) {
-        fetch(tb + 4, 1);
+    fetch(t0, 0); fetch(t0 + 4, 1);
+    for (int tb = t0; tb < t1; tb += 12) {
+        fetch(tb + 8, 2);
         step(0);
-        fetch(tb + 8, 0);
+        fetch(tb + 12, 0);
         step(1);
+        fetch(tb + 16, 1);
+        step(2);
     }
 #pragma unroll
     for (int k = 0; k < BDT; ++k) {
