@@ -354,8 +354,12 @@ __global__ void __launch_bounds__(64 * CW_WAVES) k_cols_wishart(WArgs a) {
 //   qw = w0 + Rm
 // own = sum_t <x x^T> over the children (Q: t >= 1) or sum_t y y^T (R).  Rm is kept for the lower bound.
 __global__ void __launch_bounds__(256) k_wresid(WArgs a) {
-    __shared__ double Mb[64 * WLD], T1[64 * WLD];
+    // Three 64 x 64 x 64 products per (replicate, matrix) on the matrix cores: T1 = <M> G, E = T1 <M>^T, HM = H <M>^T (they were
+    // 0.54 ms of scalar FMAs with strided operand walks).  Wavefront w owns row tile w; operands zero padded to 64 in LDS
+    // (stride WLD: an A operand's 16 rows of a k-step then fall into different banks).
+    __shared__ double Mb[64 * WLD], T1[64 * WLD], Hb[64 * WLD], Gb[64 * WLD];
     const int WHICH = a.which0 + blockIdx.y, n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K, T = a.T, DP = a.DP;
+    const int w = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int rows = WHICH == 0 ? D : K;
     const double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
     const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + (size_t)n * D * cov_stride(rows);
@@ -363,39 +367,71 @@ __global__ void __launch_bounds__(256) k_wresid(WArgs a) {
     const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
     const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
     double* Rm = (WHICH == 0 ? a.RQ : a.RR) + (size_t)n * rows * rows;
-    for (int idx = tid; idx < rows * D; idx += 256) Mb[(idx / D) * WLD + idx % D] = M[idx];
-    __syncthreads();
-    for (int idx = tid; idx < rows * D; idx += 256) {       // T1 = <M> G
-        const int k = idx / D, j = idx % D;
-        double s = 0.0;
-#pragma unroll 16
-        for (int i = 0; i < D; ++i) s += Mb[k * WLD + i] * G[(size_t)i * D + j];
-        T1[k * WLD + j] = s;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int i = idx >> 6, j = idx & 63;
+        Mb[i * WLD + j] = (i < rows && j < D) ? M[(size_t)i * D + j] : 0.0;
+        Hb[i * WLD + j] = (i < rows && j < D) ? H[(size_t)i * D + j] : 0.0;
+        Gb[i * WLD + j] = (i < D && j < D) ? G[(size_t)i * D + j] : 0.0;
     }
     __syncthreads();
+    // T1 = <M> G: row tile w; A operand (row 16 w + r, k = 4 s + q) of Mb, B operand (k, column 16 nn + r) of Gb
+    {
+        d4 acc[4];
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) acc[nn] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const double av = Mb[(16 * w + r) * WLD + 4 * s4 + q];
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) acc[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Gb[(4 * s4 + q) * WLD + 16 * nn + r], acc[nn], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T1[(16 * w + 4 * e + q) * WLD + 16 * nn + r] = acc[nn][e];
+    }
+    __syncthreads();
+    // E = T1 <M>^T and HM = H <M>^T: B operand (k = j, column l) = Mb[l][j]
+    d4 accE[4], accH[4];
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) { accE[nn] = d4{0.0, 0.0, 0.0, 0.0}; accH[nn] = accE[nn]; }
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+        const double at = T1[(16 * w + r) * WLD + 4 * s4 + q], ah = Hb[(16 * w + r) * WLD + 4 * s4 + q];
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+            const double bm = Mb[(16 * nn + r) * WLD + 4 * s4 + q];
+            accE[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, bm, accE[nn], 0, 0, 0);
+            accH[nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah, bm, accH[nn], 0, 0, 0);
+        }
+    }
     const double* x0 = a.X + (size_t)n * T * DP;
     const double* S0 = a.Sigma + (size_t)n * 3 * D * D;
     const double* GC = mo + MOM_GC(D, K);
-    for (int idx = tid; idx < rows * rows; idx += 256) {
-        const int k = idx / rows, l = idx % rows;
-        double e = 0.0, hm = 0.0;
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const int k = 16 * w + 4 * e4 + q, l = 16 * nn + r;         // accumulator element (row k, column l)
+            if (k >= rows || l >= rows) continue;
+            const int idx = k * rows + l;
+            double e = accE[nn][e4];
+            const double hm = accH[nn][e4];
+            if (a.SG) e += a.SG[((size_t)n * 2 + WHICH) * 64 * 64 + idx];       // sum_i S_i G[i,i], formed by k_cols_wishart
+            else {
 #pragma unroll 16
-        for (int j = 0; j < D; ++j) { e += T1[k * WLD + j] * Mb[l * WLD + j]; hm += H[(size_t)k * D + j] * Mb[l * WLD + j]; }
-        if (a.SG) e += a.SG[((size_t)n * 2 + WHICH) * 64 * 64 + idx];       // sum_i S_i G[i,i], formed by k_cols_wishart
-        else {
-#pragma unroll 16
-            for (int i = 0; i < D; ++i) e += cov[(size_t)i * cov_stride(rows) + cov_pos(rows, k, l)] * G[(size_t)i * D + i];
+                for (int i = 0; i < D; ++i) e += cov[(size_t)i * cov_stride(rows) + cov_pos(rows, k, l)] * G[(size_t)i * D + i];
+            }
+            double own;
+            if (WHICH == 0) own = GC[idx] - x0[xpos(k)] * x0[xpos(l)] - S0[idx];          // sum_{t >= 1} <x x^T>
+            else own = a.SyyF[(size_t)n * K * K + idx] + (a.YcovS ? a.YcovS[(size_t)n * K * K + idx] : 0.0);        // <y y^T> = qmu qmu^T + qcov
+            const double rr = 0.5 * (own + e) - hm;
+            Rm[idx] = rr;
+            if (a.update) {
+                const double* w0 = WHICH == 0 ? a.pri.Q_w0 : a.pri.R_w0;
+                (WHICH == 0 ? a.Q_w : a.R_w)[(size_t)n * rows * rows + idx] = w0[idx] + rr;
+            }
         }
-        double own;
-        if (WHICH == 0) own = GC[idx] - x0[xpos(k)] * x0[xpos(l)] - S0[idx];          // sum_{t >= 1} <x x^T>
-        else own = a.SyyF[(size_t)n * K * K + idx] + (a.YcovS ? a.YcovS[(size_t)n * K * K + idx] : 0.0);        // <y y^T> = qmu qmu^T + qcov
-        const double r = 0.5 * (own + e) - hm;
-        Rm[idx] = r;
-        if (a.update) {
-            const double* w0 = WHICH == 0 ? a.pri.Q_w0 : a.pri.R_w0;
-            (WHICH == 0 ? a.Q_w : a.R_w)[(size_t)n * rows * rows + idx] = w0[idx] + r;
-        }
-    }
 }
 
 // ---- sum_t y_t y_t^T, once per set_observations
