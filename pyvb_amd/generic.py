@@ -397,8 +397,8 @@ class GenericPlan(object):
             self._tapes[key] = (None, t.array(), res)
             if t.marks:
                 self._programs[key] = self._program(t)
-        tid, ops, res = self._tapes[key]
-        self._ensure_executor(self.temp_high)
+        self._ensure_executor(self.temp_high)       # may replace the executor (a larger arena): every cached tape id is forgotten then,
+        tid, ops, res = self._tapes[key]            # so the entry is read only afterwards
         if self._const_dirty:
             self.ex.write(0, np.array(self._const_vals, dtype=float))
             self._const_dirty = False

@@ -565,3 +565,36 @@ def test_records_scheduled_into_bundles_compute_what_the_tape_order_computes():
         ex.close()
         scale = max(1.0, np.abs(ref).max())
         assert np.abs(got - ref).max() <= 1e-11 * scale, "case %d: %g" % (case, np.abs(got - ref).max() / scale)
+
+
+def test_cached_tapes_survive_a_growing_arena(monkeypatch):
+    """The node-by-node plan uploads a node's tape once and keeps its id.  When a later request needs a larger arena the executor is
+    replaced and every tape is uploaded again: a request for a tape cached on the OLD executor must not run its stale id (found by
+    profiles/fuzz_ops_pca.py, seed 12: "no such tape" -- the id was read before the executor was replaced)."""
+    from pyvb_amd import generic, _recognise, nodes
+    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+    rng = np.random.default_rng(5)
+    np.random.seed(3)                           # the constructors draw their initial posteriors from numpy's global generator
+    mu = nodes.Gaussian(3, np.zeros((3, 1)), np.eye(3) * 1e-2)
+    prec = nodes.DiagonalGamma(3, np.ones(3), np.ones(3))
+    xs = [nodes.Gaussian(3, mu, prec) for _ in range(6)]
+    for x in xs:
+        x.observe(rng.standard_normal((3, 1)))
+    mu.update(); first = np.array(mu.qmu)
+    plan = nodes._plan_of(mu)
+    old = plan.ex
+    plan.temp_high = old.size + 50000           # what a request with large temporaries does to the plan
+    prec.update(); _ = np.array(prec.qb)        # (requests are queued: the read issues them) runs on a new, larger executor
+    assert plan.ex is not old
+    mu.update()                                 # its tape was cached on the old executor
+    again = np.array(mu.qmu)
+    assert np.all(np.isfinite(again)) and again.shape == first.shape
+    # the same schedule without the growth
+    np.random.seed(3)
+    mu2 = nodes.Gaussian(3, np.zeros((3, 1)), np.eye(3) * 1e-2)
+    prec2 = nodes.DiagonalGamma(3, np.ones(3), np.ones(3))
+    xs2 = [nodes.Gaussian(3, mu2, prec2) for _ in range(6)]
+    for x, x0 in zip(xs2, xs):
+        x.observe(np.array(x0.qmu))
+    mu2.update(); _ = np.array(mu2.qmu); prec2.update(); _ = np.array(prec2.qb); mu2.update()
+    assert np.allclose(again, np.array(mu2.qmu), rtol=1e-13, atol=0)
