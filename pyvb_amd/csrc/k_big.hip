@@ -297,8 +297,8 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
                 iprod(j + 1);
             }
             // the new state is complete; the buffer just read is free for the next step's writes.  An LDS-only barrier: the
-            // wavefronts talk through LDS alone, and __syncthreads() would also wait for this wavefront's outstanding global loads
-            // and stores (s_waitcnt vmcnt(0)) -- the rows requested three steps ahead and the rows just stored -- at every step.
+            // wavefronts talk through LDS alone; nothing here should wait for the rows requested three steps ahead or the rows
+            // just stored (the full __syncthreads() measured the same on this target).
             // (The one global hand-over, a warm-up column reading a U row its neighbour overwrites ~Lseg steps later, is ordered by
             // the use of the loaded value before a barrier that precedes the store.)
             if constexpr (MODE == 2) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
