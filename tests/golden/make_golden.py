@@ -501,6 +501,8 @@ CASES = [
     # and outputs that hold NaN on the 128-wide kernels (k_cols_big with 70 rows, the output kernels with two entries per lane)
     ("knowns_d3k70_t20", 20, 3, 70, "diagonal_gamma", (1, 2), 20255, False, True),
     ("missing_d3k70_t12", 12, 3, 70, "diagonal_gamma", (1, 2), 20256, False, False, True),
+    ("gamma_d3k70_t10", 10, 3, 70, "gamma", (1, 2), 20257, False),
+    ("missing_gamma_d2k66_t9", 9, 2, 66, "gamma", (1, 2), 20258, False, False, True),
 ]
 
 
