@@ -450,7 +450,9 @@ PCA_CASES = [("example_n200_d5_q2", 200, 5, 2, (1, 2, 5), 30100),
              ("n40_d70_q17", 40, 70, 17, (1, 2), 30102),
              ("default_init_n50_d6_q2", 50, 6, 2, (1, 2, 4), 30103, False),
              # the full width of the row sweep (d > 224: eight wavefronts per workgroup in k_pca_pass12), q = 16
-             ("n24_d250_q16", 24, 250, 16, (1, 2), 30104)]
+             ("n24_d250_q16", 24, 250, 16, (1, 2), 30104),
+             # rows left as their constructors drew them (pyvb_pca_set_unpinned_rows) where several wavefronts share a row
+             ("default_init_n30_d70_q5", 30, 70, 5, (1, 2, 3), 30105, False)]
 
 
 def crawl_labels(mod, T=4, D=2, K=3):
