@@ -507,6 +507,8 @@ CASES = [
     ("missing_d3k70_t12", 12, 3, 70, "diagonal_gamma", (1, 2), 20256, False, False, True),
     ("gamma_d3k70_t10", 10, 3, 70, "gamma", (1, 2), 20257, False),
     ("missing_gamma_d2k66_t9", 9, 2, 66, "gamma", (1, 2), 20258, False, False, True),
+    # many states, known entries of A and C (k_cols_big on the 66 x 66 matrix): one iteration, a quarter of an hour of the reference
+    ("knowns_d66k3_t3", 3, 66, 3, "diagonal_gamma", (1,), 20259, False, True),
 ]
 
 
@@ -534,6 +536,6 @@ if __name__ == "__main__":
     for c in CASES:
         if sel and sel != ["small"] and c[0] not in sel:
             continue
-        if sel == ["small"] and c[2] >= 64:         # python tests/golden/make_golden.py d64k64_t4 d80k80_t3 for the slow ones
+        if sel == ["small"] and c[2] >= 64:         # python tests/golden/make_golden.py d64k64_t4 d80k80_t3 knowns_d66k3_t3 for the slow ones
             continue
         run_case(ref, *c)
