@@ -509,6 +509,8 @@ CASES = [
     ("missing_gamma_d2k66_t9", 9, 2, 66, "gamma", (1, 2), 20258, False, False, True),
     # many states, known entries of A and C (k_cols_big on the 66 x 66 matrix): one iteration, a quarter of an hour of the reference
     ("knowns_d66k3_t3", 3, 66, 3, "diagonal_gamma", (1,), 20259, False, True),
+    ("missing_d70k66_t4", 4, 70, 66, "diagonal_gamma", (1,), 20260, False, False, True),
+    ("gamma_d72k40_t4", 4, 72, 40, "gamma", (1,), 20261, False),
 ]
 
 
