@@ -511,6 +511,8 @@ CASES = [
     ("knowns_d66k3_t3", 3, 66, 3, "diagonal_gamma", (1,), 20259, False, True),
     ("missing_d70k66_t4", 4, 70, 66, "diagonal_gamma", (1,), 20260, False, False, True),
     ("gamma_d72k40_t4", 4, 72, 40, "gamma", (1,), 20261, False),
+    ("d96k8_t2", 2, 96, 8, "diagonal_gamma", (1,), 20262, False),       # the T = 2 edge (no interior node) with six row tiles of state
+    ("d128k128_t3", 3, 128, 128, "diagonal_gamma", (1,), 20263, False),  # the class at its full width
 ]
 
 
