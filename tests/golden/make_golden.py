@@ -520,6 +520,11 @@ CASES = [
     ("gamma_d72k40_t4", 4, 72, 40, "gamma", (1,), 20261, False),
     ("d96k8_t2", 2, 96, 8, "diagonal_gamma", (1,), 20262, False),       # the T = 2 edge (no interior node) with six row tiles of state
     ("d128k128_t3", 3, 128, 128, "diagonal_gamma", (1,), 20263, False),  # the class at its full width
+    # Wishart noise where a column covariance spans several 8 x 8 tiles (the fused column kernel's tile indexing, the packed upper
+    # tiles): the first update, plain, with known entries, with missing outputs
+    ("wishart_d20k24_t10", 10, 20, 24, "wishart", (1,), 20264, True),
+    ("wishart_knowns_d18k20_t8", 8, 18, 20, "wishart", (1,), 20265, True, True),
+    ("wishart_missing_d10k20_t8", 8, 10, 20, "wishart", (1,), 20266, True, False, True),
 ]
 
 
