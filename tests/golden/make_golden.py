@@ -525,6 +525,9 @@ CASES = [
     ("wishart_d20k24_t10", 10, 20, 24, "wishart", (1,), 20264, True),
     ("wishart_knowns_d18k20_t8", 8, 18, 20, "wishart", (1,), 20265, True, True),
     ("wishart_missing_d10k20_t8", 8, 10, 20, "wishart", (1,), 20266, True, False, True),
+    # ragged sizes of the 64-wide class (padded tiles: DT = 3, KT = 2; DT = 4, KT = 4 with K < 64)
+    ("d33k17_t20", 20, 33, 17, "diagonal_gamma", (1, 2), 20267, False),
+    ("gamma_d50k60_t12", 12, 50, 60, "gamma", (1, 2), 20268, False),
 ]
 
 
