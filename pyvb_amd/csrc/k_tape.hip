@@ -124,22 +124,46 @@ __device__ static void tape_exec(const TapeArgs& t, const int* recs, int count, 
             break; }
         case T_GEMM: {
             const int k = o[6];
-            for (int idx = tid; idx < m * n; idx += NT) {
-                int i, j; tape_divmod(idx, n, rn, i, j);
-                // strides instead of a choice per term, and eight terms fetched at a time (added in order): the sum over the children
-                // of a node with thousands of them is one such product with a row of ones, a load latency per term otherwise
-                const int as = (flags & 1) ? m : 1, bs = (flags & 2) ? 1 : n;
+            // strides instead of a choice per term, and eight terms fetched at a time: the sum over the children of a node
+            // with thousands of them is one such product with a row of ones, a load latency per term otherwise
+            const int as = (flags & 1) ? m : 1, bs = (flags & 2) ? 1 : n;
+            auto part_sum = [&](int i, int j, int l0, int step) {      // terms l0, l0 + step, ... of element (i, j), in that order
                 const P ap = a + ((flags & 1) ? i : i * k), bp = b + ((flags & 2) ? j * k : j);
                 double s = 0.0;
-                int l = 0;
-                for (; l + 8 <= k; l += 8) {
+                int l = l0;
+                for (; l + 7 * step < k; l += 8 * step) {
                     double av[8], bv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { av[u] = ap[(l + u) * as]; bv[u] = bp[(l + u) * bs]; }
+                    for (int u = 0; u < 8; ++u) { av[u] = ap[(l + u * step) * as]; bv[u] = bp[(l + u * step) * bs]; }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) s += av[u] * bv[u];
                 }
-                for (; l < k; ++l) s += ap[l * as] * bp[l * bs];
+                for (; l < k; l += step) s += ap[l * as] * bp[l * bs];
+                return s;
+            };
+            if (k >= 64 && 2 * m * n <= NT) {
+                // a long sum into few elements (the messages of thousands of children, the terms of a bound): every element's
+                // terms are split over PL neighbouring lanes of a wavefront -- lane p takes terms p, p + PL, ... -- and the PL
+                // partial sums are added in a fixed tree (shuffles): deterministic, but not the order of a chain of additions
+                int PL = 64;
+                while (PL * m * n > NT) PL >>= 1;
+                {
+                    const int e = tid / PL, p0 = tid % PL;
+                    const bool live = e < m * n;
+                    int i = 0, j = 0;
+                    if (live) tape_divmod(e, n, rn, i, j);
+                    double s = live ? part_sum(i, j, p0, PL) : 0.0;
+                    for (int sh = PL >> 1; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);
+                    if (live && p0 == 0) {
+                        if (flags & 8) s = -s;
+                        dst[e] = (flags & 4) ? dst[e] + s : s;
+                    }
+                }
+                break;
+            }
+            for (int idx = tid; idx < m * n; idx += NT) {
+                int i, j; tape_divmod(idx, n, rn, i, j);
+                double s = part_sum(i, j, 0, 1);
                 if (flags & 8) s = -s;
                 dst[idx] = (flags & 4) ? dst[idx] + s : s;
             }

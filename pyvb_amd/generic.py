@@ -828,9 +828,10 @@ class GenericPlan(object):
         """K sums at once: inits[k] + the terms item(0)[k], item(1)[k], ... (lists of Refs shaped like inits[k], or (factor, Ref)
         pairs, the factor a python float or a 1 x 1 Ref; inits[k] may be None: the sum then starts with the first term), added in
         that order.  From PAR_MIN items on, each item is emitted as a block of its own and its terms land in rows of one matrix
-        per sum, which a single product with a row of ones adds up after a barrier -- in the same order, so the result is the
-        chain of additions (to the last bit when the factors are exact; an arena factor is applied with its own rounding here
-        and inside the addition there) -- and the items (the messages of a node's children) are issued side by side (_program)."""
+        per sum, which a single product with a row of ones adds up after a barrier -- the interpreter adds a short sum in that
+        order and splits a long one (64 terms and more into few elements) over neighbouring lanes with a fixed tree of partial
+        sums: deterministic, equal to the chain of additions up to rounding -- and the items (the messages of a node's children)
+        are issued side by side (_program)."""
         K = len(inits)
         if count < self.PAR_MIN:
             accs = [None if a is None else t.copy(a) for a in inits]
