@@ -311,9 +311,13 @@ __global__ void __launch_bounds__(TAPE_THREADS) k_tape_blocks(TapeArgs t, const 
 // record of such a graph costs 300-700 ns whatever it does (profiles/tape_record_cost.py: a chain of LDS round trips and taken
 // branches, about 70 instructions); independent records -- the messages of different children, the next node's messages
 // while this node's covariance is inverted -- now overlap on the four SIMDs.
-__global__ void __launch_bounds__(TAPE_CTHREADS) k_tape_cached(TapeArgs t, const int* bmeta, const int* meta, const int* segs) {
+// BW: wavefronts of the workgroup = records of a bundle.  A launch of a few long blocks takes 8 (the LDS example's chain of 400 node
+// updates), a launch of many short ones 4: such blocks rarely have eight independent records, and workgroups half as wide fit a CU twice
+// as often (2000 blocks of a node update each: 170 -> about 120 us).
+template <int BW>
+__global__ void __launch_bounds__(64 * BW) k_tape_cached(TapeArgs t, const int* bmeta, const int* meta, const int* segs) {
     extern __shared__ double win[];
-    constexpr int NT = TAPE_CTHREADS;
+    constexpr int NT = 64 * BW;
     __shared__ double red[NT];
     const int tid = threadIdx.x;
     const int w0 = bmeta[2 * blockIdx.x], nwin = bmeta[2 * blockIdx.x + 1];
@@ -343,7 +347,7 @@ __global__ void __launch_bounds__(TAPE_CTHREADS) k_tape_cached(TapeArgs t, const
             for (int idx = tid; idx < 8 * nc; idx += NT) staged[idx] = src[idx];
             __syncthreads();
             if (bundled) {
-                for (int b0 = 0; b0 < nc; b0 += TAPE_BUNDLE) {          // TAPE_CHUNK is a multiple of TAPE_BUNDLE: a bundle never straddles two chunks
+                for (int b0 = 0; b0 < nc; b0 += BW) {          // TAPE_CHUNK is a multiple of BW: a bundle never straddles two chunks
                     tape_exec<true, 64>(t, staged + 8 * (b0 + (tid >> 6)), 1, red, (lds_double*)win, tid & 63);
                     __syncthreads();
                 }
@@ -381,6 +385,7 @@ struct pyvb_graph {
     std::vector<std::vector<int>> host_ops;
     std::vector<int*> c_ops, c_meta, c_segs;
     std::vector<std::vector<size_t>> c_lds;
+    std::vector<std::vector<int>> c_bw;              // per tape and launch: bundle width (wavefronts per workgroup)
     std::vector<int> c_nblocks;                      // per tape: blocks in the window form (c_meta = block table [nb][2], then the window table)
 };
 
@@ -510,6 +515,7 @@ static void tape_cache_free(pyvb_graph* g, int id) {
     if (g->c_meta[id]) { (void)hipFree(g->c_meta[id]); g->c_meta[id] = nullptr; }
     if (g->c_segs[id]) { (void)hipFree(g->c_segs[id]); g->c_segs[id] = nullptr; }
     g->c_lds[id].clear();
+    g->c_bw[id].clear();
 }
 
 // Build the window form of tape `id` for the given blocks ([first, count] each) and launches ([first block, number]).
@@ -539,7 +545,7 @@ static bool tape_segments(const std::vector<int>& ops, int first, int count, std
 // only read it; it goes into the first bundle after all of its dependencies that has a free slot (list scheduling: any order that
 // respects the dependencies computes what the tape computes).  Extents are taken from the unresolved records `raw`.
 #define TAPE_BUNDLE_MAX 2048        // records scheduled together (the dependency search is quadratic)
-static void tape_bundle(const std::vector<int>& raw, const std::vector<int>& ops, int first, int count, std::vector<int>& out) {
+static void tape_bundle(const std::vector<int>& raw, const std::vector<int>& ops, int first, int count, std::vector<int>& out, int BW) {
     std::vector<std::vector<TapeExtent>> ext((size_t)count);
     for (int r = 0; r < count; ++r) tape_extents(&raw[8 * (size_t)(first + r)], ext[r]);
     std::vector<int> bundle((size_t)count, 0), fill;
@@ -556,15 +562,15 @@ static void tape_bundle(const std::vector<int>& raw, const std::vector<int>& ops
             if (hazard) earliest = bundle[q] + 1;
         }
         int b = earliest;
-        while (b < (int)fill.size() && fill[b] >= TAPE_BUNDLE) ++b;
+        while (b < (int)fill.size() && fill[b] >= BW) ++b;
         if (b >= (int)fill.size()) fill.resize((size_t)b + 1, 0);
         bundle[r] = b; ++fill[b];
     }
     const size_t base = out.size();
-    out.resize(base + fill.size() * 8 * TAPE_BUNDLE, 0);                 // T_NOP == 0
+    out.resize(base + fill.size() * 8 * BW, 0);                 // T_NOP == 0
     std::vector<int> slot(fill.size(), 0);
     for (int r = 0; r < count; ++r) {
-        int* dst = &out[base + ((size_t)bundle[r] * TAPE_BUNDLE + slot[bundle[r]]++) * 8];
+        int* dst = &out[base + ((size_t)bundle[r] * BW + slot[bundle[r]]++) * 8];
         for (int k = 0; k < 8; ++k) dst[k] = ops[8 * (size_t)(first + r) + k];
     }
 }
@@ -580,6 +586,12 @@ static int tape_cache_build(pyvb_graph* g, int id, const std::vector<int>& block
     std::vector<TapeSeg> sg, best;
     std::vector<TapeExtent> ext;
     bool any = false;
+    std::vector<int> bw((size_t)nb, TAPE_BUNDLE), lbw;          // bundle width per block: that of its launch
+    for (size_t l = 0; l + 1 < launches.size(); l += 2) {
+        const int w = launches[l + 1] >= 512 ? 4 : TAPE_BUNDLE;
+        lbw.push_back(w);
+        for (int b = launches[l]; b < launches[l] + launches[l + 1]; ++b) bw[b] = w;
+    }
     for (int b = 0; b < nb; ++b) {
         const int first = blocks[2 * b], count = blocks[2 * b + 1];
         bmeta[2 * b] = (int)meta.size() / 8;
@@ -643,7 +655,7 @@ static int tape_cache_build(pyvb_graph* g, int id, const std::vector<int>& block
             const int at = (int)(cops.size() / 8);
             const bool bundled = widest <= 64;
             if (bundled) {                  // a long window is scheduled piece by piece (the search is quadratic in the piece)
-                for (int p0 = 0; p0 < len; p0 += TAPE_BUNDLE_MAX) tape_bundle(raw, ops, r + p0, std::min(TAPE_BUNDLE_MAX, len - p0), cops);
+                for (int p0 = 0; p0 < len; p0 += TAPE_BUNDLE_MAX) tape_bundle(raw, ops, r + p0, std::min(TAPE_BUNDLE_MAX, len - p0), cops, bw[b]);
             }
             else cops.insert(cops.end(), ops.begin() + 8 * (size_t)r, ops.begin() + 8 * (size_t)(r + len));
             meta[mw] = at; meta[mw + 1] = (int)(cops.size() / 8) - at; meta[mw + 2] = (int)segs.size() / 4; meta[mw + 3] = (int)best.size();
@@ -659,7 +671,7 @@ static int tape_cache_build(pyvb_graph* g, int id, const std::vector<int>& block
         int nwin = (int)meta.size() / 8, nb_ = 0, nlds = 0; long recs = 0, slots = 0, wdoubles = 0;
         for (int w = 0; w < nwin; ++w) { if (meta[8 * w + 5]) { ++nb_; slots += meta[8 * w + 1]; } if (meta[8 * w + 3]) { ++nlds; wdoubles += meta[8 * w + 4]; } recs += meta[8 * w + 1]; }
         fprintf(stderr, "tape %d: %zu records in %d blocks -> %d windows (%d in LDS, %ld doubles; %d bundled: %ld slots = %ld bundles), %ld device records\n",
-                id, raw.size() / 8, nb, nwin, nlds, wdoubles, nb_, slots, slots / TAPE_BUNDLE, recs);
+                id, raw.size() / 8, nb, nwin, nlds, wdoubles, nb_, slots, slots / (lbw.empty() ? TAPE_BUNDLE : lbw[0]), recs);
     }
     if (!any) return PYVB_OK;
     if (segs.empty()) segs.assign(4, 0);
@@ -675,6 +687,7 @@ static int tape_cache_build(pyvb_graph* g, int id, const std::vector<int>& block
         size_t need = 0;
         for (int b = launches[l]; b < launches[l] + launches[l + 1]; ++b) need = std::max(need, block_lds[b]);
         g->c_lds[id].push_back((need + 2 + (size_t)TAPE_CHUNK * 4) * sizeof(double));
+        g->c_bw[id].push_back(lbw[l / 2]);
     }
     return PYVB_OK;
 }
@@ -697,7 +710,7 @@ int pyvb_graph_tape_create(pyvb_graph* g, const int* ops, int nops, int* tape_id
     g->tapes.push_back(d); g->tape_len.push_back(nops);
     g->prog_blocks.push_back(nullptr); g->prog_launches.emplace_back();
     g->host_ops.emplace_back(ops, ops + (size_t)nops * 8);
-    g->c_ops.push_back(nullptr); g->c_meta.push_back(nullptr); g->c_segs.push_back(nullptr); g->c_lds.emplace_back(); g->c_nblocks.push_back(0);
+    g->c_ops.push_back(nullptr); g->c_meta.push_back(nullptr); g->c_segs.push_back(nullptr); g->c_lds.emplace_back(); g->c_bw.emplace_back(); g->c_nblocks.push_back(0);
     *tape_id = (int)g->tapes.size() - 1;
     return tape_cache_build(g, *tape_id, std::vector<int>{0, nops}, std::vector<int>{0, 1});     // one block, one launch
 }
@@ -741,15 +754,21 @@ int pyvb_graph_tape_run(pyvb_graph* g, int tape_id) {
         static bool attr_set = false;
         if (!attr_set) {
             const int cap = (int)((TAPE_LDS_CAP + 2 + TAPE_CHUNK * 4) * sizeof(double));
-            HIPCHK(hipFuncSetAttribute((const void*)k_tape_cached, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+            HIPCHK(hipFuncSetAttribute((const void*)k_tape_cached<TAPE_BUNDLE>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+            HIPCHK(hipFuncSetAttribute((const void*)k_tape_cached<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
             attr_set = true;
         }
         t.ops = g->c_ops[tape_id];
         static const std::vector<int> single{0, 1};
         const std::vector<int>& L = g->prog_blocks[tape_id] ? g->prog_launches[tape_id] : single;
-        for (size_t l = 0; l + 1 < L.size(); l += 2)
-            hipLaunchKernelGGL(k_tape_cached, dim3(L[l + 1]), dim3(TAPE_CTHREADS), g->c_lds[tape_id][l / 2], g->stream, t,
-                               g->c_meta[tape_id] + 2 * L[l], g->c_meta[tape_id] + 2 * g->c_nblocks[tape_id], g->c_segs[tape_id]);
+        for (size_t l = 0; l + 1 < L.size(); l += 2) {
+            const int* bm = g->c_meta[tape_id] + 2 * L[l];
+            const int* wm = g->c_meta[tape_id] + 2 * g->c_nblocks[tape_id];
+            if (g->c_bw[tape_id][l / 2] == 4)
+                hipLaunchKernelGGL(k_tape_cached<4>, dim3(L[l + 1]), dim3(256), g->c_lds[tape_id][l / 2], g->stream, t, bm, wm, g->c_segs[tape_id]);
+            else
+                hipLaunchKernelGGL(k_tape_cached<TAPE_BUNDLE>, dim3(L[l + 1]), dim3(TAPE_CTHREADS), g->c_lds[tape_id][l / 2], g->stream, t, bm, wm, g->c_segs[tape_id]);
+        }
     } else if (g->prog_blocks[tape_id]) {
         const std::vector<int>& L = g->prog_launches[tape_id];
         for (size_t l = 0; l + 1 < L.size(); l += 2)
