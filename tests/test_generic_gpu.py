@@ -598,3 +598,43 @@ def test_cached_tapes_survive_a_growing_arena(monkeypatch):
         x.observe(np.array(x0.qmu))
     mu2.update(); _ = np.array(mu2.qmu); prec2.update(); _ = np.array(prec2.qb); mu2.update()
     assert np.allclose(again, np.array(mu2.qmu), rtol=1e-13, atol=0)
+
+
+def test_launches_of_many_short_blocks_take_narrow_workgroups(monkeypatch):
+    """A queued run whose launches have 512 blocks and more is interpreted by workgroups of four wavefronts with bundles of four
+    records (k_tape_cached<4>), the others by eight (k_tape.hip): the loop over 600 latent nodes and their 600 outputs issued at
+    once must leave what the same updates issued one node at a time leave (each of those is a one-block tape of its own)."""
+    from pyvb_amd import generic, _recognise, nodes
+    monkeypatch.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+    N, d, q = 600, 6, 2
+
+    def build():
+        np.random.seed(11)
+        rng = np.random.default_rng(3)
+        X = rng.standard_normal((N, q)) @ rng.standard_normal((q, d)) + 0.1 * rng.standard_normal((N, d))
+        X[rng.random((N, d)) < 0.1] = np.nan
+        Ws = [nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3) for _ in range(q)]
+        W = nodes.hstack(Ws)
+        Mu = nodes.Gaussian(d, np.zeros((d, 1)), np.eye(d) * 1e-3)
+        Beta = nodes.Gamma(d, 1e-3, 1e-3)
+        Zs = [nodes.Gaussian(q, np.zeros((q, 1)), np.eye(q)) for _ in range(N)]
+        Xs = [nodes.Gaussian(d, W * z + Mu, Beta) for z in Zs]
+        for x, row in zip(Xs, X):
+            x.observe(row.reshape(d, 1))
+        return Ws, Mu, Beta, Zs, Xs
+
+    Ws, Mu, Beta, Zs, Xs = build()
+    for _ in range(2):                          # queued: the Z and X loops are launches of 600 blocks
+        [w.update() for w in Ws]; [z.update() for z in Zs]; [x.update() for x in Xs]; Mu.update(); Beta.update()
+        _ = np.array(Mu.qmu)
+    plan = nodes._plan_of(Mu)
+    progs = [p for p in plan._programs.values() if p is not None]
+    assert progs and max(int(l[1]) for p in progs for l in p[1]) >= 512
+    Ws2, Mu2, Beta2, Zs2, Xs2 = build()
+    for _ in range(2):                          # one node at a time: a read after every update
+        for n in Ws2 + Zs2 + Xs2 + [Mu2, Beta2]:
+            n.update()
+            _ = np.array(n.qb if isinstance(n, nodes.Gamma) else n.qmu)
+    for a, b in zip(Ws + Zs + Xs + [Mu], Ws2 + Zs2 + Xs2 + [Mu2]):
+        assert np.allclose(np.array(a.qmu), np.array(b.qmu), rtol=1e-11, atol=1e-13)
+    assert np.allclose(np.array(Beta.qb), np.array(Beta2.qb), rtol=1e-11)
