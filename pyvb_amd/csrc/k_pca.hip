@@ -298,9 +298,10 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     constexpr int PF = 2 * RT;                  // register sets of X tiles: the tiles of this step and of the next
     const int nw = blockDim.x >> 6;
     double* zp = lds12;                                 // [RT][nw][QT][4][64] accumulator dumps of the partial products
-    double* zf = zp + (size_t)RT * nw * QT * 256;       // [RT][QT][4][64] Z of the step's rows, accumulator layout
-    double* zT = zf + RT * QT * 256;                    // [RT][QP][17] the same, latent index major (the operand of the prediction)
-    double* xt = zT + RT * QT * 16 * 17 + (size_t)(threadIdx.x >> 6) * RT * 16 * P12_XS;      // [RT][16][P12_XS] per wavefront
+    constexpr int ZBUF = RT * QT * 256, ZTBUF = RT * QT * 16 * 17;
+    double* zf = zp + (size_t)RT * nw * QT * 256;       // 2 x [RT][QT][4][64] Z of a step's rows, accumulator layout
+    double* zT = zf + 2 * ZBUF;                         // 2 x [RT][QP][17] the same, latent index major (the operand of the prediction)
+    double* xt = zT + 2 * ZTBUF + (size_t)(threadIdx.x >> 6) * RT * 16 * P12_XS;      // [RT][16][P12_XS] per wavefront
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, qk = lane >> 4;
     const int DP = a.DP, QP = a.QP, d = a.d, q = a.q, DS = DP / 4;
     constexpr int QS = 4 * QT;
@@ -366,7 +367,10 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     // q = 16): stage 1 560, stage 2 790 (four of the eight wavefronts), stage 3 1900-2300, stage 4 1100-1500 cycles, against 3 x 1024
     // for the 48 MFMAs the two wavefronts of a SIMD issue: the sweep runs at the pace of its dependent chains (MFMA -> select -> LDS
     // -> MFMA), not of HBM; the write-back of the imputed entries (34 % of the 32-byte sectors) costs 0.22 of the 0.94 ms.
-    auto step = [&](unsigned nbase, auto U0) {
+    // Software pipeline over the steps: stage 1 of step n + 1, a barrier, then stage 2 of step n + 1 (wavefronts 0..3) next to stages 3
+    // and 4 of step n (all wavefronts), a barrier.  Z of a step lives in one of two LDS buffers (zsel).  (Stage 2 in a barrier interval
+    // of its own, with half of the wavefronts idle, was a sixth of a step.)
+    auto s1 = [&](unsigned nbase, auto U0) {
         constexpr int u0 = decltype(U0)::value;
         // ---- 1. this wavefront's part of Z
 #pragma unroll
@@ -383,7 +387,10 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
                 for (int r = 0; r < 4; ++r) zp[((size_t)((rt * nw + wave) * QT + t) * 4 + r) * 64 + lane] = zacc[t][r];
             }
         }
-        lds_barrier();
+    };
+    auto s2 = [&](unsigned nbase, int zsel) {
+        double* const zfw = zf + zsel * ZBUF;
+        double* const zTw = zT + zsel * ZTBUF;
         // ---- 2. sum of the parts: thread = (rt, t, r, lane) element of the accumulator layout
         for (int el = tid; el < RT * QT * 256; el += blockDim.x) {
             const int rt = el / (QT * 256), e2 = el % (QT * 256);
@@ -399,10 +406,14 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
                 if (z0_here && row == 0) s = Zc[16 * t + cc];
                 else Zc[(size_t)row * QP + 16 * t + cc] = s;
             }
-            zf[el] = row < nrows ? s : 0.0;
-            zT[(size_t)rt * QT * 16 * 17 + (16 * t + cc) * 17 + 4 * r + qq] = s;
+            zfw[el] = row < nrows ? s : 0.0;
+            zTw[(size_t)rt * QT * 16 * 17 + (16 * t + cc) * 17 + 4 * r + qq] = s;
         }
-        lds_barrier();
+    };
+    auto back = [&](unsigned nbase, auto U0, int zsel) {
+        constexpr int u0 = decltype(U0)::value;
+        const double* const zfr = zf + zsel * ZBUF;
+        const double* const zTr = zT + zsel * ZTBUF;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const unsigned n0 = nbase + 16 * rt;
@@ -410,7 +421,7 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
             unsigned (&ma)[2] = mq[u0 + rt];
             double za[QS];
 #pragma unroll
-            for (int s = 0; s < QS; ++s) za[s] = zT[(size_t)rt * QT * 16 * 17 + (4 * s + qk) * 17 + c];
+            for (int s = 0; s < QS; ++s) za[s] = zTr[(size_t)rt * QT * 16 * 17 + (4 * s + qk) * 17 + c];
             // ---- 3. prediction, imputation, write-back (all tiles of the step, then stage 4 for all of them: the chains of
             // different tiles are independent and fill each other's waits)
             const unsigned rowl = n0 + c;
@@ -450,7 +461,7 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int t = 0; t < QT; ++t) zb[s][t] = zf[(size_t)(rt * QT + t) * 256 + s * 64 + lane];
+                for (int t = 0; t < QT; ++t) zb[s][t] = zfr[(size_t)(rt * QT + t) * 256 + s * 64 + lane];
             // ---- 4. statistics on the transposed tile: element r of tile p = row n0 + 4 r + qk, column col0 + p
             d4 xn[P2T];
 #pragma unroll
@@ -483,9 +494,34 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
             fetch(nn < nrows ? nn : n0, xa, ma);
         }
     };
+    // prologue: Z of the first step
+    s1(0u, std::integral_constant<int, 0>{});
+    lds_barrier();
+    s2(0u, 0);
+    lds_barrier();
+    int zsel = 0;
     for (unsigned base = 0; base < nrows; base += 16 * PF) {
-        step(base, std::integral_constant<int, 0>{});
-        if (base + 16 * RT < nrows) step(base + 16 * RT, std::integral_constant<int, RT>{});
+        {   // step at base (register sets 0..RT-1); the next one, if any, at base + 16 RT (sets RT..)
+            const bool more = base + 16 * RT < nrows;
+            if (more) s1(base + 16 * RT, std::integral_constant<int, RT>{});
+            lds_barrier();
+            if (more) s2(base + 16 * RT, zsel ^ 1);
+            back(base, std::integral_constant<int, 0>{}, zsel);
+            lds_barrier();
+            zsel ^= 1;
+            if (!more) break;
+        }
+        {
+            const unsigned b2 = base + 16 * RT;
+            const bool more = b2 + 16 * RT < nrows;
+            if (more) s1(b2 + 16 * RT, std::integral_constant<int, 0>{});
+            lds_barrier();
+            if (more) s2(b2 + 16 * RT, zsel ^ 1);
+            back(b2, std::integral_constant<int, RT>{}, zsel);
+            lds_barrier();
+            zsel ^= 1;
+            if (!more) break;
+        }
     }
     // ---- partial sums of this chunk, laid out as k_pca_pass2's
     double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
@@ -947,7 +983,7 @@ int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
     a.keep_z0 = h->z0_done ? 1 : 0;
     const unsigned nw = (h->DT + P2T - 1) / P2T;          // wavefronts per workgroup: 32 columns each
     const size_t rt = h->QT == 1 ? 2 : 1;                 // k_pca_pass12: RT
-    const size_t lds = rt * ((size_t)nw * h->QT * 256 + (size_t)h->QT * 256 + (size_t)h->QT * 16 * 17 + (size_t)nw * 16 * P12_XS) * sizeof(double);
+    const size_t lds = rt * ((size_t)nw * h->QT * 256 + 2 * (size_t)h->QT * 256 + 2 * (size_t)h->QT * 16 * 17 + (size_t)nw * 16 * P12_XS) * sizeof(double);
     const dim3 grid(h->nchunk), block(64 * nw);
     const bool pin = h->Xdata != nullptr;
     if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass12<1, true>), grid, block, lds, h->stream, a); else hipLaunchKernelGGL((k_pca_pass12<1, false>), grid, block, lds, h->stream, a); }
