@@ -11,46 +11,182 @@ the reference's examples/Linear_Dynamic_System.py:46-66 --
 node of the graph is pointed at the plan.  Anything else raises NotImplementedError (there is no
 CPU execution path).
 """
+import hashlib
+import weakref
+
 import numpy as np
 
 from . import nodes as N
 
 
-class LDSPlan(object):
-    resume_left = 3         # how often a graph handed to the generic plan may still come back (GenericPlan._resume_fused)
+# Requests as the queue holds them: what update() records -- ("x", t), ("y", t), ("a", i), ("c", i), ("q", 0), ("r", 0) --
+# and what those spell for the whole batch, which Network.learn replays directly from its second iteration on:
+# ("F",) forward sweep, ("B",) backward sweep, ("Y",) the outputs that are not observed, ("A", lo, hi) / ("C", lo, hi)
+# columns lo..hi-1 in order, ("Q",), ("R",).
+_BATCH_OPS = ("F", "B", "Y", "A", "C", "Q", "R")
 
-    def __init__(self, Xs, Ys, As, Cs, A, C, Q, R, pri):
+_pool = {}          # signature -> weak references to LDSPlans that are bound but not yet on the device, in binding order
+
+
+class LDSGroup(object):
+    """ONE LDSBatch for M graphs of the same structure: replicate r is the graph of members[r].
+
+    The reference iterates any node list (network.py:46-49), so a user with M independent LDS graphs writes M graphs and
+    one loop.  The kernels' parallel axis is the replicate axis of pyvb_amd.lds.LDSBatch; graphs that agree in everything
+    a handle shares between its replicates -- T, D, K, the noise family, the Constant parents (priors), the known entries of
+    A / C, which outputs are unobserved -- therefore share one handle.  The queued update() requests of the members are
+    carried out in lock step: while every live member asks for the same thing (a forward sweep, the columns 0..D-1 of A ...)
+    it is one launch for all of them.  A member whose queue says something else than the majority's leaves the group
+    with its state (its replicate stays behind as a dead row that nobody reads) and is bound anew -- on its own, with
+    others that left the same way, or, for a request no fused kernel serves, node by node."""
+
+    def __init__(self, members):
         from .lds import LDSBatch
+        p0 = members[0]
+        self.members = list(members)
+        self.T, self.D, self.K, self.kind = p0.T, p0.D, p0.K, p0.kind
+        M, T, D, K = len(members), self.T, self.D, self.K
+        self.batch = b = LDSBatch(M, T, D, K, self.kind)
+        b.set_priors(p0.pri)
+        host = [m._host_state() for m in members]
+        stack = lambda key: np.stack([h[key] for h in host])
+        b.set_observations(stack("Y"))
+        if p0.free_ys:
+            b.set_output_state(stack("Yq"), stack("Yv"))
+        state = {k: stack(k) for k in ("X", "A_mean", "A_colvar", "C_mean", "C_colvar")}
+        if self.kind == "wishart":
+            b.set_state(**state)
+            b.set_wishart_state(stack("Q_w"), stack("R_w"))
+        else:
+            b.set_state(Q_b=stack("Q_b"), R_b=stack("R_b"), **state)
+        if p0.pri.get("A_obs") is not None:
+            b.set_column_observations(p0.pri["A_obs"], p0.pri["C_obs"])
+        # members that come from another handle bring the covariances their states were last updated with
+        self.x_updated = p0.classes is not None
+        if self.x_updated:
+            b.set_posterior_classes(np.stack([m.classes[0] for m in members]), np.stack([m.classes[1] for m in members]))
+        self.ran = False                # anything at all has run on the device (the outputs can update before any sweep)
+        self.cache = None
+        self._elbo = None
+        self.epoch = 0                  # counts the members that have left (Network.learn's schedule looks at it)
+        for r, m in enumerate(members):
+            m.group, m.r = self, r
+
+    def live(self):
+        return [m for m in self.members if m is not None]
+
+    def invalidate(self):
+        self.cache = None
+        self._elbo = None
+
+    def drop(self, member):
+        """`member` has left (its replicate keeps being computed with the others; nobody reads it)."""
+        self.members[member.r] = None
+        member.group = None
+        self.epoch += 1
+        if not any(m is not None for m in self.members):
+            self.batch.close()
+
+    # -- the queue -------------------------------------------------------------------------------
+    def execute(self, op):
+        b = self.batch
+        k = op[0]
+        if k == "F":
+            b.sweep("forward"); self.x_updated = True
+        elif k == "B":
+            b.sweep("backward"); self.x_updated = True
+        elif k == "Y":
+            b.update_Y()
+        elif k in ("A", "C"):
+            b.update_columns(k, op[1], op[2])
+        elif k == "Q":
+            b.update_Q()
+        else:
+            b.update_R()
+        self.ran = True
+        self.invalidate()
+
+    def flush(self):
+        """Carry out the members' queued requests (see the class comment)."""
+        try:
+            while True:
+                heads, idle = {}, []
+                for m in self.members:
+                    if m is None:
+                        continue
+                    op, n = m._peek()
+                    if n == 0:
+                        idle.append(m)
+                    else:
+                        heads.setdefault(op, []).append((m, n))
+                if not heads:
+                    return
+                best, best_n = None, len(idle)      # best None: the members without requests are the majority, the others leave
+                for op, lst in heads.items():
+                    if op is not None and (len(lst) > best_n or (len(lst) == best_n and best is None)):
+                        best, best_n = op, len(lst)
+                for op, lst in heads.items():
+                    if op != best or op is None:
+                        for m, _ in lst:
+                            m._depart(fused=op is not None)
+                if best is None:
+                    return
+                for m in idle:
+                    m._leave()
+                self.execute(best)
+                for m, n in heads[best]:
+                    m._pos += n
+        finally:
+            for m in self.members:
+                if m is not None and m._pos:
+                    del m.pending[:m._pos]
+                    m._pos = 0
+
+    def run_script(self, script):
+        """The same batch operations for every live member at once (Network.learn from its second iteration on); the caller
+        has checked that no member has anything queued."""
+        for op in script:
+            if op[0] in ("A", "C", "Q", "R") and not self.x_updated:
+                return False
+        for op in script:
+            self.execute(op)
+        return True
+
+    # -- results ---------------------------------------------------------------------------------
+    def pull(self):
+        if self.cache is None:
+            b = self.batch
+            st = b.get_state()
+            Sig, qld = b.get_posterior_classes()
+            qa, qc = b.get_column_qld()
+            c = {"st": st, "Sigma": Sig, "qld_x": qld, "qld_A": qa, "qld_C": qc}
+            if self.kind == "wishart":
+                c["w"] = b.get_wishart_state()
+                c["A_cov"], c["C_cov"] = b.get_column_cov()
+            if self.members and any(m is not None and m.free_ys for m in self.members):
+                c["Yq"], c["Yvar"], c["Yqld"] = b.get_outputs(with_qld=True)
+            self.cache = c
+        return self.cache
+
+    def elbo(self):
+        if self._elbo is None:
+            self._elbo = self.batch.elbo()
+        return self._elbo
+
+
+class LDSPlan(object):
+    """One LDS graph on the fused kernels: replicate `r` of its group's handle (LDSGroup)."""
+    resume_left = 3         # how often a graph handed to the generic plan may still come back (GenericPlan._resume_fused)
+    _count = 0
+
+    def __init__(self, Xs, Ys, As, Cs, A, C, Q, R, pri, classes=None):
         self.Xs, self.Ys, self.As, self.Cs, self.A, self.C, self.Q, self.R = Xs, Ys, As, Cs, A, C, Q, R
         self.T, self.D, self.K = len(Xs), As[0].shape[0], Cs[0].shape[0]
-        T, D, K = self.T, self.D, self.K
+        T = self.T
+        self.pri = pri
         self.kind = pri["noise"]
-        self.batch = LDSBatch(1, T, D, K, self.kind)
-        self.batch.set_priors(pri)
+        self.classes = classes          # (Sigma[3,D,D], q_ln_det[3]) of the states' last update on another handle, or None
         self.free_ys = [t for t, y in enumerate(Ys) if not y.observed]      # outputs with missing entries: nodes of their own
-        Yarr = np.hstack([y.__dict__["_h_qmu"] if y.observed else
-                          (y.obs_value if y.partially_observed else np.full((K, 1), np.nan)) for y in Ys]).T.reshape(1, T, K)
-        self.batch.set_observations(Yarr)
-        if self.free_ys:
-            Yq = np.hstack([y.__dict__["_h_qmu"] for y in Ys]).T.reshape(1, T, K)
-            Yv = np.array([y.__dict__["_h_qcov"][0, 0] for y in Ys]).reshape(1, T)
-            self.batch.set_output_state(Yq, Yv)
-        diag = lambda nodes_: np.stack([np.diag(n.__dict__["_h_qcov"]) for n in nodes_])
-        qb = lambda nd, dim: np.broadcast_to(np.asarray(nd.__dict__["_h_qb"], dtype=float), (dim,)).reshape(1, dim)
-        state = dict(
-            X=np.hstack([x.__dict__["_h_qmu"] for x in Xs]).T.reshape(1, T, D),
-            A_mean=np.hstack([a.__dict__["_h_qmu"] for a in As]).reshape(1, D, D),
-            A_colvar=diag(As).reshape(1, D, D),
-            C_mean=np.hstack([c.__dict__["_h_qmu"] for c in Cs]).reshape(1, K, D),
-            C_colvar=diag(Cs).reshape(1, D, K))
-        if self.kind == "wishart":
-            self.batch.set_state(**state)
-            self.batch.set_wishart_state(np.asarray(Q.__dict__["_h_qw"], dtype=float).reshape(1, D, D),
-                                         np.asarray(R.__dict__["_h_qw"], dtype=float).reshape(1, K, K))
-        else:
-            self.batch.set_state(Q_b=qb(Q, D), R_b=qb(R, K), **state)
-        if pri.get("A_obs") is not None:
-            self.batch.set_column_observations(pri["A_obs"], pri["C_obs"])
         self.index = {}
         for t, x in enumerate(Xs):
             self.index[id(x)] = ("x", t)
@@ -62,62 +198,179 @@ class LDSPlan(object):
             self.index[id(c)] = ("c", i)
         self.index[id(Q)] = ("q", 0)
         self.index[id(R)] = ("r", 0)
-        self.pending = []
-        self.cache = None
+        self._fwd = [("x", t) for t in range(T)]
+        self._bwd = self._fwd[::-1]
+        self._ys = [("y", t) for t in self.free_ys]
+        self.pending, self._pos = [], 0
+        self.group, self.r = None, -1
         self.stale = False              # set when a node of the graph gains a child or an observation after binding
-        self.x_updated = False
-        self.ran = False                # anything at all has run on the device (the outputs can update before any sweep)
+        self.closed = False
         self.n_random_nodes = 2 * self.T + 2 * self.D + 2
+        self.sig = _signature(self)
+        LDSPlan._count += 1
+        self._serial = LDSPlan._count
+        waiting = [ref for ref in _pool.get(self.sig, []) if ref() is not None]
+        _pool[self.sig] = waiting + [weakref.ref(self)]
         for n in _component(Xs[0]):         # the operation nodes and Constants too: their messages go through mirror()
             n._plan = self
+
+    # -- the handle ------------------------------------------------------------------------------
+    def _host_state(self):
+        """The graph's posteriors as the nodes hold them on the host, in the C ABI's layout (one replicate)."""
+        Xs, Ys, As, Cs, Q, R = self.Xs, self.Ys, self.As, self.Cs, self.Q, self.R
+        T, D, K = self.T, self.D, self.K
+        h = {"Y": np.hstack([y.__dict__["_h_qmu"] if y.observed else
+                             (y.obs_value if y.partially_observed else np.full((K, 1), np.nan)) for y in Ys]).T.reshape(T, K)}
+        if self.free_ys:
+            h["Yq"] = np.hstack([y.__dict__["_h_qmu"] for y in Ys]).T.reshape(T, K)
+            h["Yv"] = np.array([y.__dict__["_h_qcov"][0, 0] for y in Ys]).reshape(T)
+        diag = lambda nodes_: np.stack([np.diag(n.__dict__["_h_qcov"]) for n in nodes_])
+        qb = lambda nd, dim: np.broadcast_to(np.asarray(nd.__dict__["_h_qb"], dtype=float), (dim,)).reshape(dim)
+        h.update(X=np.hstack([x.__dict__["_h_qmu"] for x in Xs]).T.reshape(T, D),
+                 A_mean=np.hstack([a.__dict__["_h_qmu"] for a in As]).reshape(D, D), A_colvar=diag(As).reshape(D, D),
+                 C_mean=np.hstack([c.__dict__["_h_qmu"] for c in Cs]).reshape(K, D), C_colvar=diag(Cs).reshape(D, K))
+        if self.kind == "wishart":
+            h["Q_w"] = np.asarray(Q.__dict__["_h_qw"], dtype=float).reshape(D, D)
+            h["R_w"] = np.asarray(R.__dict__["_h_qw"], dtype=float).reshape(K, K)
+        else:
+            h["Q_b"], h["R_b"] = qb(Q, D), qb(R, K)
+        return h
+
+    def _materialize(self):
+        """State to the device -- together with every other graph of the same signature that is bound, not yet on the device
+        and waiting with the same first request (graphs that would part ways at once are not put on one handle)."""
+        if self.group is not None:
+            return self.group
+        peers, later = [], []
+        want = self._peek()
+        for ref in _pool.pop(self.sig, []):
+            p = ref()
+            if p is None or p is self or p.group is not None or p.closed or p.stale or p.Xs[0]._plan is not p:
+                continue
+            (peers if want[1] and p._peek() == want else later).append(p)
+        if later:
+            _pool[self.sig] = [weakref.ref(p) for p in later]
+        # binding order (the pool's), this graph at its own place
+        peers.append(self)
+        peers.sort(key=lambda p: p._serial)
+        LDSGroup(peers)
+        return self.group
+
+    @property
+    def batch(self):
+        return self._materialize().batch
+
+    @property
+    def x_updated(self):
+        return self.group.x_updated if self.group is not None else self.classes is not None
+
+    @property
+    def ran(self):
+        return self.group is not None and self.group.ran
+
+    @property
+    def cache(self):
+        return self.group.cache if self.group is not None else None
 
     # -- queue -----------------------------------------------------------------------------------
     def enqueue(self, node):
         self.pending.append(self.index[id(node)])
 
+    def _peek(self, gate=True):
+        """(op, n): the head of the queue as one operation on the batch that takes n entries off it -- the fused kernels
+        serve whole sweeps, `[x.update() for x in Xs]` and its reverse, and, once the states have been swept, runs of column
+        updates and the noise updates.  (None, n > 0): a request they do not serve (a single X_t.update(); parameters
+        before the first sweep: the X_t then still have their individual initial covariances, gaussian.py:70-72) -- the
+        graph goes to the node-by-node plan.  (None, 0): nothing queued."""
+        ops, i = self.pending, self._pos
+        while i < len(ops) and ops[i][0] not in ("x", "y", "a", "c", "q", "r") + _BATCH_OPS:
+            i += 1                      # nothing to do for anything else (observed nodes never update, gaussian.py:109-110)
+        self._pos = i
+        if i >= len(ops):
+            return None, 0
+        head = ops[i]
+        kind = head[0]
+        op, n = None, 1
+        if kind in _BATCH_OPS:
+            op = head
+        elif kind == "x":
+            run = ops[i:i + self.T]
+            if run == self._fwd:
+                op, n = ("F",), self.T
+            elif run == self._bwd:
+                op, n = ("B",), self.T
+        elif kind == "y":               # [y.update() for y in Ys if not y.observed]: all of them, in order, or node by node
+            if ops[i:i + len(self._ys)] == self._ys:
+                op, n = ("Y",), len(self._ys)
+        elif kind in ("a", "c"):
+            j = i
+            while j + 1 < len(ops) and ops[j + 1] == (kind, ops[j][1] + 1):
+                j += 1
+            op, n = (kind.upper(), head[1], ops[j][1] + 1), j + 1 - i
+        else:
+            op = (kind.upper(),)
+        if gate and op is not None and op[0] in ("A", "C", "Q", "R") and not self.x_updated:
+            op = None
+        return op, n
+
+    def _spell(self, first):
+        """pending[first:] as batch operations (what Network.learn replays), None if some request there is not one the
+        fused kernels serve.  Nothing is taken off the queue."""
+        keep, out = self._pos, []
+        self._pos = first
+        try:
+            while True:
+                op, n = self._peek(gate=False)
+                if n == 0:
+                    return out
+                if op is None:
+                    return None
+                out.append(op)
+                self._pos += n
+        finally:
+            self._pos = keep
+
+    def _nodes_of(self, entry):
+        """The nodes whose update() a queue entry stands for, in order."""
+        k = entry[0]
+        if k == "F":
+            return list(self.Xs)
+        if k == "B":
+            return self.Xs[::-1]
+        if k == "Y":
+            return [self.Ys[t] for t in self.free_ys]
+        if k in ("A", "C"):
+            return (self.As if k == "A" else self.Cs)[entry[1]:entry[2]]
+        if k in ("Q", "R"):
+            return [self.Q if k == "Q" else self.R]
+        return [{"x": self.Xs, "y": self.Ys, "a": self.As, "c": self.Cs, "q": [self.Q], "r": [self.R]}[k][entry[1]]]
+
     def flush(self):
-        """Run the queued update() requests.  The fused kernels serve whole sweeps -- `[x.update() for x in Xs]`, its
-        reverse -- and, once the states have been swept, runs of column updates and the noise updates.  Any other
-        sequence (a single X_t.update(), parameters before the first sweep: the X_t then still have their individual
-        initial covariances, gaussian.py:70-72) is executed node by node instead: the graph moves to the generic plan."""
-        ops, self.pending = self.pending, []
-        if not ops:
+        """Run the queued update() requests (LDSGroup.flush: in lock step with the other graphs on this handle)."""
+        if self._pos >= len(self.pending):
             return
-        self.cache = None
-        b, T, D = self.batch, self.T, self.D
-        i = 0
-        while i < len(ops):
-            kind, idx = ops[i]
-            if kind == "x":
-                run = [o[1] for o in ops[i:i + T] if o[0] == "x"]
-                if len(run) == T and run == list(range(T)):
-                    b.sweep("forward"); i += T
-                elif len(run) == T and run == list(range(T - 1, -1, -1)):
-                    b.sweep("backward"); i += T
-                else:
-                    return self._demote(ops[i:])
-                self.x_updated = self.ran = True
-            elif kind == "y":           # [y.update() for y in Ys if not y.observed]: all of them, in order, or node by node
-                run = [o[1] for o in ops[i:i + len(self.free_ys)] if o[0] == "y"]
-                if run != self.free_ys:
-                    return self._demote(ops[i:])
-                b.update_Y(); i += len(run)
-                self.ran = True
-            elif kind in ("a", "c", "q", "r"):
-                if not self.x_updated:
-                    return self._demote(ops[i:])
-                if kind in ("a", "c"):
-                    j = i
-                    while j + 1 < len(ops) and ops[j + 1] == (kind, ops[j][1] + 1):
-                        j += 1
-                    b.update_columns("A" if kind == "a" else "C", idx, ops[j][1] + 1)
-                    i = j + 1
-                elif kind == "q":
-                    b.update_Q(); i += 1
-                else:
-                    b.update_R(); i += 1
+        self._materialize().flush()
+
+    def _rest(self):
+        rest, self.pending, self._pos = self.pending[self._pos:], [], 0
+        return rest
+
+    def _depart(self, fused):
+        """Leave the group with the queue: to a fused plan of its own (bound anew from the state as it is now, the
+        requests moved over) or, for a request the fused kernels do not serve, to the node-by-node plan."""
+        if not fused:
+            return self._demote(self._rest())
+        rest, left = self._rest(), self.resume_left
+        self._leave()
+        plan = bind(self.Xs[0])
+        plan.resume_left = left
+        for entry in rest:
+            if isinstance(plan, LDSPlan):
+                plan.pending.append(entry)
             else:
-                i += 1          # observed nodes never update (gaussian.py:109-110)
+                for nd in self._nodes_of(entry):
+                    nd._plan.enqueue(nd)
+        return plan
 
     def _sync_host(self):
         """Current device posteriors into the nodes' host attributes."""
@@ -138,50 +391,45 @@ class LDSPlan(object):
         else:
             self.Q.__dict__["_h_qb"], self.R.__dict__["_h_qb"] = self.read(self.Q, "qb"), self.read(self.R, "qb")
 
+    def _leave(self):
+        """Device state back into the nodes, the graph unbound, the replicate given up."""
+        self._sync_host()
+        for n in _component(self.Xs[0]):
+            if n._plan is self:
+                n._plan = None
+        self.closed = True
+        if self.group is not None:
+            self.group.drop(self)
+
     def release(self):
         """Device state back into the nodes and the graph unbound (it is bound anew, as it is now, at the next use)."""
         self.flush()
         if self.Xs[0]._plan is not self:
             return
-        self._sync_host()
-        for n in _component(self.Xs[0]):
-            if n._plan is self:
-                n._plan = None
-        self.batch.close()
+        self._leave()
 
     def _demote(self, rest):
         """Hand the graph to the generic node-by-node plan and replay the remaining update() requests there."""
         from .generic import GenericPlan
-        lookup = {v: k for k, v in self.index.items()}
-        by_id = {id(n): n for n in self.Xs + self.Ys + self.As + self.Cs + [self.Q, self.R]}
         self._sync_host()
-        comp = _component(self.Xs[0])
-        for n in comp:
+        for n in _component(self.Xs[0]):
             n._plan = None
-        self.batch.close()
+        self.closed = True
+        if self.group is not None:
+            self.group.drop(self)
         gp = GenericPlan(self.Xs[0])
         if self.resume_left > 0:        # back to the fused kernels when a forward and a backward sweep follow each other again
             gp.resume = {"pattern": self.Xs + self.Xs[::-1], "left": self.resume_left}
-        for key in rest:
-            node = by_id[lookup[key]]
-            if not getattr(node, "observed", False):
-                node._plan.enqueue(node)        # gp -- or the fused plan again, if these requests brought the graph back to it
+        for entry in rest:
+            for node in self._nodes_of(entry):
+                if not getattr(node, "observed", False):
+                    node._plan.enqueue(node)        # gp -- or the fused plan again, if these requests brought the graph back to it
         return gp
 
     # -- attribute traffic -----------------------------------------------------------------------
     def _pull(self):
         self.flush()
-        if self.cache is None:
-            st = self.batch.get_state()
-            Sig, qld = self.batch.get_posterior_classes()
-            qa, qc = self.batch.get_column_qld()
-            self.cache = {"st": st, "Sigma": Sig[0], "qld_x": qld[0], "qld_A": qa[0], "qld_C": qc[0]}
-            if self.kind == "wishart":
-                self.cache["w"] = self.batch.get_wishart_state()
-                self.cache["A_cov"], self.cache["C_cov"] = [v[0] for v in self.batch.get_column_cov()]
-            if self.free_ys:
-                self.cache["Yq"], self.cache["Yvar"], self.cache["Yqld"] = [v[0] for v in self.batch.get_outputs(with_qld=True)]
-        return self.cache
+        return self._materialize().pull()
 
     def read(self, node, name):
         kind, i = self.index[id(node)]
@@ -190,30 +438,32 @@ class LDSPlan(object):
         self.flush()
         if node._plan is not self:
             return node._plan.read(node, name)
+        if not self.ran:
+            return node.__dict__.get("_h_" + name)          # nothing has run on the device: the host attributes are the state
         if kind == "x" and name != "qmu" and not self.x_updated:
             return node.__dict__.get("_h_" + name)          # never updated: the constructor's draw (gaussian.py:70-72)
         c = self._pull()
-        st, T = c["st"], self.T
+        st, T, r = c["st"], self.T, self.r
         if kind == "y":
             if name == "q_ln_det":
-                return float(c["Yqld"][i]) if np.isfinite(c["Yqld"][i]) else node.__dict__.get("_h_q_ln_det")
-            return c["Yq"][i].reshape(-1, 1).copy() if name == "qmu" else np.diag(c["Yvar"][i])
+                return float(c["Yqld"][r, i]) if np.isfinite(c["Yqld"][r, i]) else node.__dict__.get("_h_q_ln_det")
+            return c["Yq"][r, i].reshape(-1, 1).copy() if name == "qmu" else np.diag(c["Yvar"][r, i])
         if kind == "x":
             cls = 0 if i == 0 else (2 if i == T - 1 else 1)
             if name == "qmu":
-                return st["X"][0, i].reshape(-1, 1).copy()
-            return c["Sigma"][cls].copy() if name == "qcov" else float(c["qld_x"][cls])
+                return st["X"][r, i].reshape(-1, 1).copy()
+            return c["Sigma"][r, cls].copy() if name == "qcov" else float(c["qld_x"][r, cls])
         if kind in ("a", "c"):
             M, V, q = ("A_mean", "A_colvar", "qld_A") if kind == "a" else ("C_mean", "C_colvar", "qld_C")
             if name == "qmu":
-                return st[M][0][:, [i]].copy()
+                return st[M][r][:, [i]].copy()
             if name == "qcov" and self.kind == "wishart":
-                return c["A_cov" if kind == "a" else "C_cov"][i].copy()
-            return np.diag(st[V][0, i]) if name == "qcov" else float(c[q][i])
+                return c["A_cov" if kind == "a" else "C_cov"][r, i].copy()
+            return np.diag(st[V][r, i]) if name == "qcov" else float(c[q][r, i])
         if name == "qw" and self.kind == "wishart":
-            return c["w"]["Q_w" if kind == "q" else "R_w"][0].copy()
+            return c["w"]["Q_w" if kind == "q" else "R_w"][r].copy()
         if name == "qb" and self.kind != "wishart":
-            v = st["Q_b" if kind == "q" else "R_b"][0]
+            v = st["Q_b" if kind == "q" else "R_b"][r]
             return float(v[0]) if self.kind == "gamma" else v.copy()
         raise AttributeError(name)
 
@@ -225,36 +475,41 @@ class LDSPlan(object):
             return node._plan.write(node, name, value)
         if name not in ("qmu", "qcov", "qb", "qw"):
             return True                         # q_ln_det, qprec: host-only bookkeeping
-        self.cache = None
         kind, i = self.index[id(node)]
         if not ((kind == "x" and name == "qmu") or kind in ("a", "c") or (kind in ("q", "r") and name in ("qb", "qw"))):
             return False
-        st = self.batch.get_state()
+        if self.group is None:                  # still on the host: the caller stores the value, the handle is made from it
+            return name != "qcov"               # (a covariance is something the recogniser has to look at again)
+        g, r, b = self.group, self.r, self.group.batch
+        g.invalidate()
+        st = b.get_state()
         if kind == "x" and name == "qmu":
-            st["X"][0, i] = np.asarray(value).reshape(-1)
-            self.batch.set_state(X=st["X"])
+            st["X"][r, i] = np.asarray(value).reshape(-1)
+            b.set_state(X=st["X"])
         elif kind in ("a", "c") and name in ("qmu", "qcov"):
             M, V = ("A_mean", "A_colvar") if kind == "a" else ("C_mean", "C_colvar")
             if name == "qmu":
-                st[M][0][:, i] = np.asarray(value).reshape(-1)
-                self.batch.set_state(**{M: st[M]})              # the mean alone: with Wishart noise the covariances are dense
+                st[M][r][:, i] = np.asarray(value).reshape(-1)
+                b.set_state(**{M: st[M]})                       # the mean alone: with Wishart noise the covariances are dense
             elif self.kind == "wishart":
-                covs = list(self.batch.get_column_cov())
-                covs[0 if kind == "a" else 1][0, i] = np.asarray(value, dtype=float)
-                self.batch.set_column_cov(**{"A_cov" if kind == "a" else "C_cov": covs[0 if kind == "a" else 1]})
+                covs = list(b.get_column_cov())
+                covs[0 if kind == "a" else 1][r, i] = np.asarray(value, dtype=float)
+                b.set_column_cov(**{"A_cov" if kind == "a" else "C_cov": covs[0 if kind == "a" else 1]})
             else:
                 cov = np.asarray(value, dtype=float)
                 if np.abs(cov - np.diag(np.diag(cov))).max() != 0.0:
                     return False                                # the fused kernels keep diagonal column covariances here
-                st[V][0, i] = np.diag(cov)
-                self.batch.set_state(**{V: st[V]})
+                st[V][r, i] = np.diag(cov)
+                b.set_state(**{V: st[V]})
         elif kind in ("q", "r") and name == "qw":
-            v = np.asarray(value, dtype=float).reshape((1,) + node.shape)
-            self.batch.set_wishart_state(**{"Q_w" if kind == "q" else "R_w": v})
+            w = b.get_wishart_state()
+            key = "Q_w" if kind == "q" else "R_w"
+            w[key][r] = np.asarray(value, dtype=float).reshape(node.shape)
+            b.set_wishart_state(**{key: w[key]})
         elif kind in ("q", "r") and name == "qb":
             key = "Q_b" if kind == "q" else "R_b"
-            st[key][0] = np.broadcast_to(np.asarray(value, dtype=float), st[key][0].shape)
-            self.batch.set_state(**{key: st[key]})
+            st[key][r] = np.broadcast_to(np.asarray(value, dtype=float), st[key][r].shape)
+            b.set_state(**{key: st[key]})
         return True
 
     # -- lower bound -----------------------------------------------------------------------------
@@ -262,14 +517,14 @@ class LDSPlan(object):
         self.flush()
         if self.Xs[0]._plan is not self:        # the queue held something only the generic plan executes
             raise NotImplementedError("the graph runs node by node now: use Network.learn or the nodes' log_lower_bound()")
-        return self.batch.elbo()[0]
+        return self._materialize().elbo()[self.r]
 
     def node_llb(self, node):
         self.flush()
         if node._plan is not self:
             return node._plan.node_llb(node)
         if not self.x_updated:                  # single terms before any sweep: only the generic plan knows the initial covariances
-            self._demote([])
+            self._demote(self._rest())
             return node._plan.node_llb(node)
         kind, _ = self.index[id(node)]
         if kind == "q":
@@ -293,6 +548,17 @@ class LDSPlan(object):
             self._mirror = GenericPlan(self.Xs[0], adopt=False)
             self._mirror_of = c
         return self._mirror
+
+
+def _signature(p):
+    """Everything the graphs on one handle have in common (include/pyvb_hip.h: the Constant parents, the known entries of
+    A / C and the set of unobserved outputs are per handle, not per replicate)."""
+    h = hashlib.sha1()
+    for k in sorted(p.pri):
+        v = p.pri[k]
+        h.update(k.encode())
+        h.update(v.encode() if isinstance(v, str) else b"-" if v is None else np.ascontiguousarray(np.asarray(v, dtype=float)).tobytes())
+    return (p.T, p.D, p.K, p.kind, tuple(p.free_ys), p.classes is not None, h.hexdigest())
 
 
 # -------------------------------------------------------------------------------------------------
@@ -428,7 +694,24 @@ def describe(start):
             _fail("initial column covariances must be diagonal")
     if any(c.observed or c.partially_observed for c in As + Cs):
         pri["A_obs"], pri["C_obs"] = known_entries(As, D), known_entries(Cs, K)
-    return dict(Xs=Xs, Ys=Ys, As=As, Cs=Cs, A=A, C=C, Q=Q, R=R, pri=pri)
+    return dict(Xs=Xs, Ys=Ys, As=As, Cs=Cs, A=A, C=C, Q=Q, R=R, pri=pri, classes=_state_classes(Xs))
+
+
+def _state_classes(Xs):
+    """(Sigma[3,D,D], q_ln_det[3]) if the states' covariances take the three values a sweep under frozen parameters leaves
+    -- X_0, the interior X_t, X_{T-1} -- as they do on a graph that comes from another handle (LDSPlan._sync_host) or from
+    complete sweeps on the node-by-node plan; None for the individual random covariances of the constructors
+    (gaussian.py:70-72), with which only a sweep can start (pyvb_lds_set_posterior_classes)."""
+    T = len(Xs)
+    cov = [x.__dict__["_h_qcov"] for x in Xs]
+    qld = [x.__dict__.get("_h_q_ln_det") for x in Xs]
+    if any(q is None for q in qld):
+        return None
+    mid = 1 if T > 2 else 0
+    for t in range(2, T - 1):
+        if qld[t] != qld[mid] or not np.array_equal(cov[t], cov[mid]):
+            return None
+    return (np.stack([cov[0], cov[mid], cov[T - 1]]).astype(float), np.array([qld[0], qld[mid], qld[T - 1]], dtype=float))
 
 
 def bind(node):

@@ -6,6 +6,113 @@ from . import nodes as N
 __all__ = ["Network"]
 
 
+def _bound(p, nodes):
+    """The nodes still sit on the plan they were grouped under (a plan covers one connected graph, so one node tells)."""
+    return nodes[0]._plan is p and not (getattr(p, "stale", False) or getattr(p, "released", False) or getattr(p, "closed", False))
+
+
+class _Schedule(object):
+    """One pass of Network.learn over a node list whose graphs are bound: groups = [[plan, nodes, whole], ...] in list
+    order (Network._groups).  Graphs on the fused LDS kernels that share a device handle (_recognise.LDSGroup) are served
+    per HANDLE once their first pass has shown what their update() calls spell for it: the cost of an iteration over M
+    graphs of one structure is then that of the handle's launches, not of M walks over node lists."""
+
+    def __init__(self, groups):
+        from ._recognise import LDSPlan
+        self.groups = groups
+        self.lds = [k for k, (p, _, _) in enumerate(groups) if isinstance(p, LDSPlan)]
+        self.other = [k for k, (p, _, _) in enumerate(groups) if not isinstance(p, LDSPlan)]
+        self.scripts = {}               # position in groups -> the batch operations its nodes' update() calls spell
+        self.handles = None             # after the first pass: [handle, positions, rows, script or None, epoch, whole]
+
+    def valid(self):
+        g = self.groups
+        if not all(_bound(g[k][0], g[k][1]) for k in self.other):
+            return False
+        if self.handles is None:
+            return all(_bound(g[k][0], g[k][1]) for k in self.lds)
+        return all(h[0].epoch == h[4] for h in self.handles)
+
+    def _summarise(self):
+        """The LDS graphs per handle, once they are all on the device."""
+        by = {}
+        for k in self.lds:
+            p = self.groups[k][0]
+            if p.group is None:
+                return
+            by.setdefault(id(p.group), []).append(k)
+        self.handles = []
+        for ks in by.values():
+            grp = self.groups[ks[0]][0].group
+            sc = self.scripts.get(ks[0])
+            same = sc is not None and all(self.scripts.get(k) == sc for k in ks) and len(ks) == len(grp.live())
+            self.handles.append([grp, ks, np.array([self.groups[k][0].r for k in ks]), sc if same else None, grp.epoch,
+                                 all(self.groups[k][2] for k in ks)])
+
+    def update(self):
+        g = self.groups
+        for k in self.other:
+            p, nodes, _ = g[k]
+            if getattr(p, "generic", False):
+                p.update_all(nodes)
+            else:
+                for n in nodes:
+                    n.update()
+                p.flush()
+        if self.handles is None:        # first pass: the calls themselves, queued on every graph before anything runs
+            for k in self.lds:
+                p, nodes, _ = g[k]
+                first = len(p.pending)
+                for n in nodes:
+                    n.update()
+                self.scripts[k] = p._spell(first)
+            for k in self.lds:
+                g[k][0].flush()
+            if all(_bound(g[k][0], g[k][1]) for k in self.lds):
+                self._summarise()
+            return
+        for grp, ks, rows, sc, epoch, whole in self.handles:
+            members = [g[k][0] for k in ks]
+            if sc is not None and not any(m.pending for m in members) and grp.run_script(sc):
+                continue
+            for k, m in zip(ks, members):
+                if self.scripts.get(k) is not None:
+                    m.pending.extend(self.scripts[k])
+                else:
+                    for n in g[k][1]:
+                        n.update()
+            for m in members:
+                m.flush()
+
+    def llb(self):
+        """sum of log_lower_bound() over the list (network.py:49), accumulated plan by plan in list order."""
+        g = self.groups
+        vals = [0.0] * len(g)
+        for k in self.other:
+            p, nodes, whole = g[k]
+            if getattr(p, "generic", False):
+                vals[k] = float(p.llb_sum(nodes).sum())
+            elif whole:
+                vals[k] = float(np.sum(p.elbo_parts()))         # every random node of the graph is listed, once: the class sums
+            else:
+                vals[k] = float(sum(n.log_lower_bound() for n in nodes))    # a part of a fused graph: its terms one by one
+        done = set()
+        if self.handles is not None:
+            for grp, ks, rows, sc, epoch, whole in self.handles:
+                if whole and grp.epoch == epoch:
+                    for k, v in zip(ks, grp.elbo()[rows].sum(1).tolist()):
+                        vals[k] = v
+                    done.update(ks)
+        for k in self.lds:
+            if k not in done:
+                p, nodes, whole = g[k]
+                vals[k] = float(np.sum(p.elbo_parts())) if whole else float(sum(n.log_lower_bound() for n in nodes))
+        llb = 0.0
+        for v in vals:
+            llb += v
+        return llb
+
+
 class Network(object):
     """A list of nodes with `learn()`: update every iterable node in list order, evaluate the lower
     bound, stop when it improves by less than `tol` (network.py:40-56).
@@ -31,7 +138,8 @@ class Network(object):
     def _groups(self):
         """The iterable nodes grouped by the device plan their graph is bound to, plans in order of first appearance, nodes
         in list order inside a group.  Unconnected graphs do not exchange messages, so running the groups one after the
-        other gives what the reference's single pass over the list gives (network.py:46-49)."""
+        other gives what the reference's single pass over the list gives (network.py:46-49).  Entries: [plan, nodes,
+        whether the nodes are all random nodes of the plan's graph, each once]."""
         plans, groups = [], {}
         for n in self.iterable_nodes:
             p = N._plan_of(n)
@@ -39,37 +147,31 @@ class Network(object):
                 plans.append(p)
                 groups[id(p)] = []
             groups[id(p)].append(n)
-        return [(p, groups[id(p)]) for p in plans]
+        return [[p, groups[id(p)], len(groups[id(p)]) == len(set(id(n) for n in groups[id(p)])) == p.n_random_nodes] for p in plans]
 
     def learn(self, niters, tol=1e-3, verbose=True):
         """network.py:40-56.  The node list may span any number of unconnected graphs, each on its own plan: a fused LDS
         or VB-PCA plan takes its group's update() calls as queued requests (whole sweeps become single launches) and gives
         the lower bound as the sum of its class parts; a graph that runs node by node gets one launch for all its updates
-        and one for the sum of its log_lower_bound() terms.  The grouping is redone around every step because an update
-        order the fused kernels do not serve moves a graph to the node-by-node plan (and sweeps bring it back)."""
+        and one for the sum of its log_lower_bound() terms.  LDS graphs of the same structure share one device handle, a
+        replicate each (_recognise.LDSGroup): their requests are queued first and carried out together, one launch per
+        operation for all of them, and from the second iteration on what the first one's requests spelt for the handle is
+        replayed without walking the node list again (_Schedule).  The grouping is redone whenever an update order the
+        fused kernels do not serve has moved a graph to the node-by-node plan (or sweeps have brought it back)."""
         self.find_iterable()
         if verbose:
             print('Found' + str(len(self.iterable_nodes)) + ' iterable nodes\n')
         if not self.iterable_nodes:
             return
         old_llb = -np.inf
+        sched = None
         for i in range(niters):
-            for p, group in self._groups():
-                if getattr(p, "generic", False):
-                    p.update_all(group)
-                else:
-                    for n in group:
-                        n.update()
-                    p.flush()
-            llb = 0.0
-            for p, group in self._groups():
-                if getattr(p, "generic", False):
-                    llb += float(p.llb_sum(group).sum())
-                elif len(group) == len(set(id(n) for n in group)) == p.n_random_nodes:
-                    llb += float(np.sum(p.elbo_parts()))        # every random node of the graph is listed, once: the class sums
-                else:
-                    llb += float(sum(n.log_lower_bound() for n in group))     # a part of a fused graph: its terms one by one
-            self.llb = llb                                      # network.py:49
+            if sched is None or not sched.valid():
+                sched = _Schedule(self._groups())
+            sched.update()                                      # network.py:46-48
+            if not sched.valid():
+                sched = _Schedule(self._groups())
+            self.llb = sched.llb()                              # network.py:49
             if verbose:
                 print(niters - i, self.llb)
             if self.llb - old_llb < tol:                        # also fires when the bound decreases (SURVEY.md Q9)

@@ -528,6 +528,9 @@ CASES = [
     # ragged sizes of the 64-wide class (padded tiles: DT = 3, KT = 2; DT = 4, KT = 4 with K < 64)
     ("d33k17_t20", 20, 33, 17, "diagonal_gamma", (1, 2), 20267, False),
     ("gamma_d50k60_t12", 12, 50, 60, "gamma", (1, 2), 20268, False),
+    # a second data set of the example's shape and priors: two reference runs that share one device handle when their graphs
+    # are built side by side (tests/test_groups_gpu.py)
+    ("example_b_d2k5_t200", 200, 2, 5, "diagonal_gamma", (1, 2, 5), 20270, True),
 ]
 
 
