@@ -47,7 +47,7 @@ class _Schedule(object):
             sc = self.scripts.get(ks[0])
             same = sc is not None and all(self.scripts.get(k) == sc for k in ks) and len(ks) == len(grp.live())
             self.handles.append([grp, ks, np.array([self.groups[k][0].r for k in ks]), sc if same else None, grp.epoch,
-                                 all(self.groups[k][2] for k in ks)])
+                                 all(self.groups[k][2] for k in ks), [self.groups[k][0] for k in ks], np.array(ks)])
 
     def update(self):
         g = self.groups
@@ -71,8 +71,7 @@ class _Schedule(object):
             if all(_bound(g[k][0], g[k][1]) for k in self.lds):
                 self._summarise()
             return
-        for grp, ks, rows, sc, epoch, whole in self.handles:
-            members = [g[k][0] for k in ks]
+        for grp, ks, rows, sc, epoch, whole, members, _ in self.handles:
             if sc is not None and not any(m.pending for m in members) and grp.run_script(sc):
                 continue
             for k, m in zip(ks, members):
@@ -87,7 +86,7 @@ class _Schedule(object):
     def llb(self):
         """sum of log_lower_bound() over the list (network.py:49), accumulated plan by plan in list order."""
         g = self.groups
-        vals = [0.0] * len(g)
+        vals = np.zeros(len(g))
         for k in self.other:
             p, nodes, whole = g[k]
             if getattr(p, "generic", False):
@@ -96,19 +95,19 @@ class _Schedule(object):
                 vals[k] = float(np.sum(p.elbo_parts()))         # every random node of the graph is listed, once: the class sums
             else:
                 vals[k] = float(sum(n.log_lower_bound() for n in nodes))    # a part of a fused graph: its terms one by one
-        done = set()
+        rest = self.lds
         if self.handles is not None:
-            for grp, ks, rows, sc, epoch, whole in self.handles:
+            rest = []
+            for grp, ks, rows, sc, epoch, whole, members, where in self.handles:
                 if whole and grp.epoch == epoch:
-                    for k, v in zip(ks, grp.elbo()[rows].sum(1).tolist()):
-                        vals[k] = v
-                    done.update(ks)
-        for k in self.lds:
-            if k not in done:
-                p, nodes, whole = g[k]
-                vals[k] = float(np.sum(p.elbo_parts())) if whole else float(sum(n.log_lower_bound() for n in nodes))
+                    vals[where] = grp.elbo()[rows].sum(1)       # one launch and one copy for all graphs of the handle
+                else:
+                    rest += ks
+        for k in rest:
+            p, nodes, whole = g[k]
+            vals[k] = float(np.sum(p.elbo_parts())) if whole else float(sum(n.log_lower_bound() for n in nodes))
         llb = 0.0
-        for v in vals:
+        for v in vals.tolist():
             llb += v
         return llb
 
@@ -158,27 +157,33 @@ class Network(object):
         operation for all of them, and from the second iteration on what the first one's requests spelt for the handle is
         replayed without walking the node list again (_Schedule).  The grouping is redone whenever an update order the
         fused kernels do not serve has moved a graph to the node-by-node plan (or sweeps have brought it back)."""
-        self.find_iterable()
+        # a second call over the same list starts where the first one stopped: the list is not walked again
+        kept = getattr(self, "_kept", None)
+        sched = kept[1] if kept is not None and kept[0] == self.nodes and kept[1].valid() else None
+        if sched is None:
+            self.find_iterable()
         if verbose:
             print('Found' + str(len(self.iterable_nodes)) + ' iterable nodes\n')
         if not self.iterable_nodes:
             return
         old_llb = -np.inf
-        sched = None
-        for i in range(niters):
-            if sched is None or not sched.valid():
-                sched = _Schedule(self._groups())
-            sched.update()                                      # network.py:46-48
-            if not sched.valid():
-                sched = _Schedule(self._groups())
-            self.llb = sched.llb()                              # network.py:49
-            if verbose:
-                print(niters - i, self.llb)
-            if self.llb - old_llb < tol:                        # also fires when the bound decreases (SURVEY.md Q9)
+        try:
+            for i in range(niters):
+                if sched is None or not sched.valid():
+                    sched = _Schedule(self._groups())
+                sched.update()                                  # network.py:46-48
+                if not sched.valid():
+                    sched = _Schedule(self._groups())
+                self.llb = sched.llb()                          # network.py:49
                 if verbose:
-                    print("Convergence!")
-                break
-            old_llb = self.llb
+                    print(niters - i, self.llb)
+                if self.llb - old_llb < tol:                    # also fires when the bound decreases (SURVEY.md Q9)
+                    if verbose:
+                        print("Convergence!")
+                    break
+                old_llb = self.llb
+        finally:
+            self._kept = (list(self.nodes), sched) if sched is not None else None
 
     def fetch_network(self, verbose=True):
         """Add every node connected to the ones already listed, in the order the reference's

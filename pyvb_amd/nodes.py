@@ -84,6 +84,9 @@ def _graph_changed(node):
         if not getattr(plan, "stale", False) and not getattr(plan, "released", False):
             plan.flush()
         plan.stale = True
+        handle = getattr(plan, "group", None)
+        if handle is not None:
+            handle.epoch += 1           # Network.learn's schedule for this handle is void (network._Schedule.valid)
 
 
 class Addition(Node):

@@ -389,35 +389,39 @@ def test_wishart_noise_with_known_entries_fused_against_node_by_node(monkeypatch
 
 
 def test_expectation_of_a_product_when_the_queue_hands_the_graph_over():
-    """Found by profiles/fuzz_ops.py (round 3): an output is re-observed (the plan is bound anew), a lone column update is
-    queued on the fresh fused plan -- a request only the node-by-node plan serves before the first sweep -- and the next call
-    is pass_down_Ex / pass_down_ExxT of a product.  Issuing the queue hands the graph over while the accessor is looking for
-    its plan; it must follow, not read from the closed handle."""
+    """Found by profiles/fuzz_ops.py (round 3): an output is re-observed (the plan is bound anew), a lone update is queued on
+    the fresh fused plan -- a request only the node-by-node plan serves -- and the next call is pass_down_Ex / pass_down_ExxT
+    of a product.  Issuing the queue hands the graph over while the accessor is looking for its plan; it must follow, not
+    read from the closed handle.  (Round 3 queued a lone column update there, which a freshly bound plan could not serve
+    before its first sweep.  Since round 4 a plan bound from swept states starts from their three covariance classes
+    (_recognise._state_classes) and serves it on the fused kernels: second half of the test; the hand-over is now
+    provoked by a lone state update.)"""
     from pyvb_amd import nodes, synth, generic
     import make_golden as MG
     T, D, K = 12, 3, 4
     Y, st0, pri = synth.make_problem(T, D, K, 1, 19)
 
-    def script(g):
+    def script(g, lone):
         Xs, As, Cs, Q, R, Ys = g["Xs"], g["As"], g["Cs"], g["Q"], g["R"], g["Ys"]
         [x.update() for x in Xs]; Xs.reverse(); [x.update() for x in Xs]; Xs.reverse()
         [a.update() for a in As]; [c.update() for c in Cs]; Q.update(); R.update()
         Ys[5].observe(Ys[5].qmu * 1.5)
-        As[2].update()
+        lone(g).update()
         return Ys[2].mean_parent.pass_down_Ex(), Ys[2].mean_parent.pass_down_ExxT(), Xs[0]._plan
 
-    ex, exxt, plan = script(MG.build_graph(nodes, Y[0], pri, st0))
-    assert isinstance(plan, generic.GenericPlan)
     from pyvb_amd import _recognise
     import pytest as _pt
-    mp = _pt.MonkeyPatch()
-    try:
-        mp.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
-        ex2, exxt2, _ = script(MG.build_graph(nodes, Y[0], pri, st0))
-    finally:
-        mp.undo()
-    _close(ex, ex2, "pass_down_Ex after the hand-over", 1e-10)
-    _close(exxt, exxt2, "pass_down_ExxT after the hand-over", 1e-10)
+    for lone, kind in ((lambda g: g["Xs"][3], generic.GenericPlan), (lambda g: g["As"][2], _recognise.LDSPlan)):
+        ex, exxt, plan = script(MG.build_graph(nodes, Y[0], pri, st0), lone)
+        assert isinstance(plan, kind)
+        mp = _pt.MonkeyPatch()
+        try:
+            mp.setattr(_recognise, "bind", lambda node: generic.GenericPlan(node))
+            ex2, exxt2, _ = script(MG.build_graph(nodes, Y[0], pri, st0), lone)
+        finally:
+            mp.undo()
+        _close(ex, ex2, "pass_down_Ex after the hand-over", 1e-10)
+        _close(exxt, exxt2, "pass_down_ExxT after the hand-over", 1e-10)
 
 
 def _plan_stub():
