@@ -34,7 +34,8 @@ int pyvb_pca_destroy(pyvb_pca* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) pyvb_comm_free(h->comm);
     void* bufs[] = {h->X, h->M, h->xvar, h->nmiss, h->Z, h->W_mean, h->W_var, h->Mu_mean, h->Mu_var, h->Z_cov, h->qld_W, h->W_pm, h->W_pp,
-                    h->Mu_pm, h->Mu_pp, h->scal, h->Gz, h->g0, h->part, h->stats, h->aux, h->elbo, h->status, h->red2, h->Xdata, h->pinned, h->sx_local};
+                    h->Mu_pm, h->Mu_pp, h->scal, h->Gz, h->g0, h->part, h->stats, h->aux, h->elbo, h->status, h->red2, h->Xdata, h->pinned, h->sx_local,
+                    h->W_x, h->Mu_x};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -77,6 +78,8 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     TRY(alloc_d(&h->W_mean, (size_t)d * q)); TRY(alloc_d(&h->W_var, (size_t)q * d));
     TRY(alloc_d(&h->Mu_mean, d)); TRY(alloc_d(&h->Mu_var, d)); TRY(alloc_d(&h->Z_cov, (size_t)q * q)); TRY(alloc_d(&h->qld_W, q));
     TRY(alloc_d(&h->W_pm, (size_t)d * q)); TRY(alloc_d(&h->W_pp, (size_t)q * d)); TRY(alloc_d(&h->Mu_pm, d)); TRY(alloc_d(&h->Mu_pp, d));
+    TRY(alloc_d(&h->W_x, (size_t)d * q)); TRY(alloc_d(&h->Mu_x, d));
+    { const char* e = getenv("PYVB_PCA_WRITEBACK"); h->lazy_ok = !(e && e[0] == '1'); }
     TRY(alloc_d(&h->scal, PS_COUNT));
     TRY(alloc_d(&h->Gz, (size_t)h->QT * (DP / 4) * 64)); TRY(alloc_d(&h->g0, QP));
     TRY(alloc_d(&h->part, (size_t)h->nchunk * (h->SL.total + h->DT)));
@@ -106,8 +109,10 @@ static int down(pyvb_pca* h, double* dst, const double* src, size_t n) {
 // A requested Z update whose rows have not been written (see pyvb_pca_update_Z) is carried out: pass 1 on its own.  Called by
 // everything that reads or replaces Z, X or the parameters outside the fused sweep.
 static int resolve_z(pyvb_pca* h) {
+    int rc = pca_materialize_x(h);          // the same callers want X as it stands, and Z is about to change or be replaced
+    if (rc) return rc;
     if (!h->z_pending) return PYVB_OK;
-    int rc = pca_launch_pass1(h);
+    rc = pca_launch_pass1(h);
     h->z_pending = false; h->z0_done = false;
     return rc;
 }
@@ -362,6 +367,7 @@ int pyvb_pca_update_Z(pyvb_pca* h) {
 static int x0_step(pyvb_pca* h) {
     int rc;
     if (!h->lin_valid && (rc = ensure_full(h))) return rc;
+    if (h->xlazy && h->row_offset == 0 && h->vlo == 0 && (rc = pca_materialize_x(h))) return rc;     // row 0 itself is read here
     double* v = h->aux + (size_t)4 * h->nchunk * h->QP;
     HIPCHK(hipMemcpyAsync(v, h->stats + h->SL.osz, h->QP * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     if (h->comm && h->row_offset != 0)

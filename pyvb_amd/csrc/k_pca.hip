@@ -31,6 +31,10 @@ struct PcaArgs {
     int keep_z0;        // Z of global row 0 is final already (k_pca_pass12, k_pca_pass1)
     int z_deferred;     // PCA_PREPZ: also form sum z analytically;  PCA_X0: Z of row 0 is formed here
     int x0_prep;        // PCA_X0: first set the sum-z half of aux_tail: 1 from the statistics, 2 zero (a rank that does not own row 0); 0: the host has
+    // lazy imputation (k_pca_pass12<.., LAZY>): the missing entries of rows [vin_lo, vin_hi) are not in X but stand for
+    // <W>_x z_n + <Mu>_x with the Z in memory and the parameters as of the sweep that imputed them (W_x, Mu_x)
+    double *W_x, *Mu_x; long vin_lo, vin_hi;
+    int save_wx;        // k_pca_rowvar: copy W_mean, Mu_mean to W_x, Mu_x (the sweep before it imputed with them and stored nothing)
     PcaStatsLayout SL;
 };
 
@@ -291,8 +295,16 @@ __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define P12_XS 36       // row stride (doubles) of the transposition buffer: 32 columns + pad, 32-byte aligned rows
-template <int QT, bool PIN>     // PIN as in k_pca_pass2
+// LAZY (round 4): the imputed entries are NOT written back.  They are a function of what is stored anyway -- x_nk = (<W> z_n + <Mu>)_k
+// with the z_n this sweep stores and the parameters it runs with -- so the next sweep recomputes them where it reads the row
+// (stage 0 below: the row's previous z from Z, the previous parameters from W_x / Mu_x, the same transposed product as stage 3,
+// the missing entries of the fetched tile take it) instead of this one writing 34 % of the 32-byte sectors of X (0.7 GB of the
+// 0.87 GB the sweep wrote at N = 10^6 x 256, 10 % missing; storing the 8-byte entries alone is a read-modify-write at the memory
+// side and slower still).  The host keeps track of which rows are in that state (pyvb_pca: xlazy, vlo, vhi) and k_pca_materialize
+// -- the same product, bit for bit -- puts the entries into X when something other than the next sweep wants them.
+template <int QT, bool PIN, bool LAZY = false>     // PIN as in k_pca_pass2
 __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
+    static_assert(!(LAZY && PIN), "rows that wait for their first update keep the write-back");
     extern __shared__ double lds12[];
     constexpr int RT = QT == 1 ? 2 : 1;         // tiles per step (register budget: 256 at two wavefronts per SIMD)
     constexpr int PF = 2 * RT;                  // register sets of X tiles: the tiles of this step and of the next
@@ -302,6 +314,7 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     double* zf = zp + (size_t)RT * nw * QT * 256;       // 2 x [RT][QT][4][64] Z of a step's rows, accumulator layout
     double* zT = zf + 2 * ZBUF;                         // 2 x [RT][QP][17] the same, latent index major (the operand of the prediction)
     double* xt = zT + 2 * ZTBUF + (size_t)(threadIdx.x >> 6) * RT * 16 * P12_XS;      // [RT][16][P12_XS] per wavefront
+    double* const mux = zT + 2 * ZTBUF + (size_t)nw * RT * 16 * P12_XS;               // LAZY: <Mu>_x [DP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, qk = lane >> 4;
     const int DP = a.DP, QP = a.QP, d = a.d, q = a.q, DS = DP / 4;
     constexpr int QS = 4 * QT;
@@ -325,6 +338,17 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const int dim = 16 * j + 4 * qk + e; mu4[jj][e] = dim < d ? a.Mu_mean[dim] : 0.0; }
     }
+    // LAZY: the <W> tiles of the sweep that imputed the rows, same permuted layout as wa; <Mu>_x sits in LDS
+    double wx[LAZY ? 2 : 1][LAZY ? QS : 1];
+    if (LAZY) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int dimA = 16 * (2 * wave + jj) + 4 * (c & 3) + (c >> 2);
+#pragma unroll
+            for (int s = 0; s < QS; ++s) { const int i = 4 * s + qk; wx[jj][s] = (dimA < d && i < q) ? a.W_x[(size_t)dimA * q + i] : 0.0; }
+        }
+        for (int k = tid; k < DP; k += blockDim.x) mux[k] = k < d ? a.Mu_x[k] : 0.0;
+    }
     const int col0 = 32 * wave + 2 * c;                 // this lane's two columns in the statistics (k_pca_pass2's interleaved tiles)
     const bool colok = col0 < DP;
     d4 sxz[P2T][QT], szz[QT][QT];
@@ -345,6 +369,8 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     const unsigned lo = a.lo_upd > r0 ? (unsigned)((a.lo_upd < r1 ? a.lo_upd : r1) - r0) : 0u;     // rows [lo, hi) of the chunk are updated
     const unsigned hi = a.hi_upd > r0 ? (unsigned)((a.hi_upd < r1 ? a.hi_upd : r1) - r0) : 0u;
     const bool z0_here = a.keep_z0 && a.row_offset == 0 && r0 == 0;
+    const unsigned vlo = a.vin_lo > r0 ? (unsigned)((a.vin_lo < r1 ? a.vin_lo : r1) - r0) : 0u;    // LAZY: rows [vlo, vhi) of the chunk are to be recomputed
+    const unsigned vhi = a.vin_hi > r0 ? (unsigned)((a.vin_hi < r1 ? a.vin_hi : r1) - r0) : 0u;
     double g0r[QT];         // step 2: a thread's elements all have latent index 16 t + tid % 16 (the workgroup is a multiple of 64 wide)
 #pragma unroll
     for (int t = 0; t < QT; ++t) g0r[t] = a.g0[16 * t + (tid & 15)];
@@ -363,6 +389,39 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     };
 #pragma unroll
     for (int u = 0; u < PF; ++u) fetch(16u * u < nrows ? 16u * u : 0u, xq[u], mq[u]);
+    // LAZY, stage 0: the previous z of a step's rows as the operand of the transposed product (lane (qk, c): latent index 4 s + qk of
+    // row c; every wavefront of the workgroup fetches the same 2 KB per tile, through L1), requested a step ahead -- right after
+    // the step before has used the registers, two steps before stage 2 overwrites those rows of Z in place
+    double zq[LAZY ? RT : 1][LAZY ? QS : 1];
+    auto zfetch = [&](unsigned n0, double (&z)[LAZY ? QS : 1]) {
+        const unsigned row = (n0 + c < nrows) ? n0 + c : nrows - 1;
+#pragma unroll
+        for (int s = 0; s < (LAZY ? QS : 1); ++s) z[s] = Zc[(size_t)row * QP + 4 * s + qk];
+    };
+    auto s0 = [&](unsigned nbase, auto U0) {
+        constexpr int u0 = decltype(U0)::value;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned n0 = nbase + 16 * rt, rowl = n0 + c;
+            const bool rowv = rowl >= vlo && rowl < vhi;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                d4 pred = *reinterpret_cast<const d4*>(mux + (tok[jj] ? 32 * wave + 16 * jj + 4 * qk : 0));
+#pragma unroll
+                for (int s = 0; s < QS; ++s) pred = MFMA(wx[jj][s], zq[rt][s], pred);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rowv && ((mq[u0 + rt][jj] >> (8 * e)) & 0xffu) == 0) xq[u0 + rt][jj][e] = pred[e];
+            }
+            const unsigned nn = n0 + 16 * RT;
+            zfetch(nn < nrows ? nn : n0, zq[rt]);
+        }
+    };
+    if (LAZY) {
+        __syncthreads();                                // mux
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) zfetch(16u * rt < nrows ? 16u * rt : 0u, zq[rt]);
+    }
     // A step takes RT tiles through the four stages between two barriers.  Measured with cycle stamps per tile (one tile per step, d = 256,
     // q = 16): stage 1 560, stage 2 790 (four of the eight wavefronts), stage 3 1900-2300, stage 4 1100-1500 cycles, against 3 x 1024
     // for the 48 MFMAs the two wavefronts of a SIMD issue: the sweep runs at the pace of its dependent chains (MFMA -> select -> LDS
@@ -444,7 +503,7 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
                         if (((ma[jj] >> (8 * e)) & 0xffu) != 0) v[e] = dat[e];
                     any = true;
                 }
-                if (any && tok[jj]) *reinterpret_cast<d4*>(Xc + (size_t)rowl * DP + 32 * wave + 16 * jj + 4 * qk) = v;
+                if (!LAZY && any && tok[jj]) *reinterpret_cast<d4*>(Xc + (size_t)rowl * DP + 32 * wave + 16 * jj + 4 * qk) = v;
                 *reinterpret_cast<d4*>(xtr + c * P12_XS + 16 * jj + 4 * qk) = v;
             }
         }
@@ -495,6 +554,7 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
         }
     };
     // prologue: Z of the first step
+    if (LAZY) s0(0u, std::integral_constant<int, 0>{});
     s1(0u, std::integral_constant<int, 0>{});
     lds_barrier();
     s2(0u, 0);
@@ -503,6 +563,7 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     for (unsigned base = 0; base < nrows; base += 16 * PF) {
         {   // step at base (register sets 0..RT-1); the next one, if any, at base + 16 RT (sets RT..)
             const bool more = base + 16 * RT < nrows;
+            if (LAZY && more) s0(base + 16 * RT, std::integral_constant<int, RT>{});
             if (more) s1(base + 16 * RT, std::integral_constant<int, RT>{});
             lds_barrier();
             if (more) s2(base + 16 * RT, zsel ^ 1);
@@ -514,6 +575,7 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
         {
             const unsigned b2 = base + 16 * RT;
             const bool more = b2 + 16 * RT < nrows;
+            if (LAZY && more) s0(b2 + 16 * RT, std::integral_constant<int, 0>{});
             if (more) s1(b2 + 16 * RT, std::integral_constant<int, 0>{});
             lds_barrier();
             if (more) s2(b2 + 16 * RT, zsel ^ 1);
@@ -558,10 +620,62 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     }
 }
 
+// The missing entries of rows [vin_lo, vin_hi) into X: <W>_x z_n + <Mu>_x, formed exactly as stage 0 of k_pca_pass12<.., LAZY> forms
+// them (same operands, same chain of MFMAs: bit for bit what the next sweep would have used).  Same mapping: a workgroup per row
+// chunk, wavefront w on columns [32 w, 32 w + 32).
+template <int QT>
+__global__ void __launch_bounds__(512) k_pca_materialize(PcaArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, qk = lane >> 4;
+    const int DP = a.DP, QP = a.QP, d = a.d, q = a.q;
+    constexpr int QS = 4 * QT;
+    const long r0 = (long)blockIdx.x * a.chunk_rows;
+    const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
+    const long lo = a.vin_lo > r0 ? a.vin_lo : r0, hi = a.vin_hi < r1 ? a.vin_hi : r1;
+    if (lo >= hi) return;
+    double wx[2][QS]; d4 mu4[2]; bool tok[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * wave + jj;
+        tok[jj] = 16 * j < DP;
+        const int dimA = 16 * j + 4 * (c & 3) + (c >> 2);
+#pragma unroll
+        for (int s = 0; s < QS; ++s) { const int i = 4 * s + qk; wx[jj][s] = (dimA < d && i < q) ? a.W_x[(size_t)dimA * q + i] : 0.0; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int dim = 16 * j + 4 * qk + e; mu4[jj][e] = dim < d ? a.Mu_x[dim] : 0.0; }
+    }
+    for (long n0 = r0 + ((lo - r0) & ~15L); n0 < hi; n0 += 16) {
+        const long row = n0 + c;
+        const long rowc = row < r1 ? row : r1 - 1;
+        double z[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) z[s] = a.Z[(size_t)rowc * QP + 4 * s + qk];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if (!tok[jj]) continue;
+            const size_t off = (size_t)rowc * DP + 32 * wave + 16 * jj + 4 * qk;
+            const unsigned m = *reinterpret_cast<const unsigned*>(a.M + off);
+            d4 pred = mu4[jj];
+#pragma unroll
+            for (int s = 0; s < QS; ++s) pred = MFMA(wx[jj][s], z[s], pred);
+            if (row >= lo && row < hi && m != 0x01010101u) {
+                d4 v = *reinterpret_cast<const d4*>(a.X + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((m >> (8 * e)) & 0xffu) == 0) v[e] = pred[e];
+                *reinterpret_cast<d4*>(a.X + off) = v;
+            }
+        }
+    }
+}
+
 // the variances of the missing entries of the chunk's rows (1 / <beta> for the rows being updated) and their sums:
 // sum_n #missing_n var_n, and sum over partially observed rows of #missing_n log var_n.  One workgroup per chunk.
 __global__ void __launch_bounds__(256) k_pca_rowvar(PcaArgs a) {
     __shared__ double red[4];
+    if (a.save_wx && blockIdx.x == 0) {         // the parameters the sweep before this launch imputed with (k_pca_pass12<.., LAZY>)
+        for (int i = threadIdx.x; i < a.d * a.q; i += 256) a.W_x[i] = a.W_mean[i];
+        for (int i = threadIdx.x; i < a.d; i += 256) a.Mu_x[i] = a.Mu_mean[i];
+    }
     const long r0 = (long)blockIdx.x * a.chunk_rows;
     const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
     const double var_new = a.scal[PS_BETA_B] / a.scal[PS_BETA_A];
@@ -932,6 +1046,7 @@ static PcaArgs pca_args(pyvb_pca* h) {
     a.d = h->d; a.q = h->q; a.DP = h->DP; a.QP = h->QP; a.DT = h->DT; a.QT = h->QT; a.nchunk = h->nchunk; a.mode = 0; a.SL = h->SL;
     a.res_cached = h->res_valid ? 1 : 0;
     a.keep_z0 = 0; a.z_deferred = 0; a.x0_prep = 0;
+    a.W_x = h->W_x; a.Mu_x = h->Mu_x; a.vin_lo = a.vin_hi = 0; a.save_wx = 0;
     return a;
 }
 
@@ -956,6 +1071,7 @@ int pca_launch_small(pyvb_pca* h, int mode) {
 }
 
 int pca_launch_pass1(pyvb_pca* h) {
+    { int rc = pca_materialize_x(h); if (rc) return rc; }
     PcaArgs a = pca_args(h);
     a.keep_z0 = h->z0_done ? 1 : 0;
     const size_t lds = (size_t)h->QT * (h->DP / 4) * 64 * sizeof(double);
@@ -966,6 +1082,7 @@ int pca_launch_pass1(pyvb_pca* h) {
 }
 
 int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
+    { int rc = pca_materialize_x(h); if (rc) return rc; }
     PcaArgs a = pca_args(h); a.lo_upd = lo_upd; a.hi_upd = hi_upd;
     const unsigned nw = (h->DT + P2T - 1) / P2T;          // wavefronts per row chunk: 32 columns each, four to a workgroup
     const dim3 grid(h->nchunk, (nw + 3) / 4), block(64 * (nw < 4 ? nw : 4));
@@ -977,19 +1094,42 @@ int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
     return PYVB_OK;
 }
 
-// Z and X updates and the statistics in one sweep (k_pca_pass12); rows [lo_upd, hi_upd) of X are updated
+// The missing entries of the rows a lazy sweep imputed (pyvb_pca: xlazy) into X, for everything that reads X other than the next sweep
+int pca_materialize_x(pyvb_pca* h) {
+    if (!h->xlazy) return PYVB_OK;
+    PcaArgs a = pca_args(h); a.vin_lo = h->vlo; a.vin_hi = h->vhi;
+    const unsigned nw = (h->DT + P2T - 1) / P2T;
+    if (h->QT == 1) hipLaunchKernelGGL(k_pca_materialize<1>, dim3(h->nchunk), dim3(64 * nw), 0, h->stream, a);
+    else hipLaunchKernelGGL(k_pca_materialize<2>, dim3(h->nchunk), dim3(64 * nw), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    h->xlazy = false;
+    return PYVB_OK;
+}
+
+// Z and X updates and the statistics in one sweep (k_pca_pass12); rows [lo_upd, hi_upd) of X are updated.  The standard sweep
+// of an iteration -- all rows, or all but row 0, which the crawl order updates on its own -- leaves the imputed entries to be
+// recomputed by the next one (LAZY); any other range, latent dimensions beyond 16 (the register budget) and rows that still
+// wait for their first update take the write-back.
 int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
+    const bool pin = h->Xdata != nullptr;
+    const bool lazy = h->lazy_ok && h->QT == 1 && !pin && lo_upd <= 1 && hi_upd == h->N && hi_upd > lo_upd
+                      && (!h->xlazy || (lo_upd <= h->vlo && h->vhi <= hi_upd));
+    int rc;
+    if (!lazy && (rc = pca_materialize_x(h))) return rc;
     PcaArgs a = pca_args(h); a.lo_upd = lo_upd; a.hi_upd = hi_upd;
     a.keep_z0 = h->z0_done ? 1 : 0;
+    if (lazy && h->xlazy) { a.vin_lo = h->vlo; a.vin_hi = h->vhi; }
+    a.save_wx = lazy ? 1 : 0;
     const unsigned nw = (h->DT + P2T - 1) / P2T;          // wavefronts per workgroup: 32 columns each
     const size_t rt = h->QT == 1 ? 2 : 1;                 // k_pca_pass12: RT
-    const size_t lds = rt * ((size_t)nw * h->QT * 256 + 2 * (size_t)h->QT * 256 + 2 * (size_t)h->QT * 16 * 17 + (size_t)nw * 16 * P12_XS) * sizeof(double);
+    const size_t lds = (rt * ((size_t)nw * h->QT * 256 + 2 * (size_t)h->QT * 256 + 2 * (size_t)h->QT * 16 * 17 + (size_t)nw * 16 * P12_XS) + (lazy ? h->DP : 0)) * sizeof(double);
     const dim3 grid(h->nchunk), block(64 * nw);
-    const bool pin = h->Xdata != nullptr;
-    if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass12<1, true>), grid, block, lds, h->stream, a); else hipLaunchKernelGGL((k_pca_pass12<1, false>), grid, block, lds, h->stream, a); }
+    if (lazy) hipLaunchKernelGGL((k_pca_pass12<1, false, true>), grid, block, lds, h->stream, a);
+    else if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass12<1, true>), grid, block, lds, h->stream, a); else hipLaunchKernelGGL((k_pca_pass12<1, false>), grid, block, lds, h->stream, a); }
     else { if (pin) hipLaunchKernelGGL((k_pca_pass12<2, true>), grid, block, lds, h->stream, a); else hipLaunchKernelGGL((k_pca_pass12<2, false>), grid, block, lds, h->stream, a); }
     hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
+    if (lazy) { h->xlazy = true; h->vlo = lo_upd; h->vhi = hi_upd; }
     return PYVB_OK;
 }
 

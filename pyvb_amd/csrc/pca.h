@@ -56,6 +56,10 @@ struct pyvb_pca {
     bool z_pending;                      // [z.update() for z in Zs] has been requested and its operands (Gz, g0, sum z) are set, but the
                                          // rows of Z are not written yet: the next pass over X does it on its way (k_pca_pass12)
     bool z0_done;                        // while z_pending: Xs[0].update() has run and stored z_0 itself
+    double *W_x, *Mu_x;                  // [d][q], [d]: the parameters the last lazy sweep imputed with
+    bool xlazy; long vlo, vhi;           // the missing entries of rows [vlo, vhi) are not in X: they stand for <W>_x z_n + <Mu>_x
+                                         // (k_pca_pass12<.., LAZY>); pca_materialize_x puts them there
+    bool lazy_ok;                        // PYVB_PCA_WRITEBACK=1 in the environment at creation turns the lazy sweep off (A/B measurements)
     pyvb_comm* comm; int rank, world;
 };
 
@@ -63,6 +67,7 @@ int pca_launch_small(pyvb_pca* h, int mode);
 int pca_launch_pass1(pyvb_pca* h);
 int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd);
 int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd);
+int pca_materialize_x(pyvb_pca* h);
 int pca_launch_reduce(pyvb_pca* h, int what);
 int pca_launch_rowqld(pyvb_pca* h, double* out);      // out: device [N]
 enum { PCA_W = 0, PCA_PREPZ = 1, PCA_MU = 2, PCA_BETA = 3, PCA_ELBO = 4, PCA_X0 = 5, PCA_APPLY = 6,
