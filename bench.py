@@ -93,63 +93,105 @@ def cpu_baseline_and_parity(sample, pri, iters, got_elbo, got_X):
     return base, rel, rel_x
 
 
-def pca_workload(steps, warmup, with_cpu):
-    """BASELINE configs[4] on one GPU, appended to the headline line as workloads.pca_config5: VB-PCA with missing data
+def pca_workload(steps, warmup, with_cpu, comm=None, rank=0, world=1, device=0, transport="none", rows=1000000):
+    """BASELINE configs[4], appended to the headline line as workloads.pca_config5: VB-PCA with missing data
     (examples/PCA_missing_data.py:31-45 of the reference), N = 10^6 rows x d = 256, q = 16, 10 % missing.  Measured like the
-    headline: inputs resident before the timed region, `steps` iterations after `warmup`; parity on a 20000-row copy of the
-    problem run for the same number of iterations through the same kernels and through oracle/pca_closed_form.py, which is
-    also the CPU baseline (scaled by rows: the cost is linear in N)."""
-    from pyvb_amd import synth
+    headline: inputs resident before the timed region, `steps` iterations after `warmup`, a barrier on both sides, the maximum
+    over the ranks.  With world > 1 the ROWS of the one model are sharded over the ranks (strong scaling: the total stays
+    10^6; every rank generates its own shard) and every iteration carries three all-reduces -- the statistics vector after
+    the sweep, [sum z | delta sum x] after the Z step and after the X_0 step (pyvb_amd/csrc/api_pca.hip) -- over RCCL, or over
+    the rendezvous sockets when the caller allowed the degraded transport.  Parity: a 20000-row copy of the problem, sharded
+    the same way over the same transport, against oracle/pca_closed_form.py on rank 0, which is also the CPU baseline
+    (scaled by rows: the cost is linear in N).  Every rank must call this; rank 0 gets the entry, the others None."""
+    from pyvb_amd import synth, dist as pdist
     from pyvb_amd.pca import PCABatch
-    N, d, q = 1000000, 256, 16
-    init, pri = synth.pca_problem(N, d, q, 33)
-    nmiss = float((~init["obs"]).sum())
-    b = PCABatch.from_problem(init, pri)
-    del init
+    from pyvb_amd.lds import LDSBatch
+    N, d, q = int(rows), 256, 16
+    pri = synth.pca_problem(16, d, q, 33)[1]
+
+    def shard(n_total):
+        lo, hi = pdist.shard_range(n_total, rank, world)
+        X, obs, Z0, W0 = synth.pca_rows(lo, hi, d, q, 33)
+        b = PCABatch(hi - lo, d, q, device, N_total=n_total, row_offset=lo)
+        if world > 1:
+            if transport == "rccl":
+                uid = comm.broadcast_bytes(LDSBatch.comm_unique_id() if rank == 0 else None)
+                b.comm_init(uid, rank, world)
+            else:
+                b.comm_init_host(comm, rank, world)
+        b.set_priors(pri)
+        b.set_data(np.where(obs, X, np.nan))
+        b.set_state(X_missing=np.where(obs, X, 0.0), W_mean=W0, Z=Z0, Z_cov=np.eye(q), Mu_mean=np.zeros(d), beta_b=1.0)
+        return b, float((~obs).sum())
+
+    b, nmiss = shard(N)
     b.iterate(warmup); b.sync()
+    if comm is not None:
+        comm.barrier()
     t0 = time.perf_counter()
     b.iterate(steps); b.sync()
+    if comm is not None:
+        comm.barrier()
     dt = time.perf_counter() - t0
-    elbo = b.elbo()
+    if comm is not None:
+        dt = comm.max_float(dt)
+        nmiss = float(comm.allreduce_sum(np.array([nmiss]))[0])
+    elbo = b.elbo()                         # global: the statistics are all-reduced
     b.close()
-    n_s = 20000
-    sinit, _ = synth.pca_problem(n_s, d, q, 33)
-    sb = PCABatch.from_problem(sinit, pri); sb.iterate(warmup + steps); got = sb.get_state(); ge = sb.elbo(); sb.close()
+    n_s = min(20000, N)
+    sb, _ = shard(n_s)
+    sb.iterate(warmup + steps)
+    got = sb.get_state(); ge = sb.elbo(); sb.close()
+    if rank != 0:
+        return None
     parity, cpu = None, None
     if with_cpu:
         from oracle import pca_closed_form as P        # checker and CPU baseline only
+        sinit, _ = synth.pca_problem(n_s, d, q, 33)
         sst = P.make_state(sinit, pri, n_s, d, q)
         t1 = time.perf_counter()
         for _ in range(warmup + steps):
             ref = P.iterate(sst, pri)
         cpu_dt = time.perf_counter() - t1
         rel = lambda x, y: float(np.abs(x - y).max() / np.abs(y).max())
-        parity = max(rel(got["W_mean"], sst["W_mean"]), rel(got["Z"], sst["Z"]), rel(got["X"], sst["X"]),
+        m = got["Z"].shape[0]                           # rank 0's rows of the copy
+        parity = max(rel(got["W_mean"], sst["W_mean"]), rel(got["Z"], sst["Z"][:m]), rel(got["X"], sst["X"][:m]),
                      float(np.abs(ge - ref).max() / np.abs(ref).sum()))
         cpu = {"value": (warmup + steps) / cpu_dt * n_s / N, "unit": "VB iterations/s at N=%d (scaled from the sample)" % N,
                "cores": os.cpu_count(), "kind": "port",
                "sample": "%d rows, %d iterations of oracle/pca_closed_form.py in %.1f s" % (n_s, warmup + steps, cpu_dt)}
     # algorithmic bytes of an iteration: X and the byte mask are read once (the Z and the X updates share one sweep over the rows,
-    # k_pca_pass12), Z is written once, the missing entries are written back.  (Two sweeps -- the reference's order taken
-    # literally, and this path before round 3 -- move X twice and Z three times: `algorithmic_bytes_two_sweeps`.)
-    alg = 1.0 * N * d * 8 + N * d + 1.0 * N * q * 8 + nmiss * 8
+    # k_pca_pass12), the previous Z is read and the new one written; the imputed entries are not stored (round 4: the next sweep
+    # recomputes them from Z and the parameters).  (Two sweeps -- the reference's order taken literally, and this path before
+    # round 3 -- move X twice and Z three times and write the missing entries back: `algorithmic_bytes_two_sweeps`.)
+    alg = 1.0 * N * d * 8 + N * d + 2.0 * N * q * 8
     alg2 = 2.0 * N * d * 8 + N * d + 2.0 * N * q * 8 + nmiss * 8
     traffic, tsrc = None, None
-    tpath = os.path.join(REPO, "profiles", "r03", "traffic_pca_pmc.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        hit = [v["hbm_bytes_per_launch"] for k, v in tj.items() if "k_pca_pass12" in k]
-        if hit:
-            traffic = hit[0]
-            tsrc = "profiles/r03/traffic_pca_pmc.json: k_pca_pass12, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (committed; not measured in this run)"
+    for tag in ("r04", "r03"):
+        tpath = os.path.join(REPO, "profiles", tag, "traffic_pca_pmc.json")
+        if world == 1 and N == 1000000 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            hit = [v["hbm_bytes_per_launch"] for k, v in tj.items() if "k_pca_pass12" in k]
+            if hit:
+                traffic = hit[0]
+                tsrc = "profiles/%s/traffic_pca_pmc.json: k_pca_pass12, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (committed; not measured in this run)" % tag
+                break
     step_s = dt / steps
-    return {"workload": "VB-PCA N=%d d=%d q=%d, 10%% missing (BASELINE configs[4] on one GPU)" % (N, d, q),
-            "metric": "VB-PCA iterations/sec", "value": steps / dt, "unit": "VB iterations/s", "steps": steps, "warmup": warmup,
-            "ms_per_step": step_s * 1e3, "dtype": "f64", "rel_err_vs_numpy": parity,
-            "parity_checked_on": "a %d-row copy of the problem, %d iterations, same kernels" % (n_s, warmup + steps),
-            "elbo_total": float(elbo.sum()),
-            "roofline": {"bound": "hbm", "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "algorithmic_bytes_two_sweeps": alg2,
+    QP, DP = 16, 256
+    stats_doubles = (QP * QP + DP * QP + DP + QP + 4 + 7) // 8 * 8         # pyvb_amd/csrc/pca.h: pca_stats_layout
+    coll_bytes = 8 * (stats_doubles + 2 * (QP + DP))
+    collective = "none (1 GPU)" if world == 1 else \
+        ("%s all-reduce, 3 per iteration: statistics %d B + 2 x [sum z | delta sum x] %d B = %d B per iteration"
+         % ("rccl" if transport == "rccl" else "host (over TCP: DEGRADED)", 8 * stats_doubles, 8 * (QP + DP), coll_bytes))
+    return {"workload": "VB-PCA N=%d d=%d q=%d, 10%% missing (%s), rows sharded over %d GPU(s)"
+                        % (N, d, q, "BASELINE configs[4]" if N == 1000000 else "not a BASELINE configuration", world),
+            "metric": "VB-PCA iterations/sec", "value": steps / dt, "unit": "VB iterations/s", "n_gpus": world, "scaling": "strong",
+            "steps": steps, "warmup": warmup, "ms_per_step": step_s * 1e3, "dtype": "f64", "rel_err_vs_numpy": parity,
+            "parity_checked_on": "a %d-row copy of the problem sharded the same way, %d iterations, same kernels and collectives" % (n_s, warmup + steps),
+            "elbo_total": float(elbo.sum()), "collective": collective, "collective_bytes_per_step": 0 if world == 1 else coll_bytes,
+            "degraded": world > 1 and transport != "rccl",
+            "roofline": {"bound": "hbm", "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": alg / step_s / 1e9 / (HBM_PEAK_GBS * world), "algorithmic_bytes": alg, "algorithmic_bytes_two_sweeps": alg2,
                          "traffic": traffic, "traffic_source": tsrc,
                          "kernel": "whole iteration (k_pca_pass12 + reductions + small kernels)"},
             "cpu_baseline": cpu}
@@ -235,6 +277,7 @@ def launch_ranks(n, argv):
     reader.start()
     rc = 0
     live = set(range(n))
+    kill_at = None              # after one rank has failed: when the others, already asked to terminate, are killed
     while live:
         for r in sorted(live):
             code = procs[r].poll()
@@ -246,6 +289,11 @@ def launch_ranks(n, argv):
                 sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
                 for o in live:
                     procs[o].terminate()        # exactly the children started above
+                kill_at = time.time() + 15.0
+        if kill_at is not None and live and time.time() > kill_at:
+            for o in live:                      # a rank stuck in a GPU call ignores SIGTERM: do not wait for it for ever
+                procs[o].kill()
+            kill_at = time.time() + 15.0
         time.sleep(0.05)
     reader.join()
     lines = [l for l in out0 if l.startswith("{")]
@@ -277,6 +325,9 @@ def main():
     ap.add_argument("--K", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="skip the second workload (VB-PCA, BASELINE configs[4]) after the headline")
+    ap.add_argument("--workloads", default="auto", help="comma list of pca_config5, lds_d128; auto: both after the headline shape on one "
+                                                        "GPU, pca_config5 (rows sharded over the ranks) with several")
+    ap.add_argument("--pca-rows", type=int, default=1000000, help="rows of the VB-PCA workload (BASELINE configs[4]: 10^6)")
     ap.add_argument("--parity-replicates", type=int, default=4, help="replicates of the timed batch re-run in the oracle")
     ap.add_argument("--rccl-single", action="store_true",
                     help="with one process: still create a (one-rank) RCCL communicator and all-reduce the lower bound through it, "
@@ -492,15 +543,25 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        b.close()
-        b = None
-        if world == 1 and not args.no_workloads and (N, T, D, K) == (1024, 10000, 64, 64):
-            # the other GPU-sized configuration of BASELINE.json, after the headline's timed region and with its memory released
-            out["workloads"] = {"pca_config5": pca_workload(args.steps, args.warmup, not args.no_cpu_baseline),
-                                "lds_d128": d128_workload(args.steps, args.warmup, not args.no_cpu_baseline)}
+    else:
+        out = None
+    b.close()
+    # the other GPU-sized configurations of BASELINE.json, after the headline's timed region and with its memory released.
+    # VB-PCA (configs[4]) is a job of ALL ranks -- its rows are sharded over them; the 128-wide LDS class runs on one GPU only
+    if args.workloads == "auto":
+        want = [] if args.no_workloads or (N, T, D, K) != (1024, 10000, 64, 64) else (["pca_config5", "lds_d128"] if world == 1 else ["pca_config5"])
+    else:
+        want = [w for w in args.workloads.split(",") if w]
+    wl = {}
+    if "pca_config5" in want:
+        transport = "none" if world == 1 else ("rccl" if use_rccl else "host")
+        wl["pca_config5"] = pca_workload(args.steps, args.warmup, not args.no_cpu_baseline, comm, rank, world, device, transport, args.pca_rows)
+    if "lds_d128" in want and world == 1:
+        wl["lds_d128"] = d128_workload(args.steps, args.warmup, not args.no_cpu_baseline)
+    if rank == 0:
+        if wl:
+            out["workloads"] = wl
         print(json.dumps(out), flush=True)
-    if b is not None:
-        b.close()
     comm.close()
 
 

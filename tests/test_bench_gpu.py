@@ -102,3 +102,31 @@ def test_one_rank_cannot_stand_for_several_gpus():
     r = _run([sys.executable, "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL, {"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_pca_workload_with_its_rows_sharded_over_two_ranks():
+    """BASELINE configs[4] "batched over 8 GPUs": with --gpus N > 1 every rank joins the VB-PCA workload with its shard of the
+    rows and rank 0 appends workloads.pca_config5 with n_gpus, the collective's byte count and `degraded`.  Two ranks on the
+    one GPU of this box (host transport: RCCL refuses duplicate devices) against the single-rank run of the same problem."""
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env_clean.update(env)
+    extra = ["--workloads", "pca_config5", "--pca-rows", "60000"]
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + extra + SMALL, cwd=REPO, env=env_clean, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = _line(r1.stdout)["workloads"]["pca_config5"]
+    assert one["n_gpus"] == 1 and one["degraded"] is False and one["collective_bytes_per_step"] == 0 and one["rel_err_vs_numpy"] < 1e-8
+    r2 = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--allow-host-fallback"] + extra + SMALL, cwd=REPO, env=env_clean,
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    d = _line(r2.stdout)
+    two = d["workloads"]["pca_config5"]
+    assert d["n_gpus"] == 2 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    if d["config"]["degraded"]:
+        assert two["degraded"] is True and "DEGRADED" in two["collective"]
+    else:
+        assert two["collective"].startswith("rccl")
+    assert two["collective_bytes_per_step"] == 8 * (4632 + 2 * 272)
+    assert two["rel_err_vs_numpy"] < 1e-8                               # the sharded copy against the oracle
+    assert abs(two["elbo_total"] - one["elbo_total"]) <= 1e-9 * abs(one["elbo_total"])      # the sharded run against the single-rank one
+    assert "lds_d128" not in d["workloads"]

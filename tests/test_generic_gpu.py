@@ -183,8 +183,7 @@ def test_single_messages_and_terms_of_the_fused_lds_plan(golden):
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_golden as MG
     meta, Y, st0, pri, z = golden
-    if meta["noise"] == "wishart" or meta["D"] > 8 or meta["T"] > 60:
-        pytest.skip("node-by-node evaluation is for small graphs")
+    wishart = meta["noise"] == "wishart"
     g = MG.build_graph(nodes, Y[0], pri, {k: v for k, v in st0.items()})
     Xs, Ys, As, Cs, Q, R = g["Xs"], g["Ys"], g["As"], g["Cs"], g["Q"], g["R"]
     for t, y in enumerate(Ys):          # outputs with missing entries: the fixture's explicit initial posterior
@@ -198,17 +197,20 @@ def test_single_messages_and_terms_of_the_fused_lds_plan(golden):
         [y.update() for y in Ys if not y.observed]
         [a.update() for a in As]; [c.update() for c in Cs]
         Q.update(); R.update()
-    ref = z["it%d_elbo_parts" % it]
+    # the class sums of the fused kernels (k_elbo / k_elbo_dense) and, where the reference has a lower bound (not with a Wishart
+    # parent: SURVEY.md Q8, parity unpinned there), the fixture's
+    fused_parts = Xs[0]._plan.elbo_parts()
+    ref = fused_parts if wishart else z["it%d_elbo_parts" % it]
     scale = np.abs(ref).sum()
-    got = [sum(n.log_lower_bound() for n in grp) for grp in (Xs, Ys, As, Cs)]
-    for v, r in zip(got, ref[:4]):
-        assert abs(v - r) <= 1e-8 * scale, (got, ref)
+    got = [sum(n.log_lower_bound() for n in grp) for grp in (Xs, Ys, As, Cs)] + [Q.log_lower_bound(), R.log_lower_bound()]
+    for v, r, f in zip(got, ref, fused_parts):
+        assert abs(v - r) <= 1e-8 * scale and abs(v - f) <= 1e-8 * scale, (got, ref, fused_parts)
     m1, m2 = Ys[1].pass_up_m1_m2(Ys[1].mean_parent)             # gaussian.py:179-183
     Rbar = R.pass_down_Ex()
     _close(m1, Rbar, "m1 of an observed output", 1e-9)
     _close(m2, Rbar @ Ys[1].qmu, "m2 of an observed output", 1e-9)
     T = len(Xs)
-    if T > 2:
+    if T > 2 and meta["D"] <= 16 and not wishart:               # the D^4 tensor below is what it says
         # Mult(., X_1) asked by X_1: the hstack branch with the D^4 tensor, node.py:213-227.  The fused plan answers from a
         # mirror of its state; the same graph forced node by node (its posteriors assigned from the fused run) must agree,
         # and so must the closed form <A^T L A> = Abar^T L Abar + diag_i tr(S_i L) that k_prep uses

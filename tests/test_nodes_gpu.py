@@ -25,8 +25,6 @@ def _rel(a, b):
 def test_example_loop_through_the_node_api(golden):
     from pyvb_amd import nodes
     meta, Y, st0, pri, z = golden
-    if meta["D"] > 16:
-        pytest.skip("node-by-node reads are slow for the large fixture; covered by test_gpu_parity")
     g = _golden_module().build_graph(nodes, Y[0], pri, {k: v for k, v in st0.items()})
     Xs, As, Cs, Q, R = g["Xs"], g["As"], g["Cs"], g["Q"], g["R"]
     missing = bool(np.isnan(Y).any())
