@@ -295,6 +295,15 @@ __global__ void __launch_bounds__(256, P2_OCC) k_pca_pass2(PcaArgs a) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define P12_XS 36       // row stride (doubles) of the transposition buffer: 32 columns + pad, 32-byte aligned rows
+// -DP12_STAMP (profiles/pca_stamps.py builds it as a variant library): wavefronts 0 and 4 of every workgroup add up, stage by
+// stage, the time they spend (s_memtime ticks: core clock on this part) -- [s0, s1, wait at barrier A, s2, stage 3, stage 4 + fetch, wait at
+// barrier B, whole kernel, steps]; pyvb_pca_debug_stamps copies the table out.  Not in the shipped library.
+#ifdef P12_STAMP
+__device__ unsigned long long g_p12_stamp[4096 * 2 * 12];
+#define STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[i] += _t - st_last; st_last = _t; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 // LAZY (round 4): the imputed entries are NOT written back.  They are a function of what is stored anyway -- x_nk = (<W> z_n + <Mu>)_k
 // with the z_n this sweep stores and the parameters it runs with -- so the next sweep recomputes them where it reads the row
 // (stage 0 below: the row's previous z from Z, the previous parameters from W_x / Mu_x, the same transposed product as stage 3,
@@ -422,6 +431,10 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) zfetch(16u * rt < nrows ? 16u * rt : 0u, zq[rt]);
     }
+#ifdef P12_STAMP
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_last;
+#endif
     // A step takes RT tiles through the four stages between two barriers.  Measured with cycle stamps per tile (one tile per step, d = 256,
     // q = 16): stage 1 560, stage 2 790 (four of the eight wavefronts), stage 3 1900-2300, stage 4 1100-1500 cycles, against 3 x 1024
     // for the 48 MFMAs the two wavefronts of a SIMD issue: the sweep runs at the pace of its dependent chains (MFMA -> select -> LDS
@@ -506,15 +519,20 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
                 if (!LAZY && any && tok[jj]) *reinterpret_cast<d4*>(Xc + (size_t)rowl * DP + 32 * wave + 16 * jj + 4 * qk) = v;
                 *reinterpret_cast<d4*>(xtr + c * P12_XS + 16 * jj + 4 * qk) = v;
             }
+            // This register set is free from here on (stage 4 works on the LDS copy): the tile PF further on is requested NOW, in
+            // front of the fences below, which no global load may be moved across -- at the end of stage 4, where this call used
+            // to stand, the rows had a barrier's time to arrive before stage 1 of the next step asked for them (cycle stamps,
+            // profiles/r04/pca_stamps_*.txt: 3000 of a step's 16000 cycles were that wait)
+            const unsigned nn = n0 + 16 * PF;
+            fetch(nn < nrows ? nn : n0, xa, ma);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        STAMP(4);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const unsigned n0 = nbase + 16 * rt;
-            d4 (&xa)[2] = xq[u0 + rt];
-            unsigned (&ma)[2] = mq[u0 + rt];
             double* const xtr = xt + rt * 16 * P12_XS;
             double zb[4][QT];
 #pragma unroll
@@ -549,9 +567,8 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
                         for (int u = 0; u < QT; ++u) szz[t][u] = MFMA(zb[s][t], zb[s][u], szz[t][u]);
                     }
             }
-            const unsigned nn = n0 + 16 * PF;              // this register set is free again: the tile PF further on
-            fetch(nn < nrows ? nn : n0, xa, ma);
         }
+        STAMP(5);
     };
     // prologue: Z of the first step
     if (LAZY) s0(0u, std::integral_constant<int, 0>{});
@@ -559,16 +576,22 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     lds_barrier();
     s2(0u, 0);
     lds_barrier();
+    STAMP(9);
     int zsel = 0;
     for (unsigned base = 0; base < nrows; base += 16 * PF) {
         {   // step at base (register sets 0..RT-1); the next one, if any, at base + 16 RT (sets RT..)
             const bool more = base + 16 * RT < nrows;
             if (LAZY && more) s0(base + 16 * RT, std::integral_constant<int, RT>{});
+            STAMP(0);
             if (more) s1(base + 16 * RT, std::integral_constant<int, RT>{});
+            STAMP(1);
             lds_barrier();
+            STAMP(2);
             if (more) s2(base + 16 * RT, zsel ^ 1);
+            STAMP(3);
             back(base, std::integral_constant<int, 0>{}, zsel);
             lds_barrier();
+            STAMP(6);
             zsel ^= 1;
             if (!more) break;
         }
@@ -576,15 +599,28 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
             const unsigned b2 = base + 16 * RT;
             const bool more = b2 + 16 * RT < nrows;
             if (LAZY && more) s0(b2 + 16 * RT, std::integral_constant<int, 0>{});
+            STAMP(0);
             if (more) s1(b2 + 16 * RT, std::integral_constant<int, 0>{});
+            STAMP(1);
             lds_barrier();
+            STAMP(2);
             if (more) s2(b2 + 16 * RT, zsel ^ 1);
+            STAMP(3);
             back(b2, std::integral_constant<int, RT>{}, zsel);
             lds_barrier();
+            STAMP(6);
             zsel ^= 1;
             if (!more) break;
         }
     }
+#ifdef P12_STAMP
+    if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = g_p12_stamp + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 12;
+        for (int i = 0; i < 10; ++i) o[i] = st_acc[i];
+        o[10] = __builtin_amdgcn_s_memtime() - st_begin;
+        o[11] = (nrows + 16 * RT - 1) / (16 * RT);
+    }
+#endif
     // ---- partial sums of this chunk, laid out as k_pca_pass2's
     double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
 #pragma unroll
@@ -1132,6 +1168,14 @@ int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
     if (lazy) { h->xlazy = true; h->vlo = lo_upd; h->vhi = hi_upd; }
     return PYVB_OK;
 }
+
+#ifdef P12_STAMP
+extern "C" int pyvb_pca_debug_stamps(unsigned long long* out, int nblocks) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p12_stamp), (size_t)nblocks * 2 * 12 * sizeof(unsigned long long)));
+    return PYVB_OK;
+}
+#endif
 
 int pca_launch_rowqld(pyvb_pca* h, double* out) {
     PcaArgs a = pca_args(h);
