@@ -80,6 +80,18 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     TRY(alloc_d(&h->W_pm, (size_t)d * q)); TRY(alloc_d(&h->W_pp, (size_t)q * d)); TRY(alloc_d(&h->Mu_pm, d)); TRY(alloc_d(&h->Mu_pp, d));
     TRY(alloc_d(&h->W_x, (size_t)d * q)); TRY(alloc_d(&h->Mu_x, d));
     { const char* e = getenv("PYVB_PCA_WRITEBACK"); h->lazy_ok = !(e && e[0] == '1'); }
+    { const char* e = getenv("PYVB_PCA_SWEEP"); h->rows_ok = e && e[0] == 'r'; }       // "rows": k_pca_rows (measured slower: k_pca.hip)
+    {   // k_pca_rows: one workgroup of four wavefronts per CU, the rows dealt out in multiples of 16
+        int ncu = 0;
+        TRYHIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        if (ncu < 1) ncu = 1;
+        long rowsB = (N + ncu - 1) / ncu;
+        rowsB = (rowsB + 15) & ~15L;
+        if (rowsB < 64) rowsB = 64;
+        long ncB = (N + rowsB - 1) / rowsB;
+        if (ncB > nchunk) { ncB = nchunk; rowsB = ((N + ncB - 1) / ncB + 15) & ~15L; ncB = (N + rowsB - 1) / rowsB; }
+        h->nchunkB = (int)ncB; h->chunk_rowsB = rowsB;
+    }
     TRY(alloc_d(&h->scal, PS_COUNT));
     TRY(alloc_d(&h->Gz, (size_t)h->QT * (DP / 4) * 64)); TRY(alloc_d(&h->g0, QP));
     TRY(alloc_d(&h->part, (size_t)h->nchunk * (h->SL.total + h->DT)));

@@ -656,6 +656,285 @@ __global__ void __launch_bounds__(512) k_pca_pass12(PcaArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The sweep of an iteration, second form (round 4): a wavefront owns WHOLE ROWS.
+//
+// k_pca_pass12 gives every wavefront of a workgroup 32 columns of the same 16 rows, so the eight partial products of a tile's Z
+// meet in LDS and the workgroup walks in lock step, two barriers a step: its cycle stamps (profiles/r04/pca_stamps_*.txt) show a
+// step of 32 rows taking 16 000 cycles of which the matrix pipe is busy 6 000 -- the rest is barrier skew, LDS round trips
+// and the instruction streams of eight wavefronts that all do the same thing at the same time.  Here a wavefront takes a
+// 16-row tile through all of it alone:
+//   A. over the row's eight 32-column blocks: [the missing entries recomputed from the row's previous z, as LAZY above]
+//      and Z += X Gz^T, one accumulator for the whole row -- no partial sums, no exchange;
+//   B. z = Z - g0 stored; both operand forms of it: the accumulator IS the B operand of sum x z^T (k = row), the transposed one
+//      (k = latent index, for the prediction) goes through 2 KB of this wavefront's own LDS;
+//   C. over the blocks again (X a second time, from L2): prediction, imputation (nothing stored: LAZY), the 32-column piece
+//      through this wavefront's transposition buffer into accumulator layout, sum x z^T / sum x / sum |x|^2.
+// No workgroup barrier between the prologue and the final reduction: the four wavefronts of a workgroup -- one per SIMD, so that
+// the 128 accumulator registers of the whole 256 x 16 sum x z^T fit beside the working set -- drift apart.  The operand tables
+// (Gz^T, <W>, <W>_x as MFMA operands for all 16 column tiles: 96 KB) are in LDS, shared.  X is fetched through a ring of four
+// register sets, three 32-column blocks ahead, across phases and tiles.
+// Same operands, same products, same order of the sums over a tile's rows as k_pca_pass12; what differs is the order in
+// which the tiles of a chunk are added up (per wavefront, then the wavefronts in order), i.e. rounding.
+// MEASURED (N = 10^6 x 256, q = 16, one MI355X, profiles/r04/pca_rows_vs_columns.txt): correct at once (all PCA tests, 1.4e-13
+// against the oracle) and SLOWER -- 1.11-1.19 ms per iteration against 1.03-1.04 for k_pca_pass12<.., LAZY>.  The matrix pipe needs
+// 256 MFMAs x 64 cycles = 16 400 cycles per tile and SIMD (0.43 ms for the sweep); the tile takes 36 000.  With one wavefront per SIMD
+// (256 + 172 registers: two do not fit) nobody fills the waits of the ~2 500 other instructions of a tile -- LDS operand reads, the
+// byte-mask selects, 670 moves between the accumulator and the vector registers -- and the compiler does not interleave them with
+// the MFMAs over blocks of this size (operand reads batched per block: 1.19 -> 1.11; bounds tests removed so that a phase is one
+// basic block: 1.14).  Kept as PYVB_PCA_SWEEP=rows, with the fixtures run through it, as the record of the attempt; the sweep in
+// use is k_pca_pass12<.., LAZY>.
+#define PR_NW 4
+__device__ __forceinline__ void wave_lds_sync() {
+    // the LDS operations of one wavefront execute in order: what has to be kept in order is the compiler (no wait, in particular
+    // none for the rows requested ahead)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+// FULL: all 16 column tiles exist (d > 240): no bounds tests on them, so that a tile's phase is one basic block for the scheduler
+template <bool FULL>
+__global__ void __launch_bounds__(64 * PR_NW) k_pca_rows(PcaArgs a) {
+    extern __shared__ double ldsr[];
+    constexpr int QS = 4, NB = 8, RING = 4, AHEAD = 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, qk = lane >> 4;
+    const int DP = a.DP, d = a.d, q = a.q, DT = a.DT;
+    constexpr int QP = 16;
+    double* const gzL = ldsr;                               // [DT][4][64]   B operands of Z = X Gz^T (a.Gz as it is)
+    double* const waL = gzL + (size_t)DT * 256;             // [DT][4][64]   <W> tiles, rows permuted (k_pca_pass12, 3.)
+    double* const wxL = waL + (size_t)DT * 256;             // the same of <W>_x
+    double* const muL = wxL + (size_t)DT * 256;             // [DP]
+    double* const mxL = muL + DP;                           // [DP]
+    double* const g0L = mxL + DP;                           // [16]
+    double* const zTw = g0L + 16 + (size_t)wave * (16 * 17 + 16 * P12_XS);     // this wavefront's: z transposed [16][17]
+    double* const xtw = zTw + 16 * 17;                                           // and the 32-column piece [16][P12_XS]
+    for (int i = tid; i < DT * 256; i += 64 * PR_NW) {
+        gzL[i] = a.Gz[i];
+        const int j = i >> 8, s4 = (i >> 6) & 3, ln = i & 63, cc = ln & 15, qq = ln >> 4;
+        const int dimA = 16 * j + 4 * (cc & 3) + (cc >> 2), li = 4 * s4 + qq;
+        const bool in = dimA < d && li < q;
+        waL[i] = in ? a.W_mean[(size_t)dimA * q + li] : 0.0;
+        wxL[i] = in ? a.W_x[(size_t)dimA * q + li] : 0.0;
+    }
+    for (int k = tid; k < DP; k += 64 * PR_NW) { muL[k] = k < d ? a.Mu_mean[k] : 0.0; mxL[k] = k < d ? a.Mu_x[k] : 0.0; }
+    if (tid < 16) g0L[tid] = a.g0[tid];
+    __syncthreads();
+
+    const long r0 = (long)blockIdx.x * a.chunk_rows;
+    const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
+    const unsigned nrows = (unsigned)(r1 - r0);
+    const unsigned ntiles = (nrows + 15) >> 4;
+    double* const Xc = a.X + (size_t)r0 * DP;
+    const unsigned char* const Mc = a.M + (size_t)r0 * DP;
+    double* const Zc = a.Z + (size_t)r0 * QP;
+    const unsigned lo = a.lo_upd > r0 ? (unsigned)((a.lo_upd < r1 ? a.lo_upd : r1) - r0) : 0u;
+    const unsigned hi = a.hi_upd > r0 ? (unsigned)((a.hi_upd < r1 ? a.hi_upd : r1) - r0) : 0u;
+    const unsigned vlo = a.vin_lo > r0 ? (unsigned)((a.vin_lo < r1 ? a.vin_lo : r1) - r0) : 0u;
+    const unsigned vhi = a.vin_hi > r0 ? (unsigned)((a.vin_hi < r1 ? a.vin_hi : r1) - r0) : 0u;
+    const bool z0_here = a.keep_z0 && a.row_offset == 0 && r0 == 0;
+    const double g0c = g0L[c];
+    const double z0keep = z0_here ? Zc[c] : 0.0;        // read once, here: a load inside the loop would make every tile wait for all rows in flight
+
+    d4 sxz[NB][2], szz = d4{0, 0, 0, 0};
+    double sx[NB][2], sxx = 0.0, sz = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { sxz[b][p] = d4{0, 0, 0, 0}; sx[b][p] = 0.0; }
+
+    // ---- the stream of X: position pos of a tile = block pos % 8 (0..7 phase A, 8..15 phase C); the set of position pos is pos % 4
+    d4 rx[RING][2]; unsigned rm[RING][2];
+    auto fetch = [&](d4 (&x)[2], unsigned (&m)[2], unsigned tile, int b) {
+        const unsigned rw = 16u * tile + c;
+        const unsigned row = rw < nrows ? rw : nrows - 1;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * b + jj;
+            const unsigned off = row * DP + ((FULL || j < DT) ? 16 * j + 4 * qk : 0);
+            x[jj] = *reinterpret_cast<const d4*>(Xc + off);
+            m[jj] = *reinterpret_cast<const unsigned*>(Mc + off);
+        }
+    };
+    auto zfetch = [&](double (&z)[QS], unsigned tile) {
+        const unsigned rw = 16u * tile + c;
+        const unsigned row = rw < nrows ? rw : nrows - 1;
+#pragma unroll
+        for (int s4 = 0; s4 < QS; ++s4) z[s4] = Zc[(size_t)row * QP + 4 * s4 + qk];
+    };
+    double zq[QS];                      // previous z of the tile's rows, operand of the recomputation
+    unsigned t = wave;
+    if (t < ntiles) {
+        // in the order of the loop (z first, the blocks behind it): the counter of outstanding loads the compiler waits on at the
+        // loop head is the minimum over the way in and the way round
+        zfetch(zq, t);
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) fetch(rx[u], rm[u], t, u);
+    }
+    for (; t < ntiles; t += PR_NW) {
+        const unsigned n0 = 16u * t, rowl = n0 + c;
+        const unsigned tnext = (t + PR_NW < ntiles) ? t + PR_NW : t;
+        const bool rowv = rowl >= vlo && rowl < vhi;
+        const bool rowupd = rowl < nrows && rowl >= lo && rowl < hi;
+        d4 zacc = d4{0, 0, 0, 0};
+        d4 z;
+        double za[QS];
+#pragma unroll
+        for (int pos = 0; pos < 2 * NB; ++pos) {
+            const int b = pos & (NB - 1);
+            d4 (&xa)[2] = rx[pos & (RING - 1)];
+            unsigned (&ma)[2] = rm[pos & (RING - 1)];
+            if (pos < NB) {
+                // ---- A: recompute what the sweep before left unstored, then this block's part of Z.  All operands of the block
+                // are requested from LDS first (one wait per block, not one per product: a single wavefront per SIMD has nobody
+                // to hide an LDS round trip behind), the ones of the recomputation ahead of the ones of the Z product.
+                if (FULL || 2 * b < DT) {
+                    double wxo[2][QS], gzo[2][4]; d4 mxo[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = (FULL || 2 * b + jj < DT) ? 2 * b + jj : 2 * b;
+                        mxo[jj] = *reinterpret_cast<const d4*>(mxL + 16 * j + 4 * qk);
+#pragma unroll
+                        for (int s4 = 0; s4 < QS; ++s4) wxo[jj][s4] = wxL[(j * 4 + s4) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = (FULL || 2 * b + jj < DT) ? 2 * b + jj : 2 * b;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gzo[jj][e] = gzL[(j * 4 + e) * 64 + lane];
+                    }
+                    d4 pred[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {            // the two recomputations side by side (independent chains)
+                        pred[jj] = mxo[jj];
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < QS; ++s4)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) pred[jj] = MFMA(wxo[jj][s4], zq[s4], pred[jj]);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        if (FULL || 2 * b + jj < DT) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (rowv && ((ma[jj] >> (8 * e)) & 0xffu) == 0) xa[jj][e] = pred[jj][e];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) zacc = MFMA(xa[jj][e], gzo[jj][e], zacc);
+                        }
+                    }
+                }
+            } else {
+                // ---- C: prediction, imputation, statistics of this block
+                if (FULL || 2 * b < DT) {
+                    double wao[2][QS]; d4 muo[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = (FULL || 2 * b + jj < DT) ? 2 * b + jj : 2 * b;
+                        muo[jj] = *reinterpret_cast<const d4*>(muL + 16 * j + 4 * qk);
+#pragma unroll
+                        for (int s4 = 0; s4 < QS; ++s4) wao[jj][s4] = waL[(j * 4 + s4) * 64 + lane];
+                    }
+                    d4 pred[2] = {muo[0], muo[1]};
+#pragma unroll
+                    for (int s4 = 0; s4 < QS; ++s4)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) pred[jj] = MFMA(wao[jj][s4], za[s4], pred[jj]);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        d4 v = xa[jj];
+                        if (FULL || 2 * b + jj < DT) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (rowupd && ((ma[jj] >> (8 * e)) & 0xffu) == 0) v[e] = pred[jj][e];
+                        } else v = d4{0, 0, 0, 0};
+                        *reinterpret_cast<d4*>(xtw + c * P12_XS + 16 * jj + 4 * qk) = v;
+                    }
+                    wave_lds_sync();
+                    d4 xn[2];
+                    d2 v2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v2[r] = *reinterpret_cast<const d2*>(xtw + (4 * r + qk) * P12_XS + 2 * c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool live = (n0 + 4 * r + qk < nrows) && (FULL || 32 * b + 2 * c < DP);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const double x = live ? v2[r][p] : 0.0;
+                            xn[p][r] = x; sx[b][p] += x; sxx += x * x;
+                        }
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) sxz[b][p] = MFMA(xn[p][s4], z[s4], sxz[b][p]);
+                    wave_lds_sync();                    // the piece has been read: the next block may overwrite it
+                }
+            }
+            // the set of three positions on: same tile while it lasts, then the wavefront's next tile
+            {
+                const int np = pos + AHEAD;
+                if (np < 2 * NB) fetch(rx[np & (RING - 1)], rm[np & (RING - 1)], t, np & (NB - 1));
+                else fetch(rx[np & (RING - 1)], rm[np & (RING - 1)], tnext, np - 2 * NB);
+            }
+            if (pos == NB - 1) {
+                // ---- B: the tile's z (accumulator layout: lane (qk, c), register r = row 4 r + qk, latent index c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned row = n0 + 4 * r + qk;
+                    double v = zacc[r] - g0c;
+                    const bool keep = z0_here && row == 0;      // z_0 was stored by Xs[0].update() itself (keep_z0)
+                    v = keep ? z0keep : v;
+                    if (row < nrows) { if (!keep) Zc[(size_t)row * QP + c] = v; }
+                    else v = 0.0;
+                    z[r] = v; sz += v;
+                    zTw[c * 17 + 4 * r + qk] = v;
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) szz = MFMA(z[s4], z[s4], szz);
+                zfetch(zq, tnext);                      // rows of this wavefront's next tile: nobody writes them before it does
+                wave_lds_sync();
+#pragma unroll
+                for (int s4 = 0; s4 < QS; ++s4) za[s4] = zTw[(4 * s4 + qk) * 17 + c];
+            }
+        }
+    }
+    // ---- the wavefronts' sums into one per workgroup, in wavefront order (LDS: the tables are done with)
+    __syncthreads();
+    double* const red = ldsr;           // [Sxz 256 x 16 | sx 256 | Szz 16 x 16 | sz 16 | sxx]
+    for (int w = 0; w < PR_NW; ++w) {
+        if (wave == w) {
+            const bool first = w == 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int dim = 32 * b + 2 * (4 * r + qk) + p;
+                        double* o = red + (size_t)dim * QP + c;
+                        *o = first ? sxz[b][p][r] : *o + sxz[b][p][r];
+                    }
+                    double s = sx[b][p];
+                    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                    if (qk == 0) { double* o = red + 4096 + 32 * b + 2 * c + p; *o = first ? s : *o + s; }
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { double* o = red + 4352 + (4 * r + qk) * QP + c; *o = first ? szz[r] : *o + szz[r]; }
+            double s = sz;
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            if (qk == 0) { double* o = red + 4608 + c; *o = first ? s : *o + s; }
+            const double sq = wsum(sxx);
+            if (lane == 0) { double* o = red + 4624; *o = first ? sq : *o + sq; }
+        }
+        __syncthreads();
+    }
+    double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
+    for (int i = tid; i < DP * QP; i += 64 * PR_NW) P[a.SL.oSxz + i] = red[i];
+    for (int i = tid; i < DP; i += 64 * PR_NW) P[a.SL.osx + i] = red[4096 + i];
+    for (int i = tid; i < QP * QP; i += 64 * PR_NW) P[a.SL.oSzz + i] = red[4352 + i];
+    if (tid < QP) P[a.SL.osz + tid] = red[4608 + tid];
+    if (tid < a.DT) P[a.SL.total + tid] = tid == 0 ? red[4624] : 0.0;
+}
+
 // The missing entries of rows [vin_lo, vin_hi) into X: <W>_x z_n + <Mu>_x, formed exactly as stage 0 of k_pca_pass12<.., LAZY> forms
 // them (same operands, same chain of MFMAs: bit for bit what the next sweep would have used).  Same mapping: a workgroup per row
 // chunk, wavefront w on columns [32 w, 32 w + 32).
@@ -1127,6 +1406,7 @@ int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
     else { if (pin) hipLaunchKernelGGL((k_pca_pass2<2, true>), grid, block, 0, h->stream, a); else hipLaunchKernelGGL((k_pca_pass2<2, false>), grid, block, 0, h->stream, a); }
     hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
+    h->part_chunks = h->nchunk;
     return PYVB_OK;
 }
 
@@ -1156,6 +1436,27 @@ int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
     a.keep_z0 = h->z0_done ? 1 : 0;
     if (lazy && h->xlazy) { a.vin_lo = h->vlo; a.vin_hi = h->vhi; }
     a.save_wx = lazy ? 1 : 0;
+    if (lazy && h->rows_ok) {
+        // the row-owning sweep (k_pca_rows) on its own partition of the rows: one workgroup per CU, equal shares of 16-row tiles
+        a.nchunk = h->nchunkB; a.chunk_rows = h->chunk_rowsB;
+        size_t need = 3 * (size_t)h->DT * 256 + 2 * (size_t)h->DP + 16 + PR_NW * (16 * 17 + 16 * P12_XS);
+        if (need < 4640) need = 4640;                   // the final reduction's buffer
+        const size_t lds = need * sizeof(double);
+        static bool attr_set[64] = {};
+        if (h->device < 64 && !attr_set[h->device]) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_pca_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void*)k_pca_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[h->device] = true;
+        }
+        if (h->DT == 16) hipLaunchKernelGGL(k_pca_rows<true>, dim3(a.nchunk), dim3(64 * PR_NW), lds, h->stream, a);
+        else hipLaunchKernelGGL(k_pca_rows<false>, dim3(a.nchunk), dim3(64 * PR_NW), lds, h->stream, a);
+        hipLaunchKernelGGL(k_pca_rowvar, dim3(a.nchunk), dim3(256), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+        h->part_chunks = a.nchunk;
+        h->xlazy = true; h->vlo = lo_upd; h->vhi = hi_upd;
+        return PYVB_OK;
+    }
+    h->part_chunks = h->nchunk;
     const unsigned nw = (h->DT + P2T - 1) / P2T;          // wavefronts per workgroup: 32 columns each
     const size_t rt = h->QT == 1 ? 2 : 1;                 // k_pca_pass12: RT
     const size_t lds = (rt * ((size_t)nw * h->QT * 256 + 2 * (size_t)h->QT * 256 + 2 * (size_t)h->QT * 16 * 17 + (size_t)nw * 16 * P12_XS) + (lazy ? h->DP : 0)) * sizeof(double);
@@ -1186,6 +1487,7 @@ int pca_launch_rowqld(pyvb_pca* h, double* out) {
 
 int pca_launch_reduce(pyvb_pca* h, int what) {
     PcaArgs a = pca_args(h);
+    if (what == 0 && h->part_chunks > 0) a.nchunk = h->part_chunks;     // the partition of the sweep that wrote the partials
     const size_t n = what == 1 ? (size_t)h->QP : h->SL.total;
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_pca_reduce, dim3(nb, PCA_RED), dim3(256), 0, h->stream, a, what, 0, h->red2);

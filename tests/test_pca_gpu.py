@@ -55,6 +55,65 @@ def test_golden_fixtures(path):
     b.close()
 
 
+@pytest.mark.parametrize("path", [f for f in FILES if "default_init" not in f], ids=lambda p: os.path.basename(p)[4:-4])
+def test_golden_fixtures_through_the_row_owning_sweep(path, monkeypatch):
+    """k_pca_rows (a wavefront owns whole rows; PYVB_PCA_SWEEP=rows at handle creation): measured slower than the sweep in use
+    (pyvb_amd/csrc/k_pca.hip) and kept as an alternative -- it has to give the reference's numbers all the same."""
+    from pyvb_amd.pca import PCABatch
+    monkeypatch.setenv("PYVB_PCA_SWEEP", "rows")
+    N, d, q, init, pri, z = _load(path)
+    b = PCABatch.from_problem(init, pri)
+    for it in range(1, int(max(z["iters"])) + 1):
+        b.iterate(1)
+        if it in z["iters"]:
+            tag = "it%d_" % it
+            g = b.get_state()
+            for k in ("W_mean", "W_var", "Z", "Z_cov", "X", "Mu_mean", "Mu_var", "beta_a", "beta_b"):
+                _close(g[k], z[tag + k], tag + k)
+            parts = b.elbo()
+            ref = z[tag + "elbo_parts"]
+            assert np.all(np.abs(parts - ref) <= RTOL * np.abs(ref).sum()), (parts, ref)
+    b.close()
+
+
+@pytest.mark.parametrize("sweep", ["columns", "rows"])
+def test_imputed_entries_are_recomputed_not_stored(sweep, monkeypatch):
+    """Round 4: the sweep of an iteration leaves the imputed entries of X unstored (they are <W> z_n + <Mu> of what IS stored; the
+    next sweep recomputes them, pyvb_pca_get_state and every other reader has them put into X first: pca_materialize_x).  A run
+    that is interrupted by reads, by a partial row update and by a Z update of its own ends bitwise where an uninterrupted one
+    ends, and both agree with a handle that stores the entries (PYVB_PCA_WRITEBACK=1) to rounding."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    from pyvb_amd.pca import PCABatch
+    N, d, q = 3000, 250, 16
+    init, pri = G.pca_problem(N, d, q, seed=77)
+    monkeypatch.setenv("PYVB_PCA_SWEEP", sweep)
+    a = PCABatch.from_problem(init, pri); a.iterate(5); sa = a.get_state(); ea = a.elbo(); a.close()
+    b = PCABatch.from_problem(init, pri)
+    b.iterate(2)
+    mid = b.get_state()                                 # materialises X
+    assert np.isfinite(mid["X"]).all()
+    b.iterate(1)
+    b.elbo()
+    b.iterate(2)
+    sb = b.get_state(); eb = b.elbo(); b.close()
+    for k in ("X", "Z", "W_mean", "Mu_mean", "beta_b"):
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(ea, eb)
+    monkeypatch.setenv("PYVB_PCA_WRITEBACK", "1")
+    c = PCABatch.from_problem(init, pri); c.iterate(5); sc = c.get_state(); ec = c.elbo(); c.close()
+    for k in ("X", "Z", "W_mean", "Mu_mean"):
+        _close(sa[k], sc[k], "lazy vs stored: " + k)
+    assert np.all(np.abs(ea - ec) <= 1e-10 * np.abs(ec).sum())
+    # the oracle, too
+    st = P.make_state(init, pri, N, d, q)
+    for _ in range(5):
+        ref = P.iterate(st, pri)
+    _close(sa["X"], st["X"], "X after five iterations")
+    assert np.all(np.abs(ea - ref) <= RTOL * np.abs(ref).sum())
+
+
 @pytest.mark.parametrize("N,d,q", [(300, 20, 4), (1000, 64, 16), (77, 33, 17), (5000, 256, 16), (16, 3, 1), (17, 250, 31)])
 def test_stagewise_vs_oracle(N, d, q):
     import importlib.util
