@@ -40,7 +40,7 @@ typedef struct pyvb_lds pyvb_lds;
 
 typedef enum {
     PYVB_OK = 0,
-    PYVB_E_ARG = 1,          /* bad argument (shape limits: 2 <= T, 1 <= D,K <= 64) */
+    PYVB_E_ARG = 1,          /* bad argument (shape limits: 2 <= T, 1 <= D,K <= 128; with Wishart noise D,K <= 64) */
     PYVB_E_HIP = 2,          /* HIP runtime error */
     PYVB_E_LINALG = 3,       /* a posterior precision was not positive definite (numpy LinAlgError in the reference) */
     PYVB_E_STALE = 4,        /* statistics requested while the X_t were updated under different parameters */

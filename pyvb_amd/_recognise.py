@@ -7,9 +7,11 @@ the reference's examples/Linear_Dynamic_System.py:46-66 --
     X_0 ~ N(Constant, Constant)      X_t ~ N(A * X_{t-1}, Q)      Y_t ~ N(C * X_t, R), observed
     Q, R both DiagonalGamma or both Gamma
 
--- it builds an `LDSPlan`: the posterior state is uploaded into a one-replicate LDSBatch and every
-node of the graph is pointed at the plan.  Anything else raises NotImplementedError (there is no
-CPU execution path).
+-- it builds an `LDSPlan`: the graph becomes one replicate of an LDSBatch, which it shares with every other
+graph of the same structure that is waiting to run (LDSGroup), and every node of the graph is pointed at the
+plan.  The VB-PCA graph of examples/PCA_missing_data.py gets a `PCAPlan`; any other graph -- `describe` signals
+it with NotImplementedError, which `bind` catches -- the node-by-node plan of pyvb_amd/generic.py.  All of them
+run on the device: there is no CPU execution path.
 """
 import hashlib
 import weakref
@@ -581,8 +583,8 @@ def _component(start):
 
 
 def _fail(why):
-    raise NotImplementedError("this graph has no HIP plan (%s); pyvb_amd executes the linear-dynamical-system graph of "
-                              "examples/Linear_Dynamic_System.py only and has no CPU fallback" % why)
+    """Not the graph a fused plan serves: `bind` catches this and gives the graph the node-by-node plan."""
+    raise NotImplementedError("not a graph of the fused kernels (%s)" % why)
 
 
 def _diag_constant(node, what):

@@ -837,10 +837,9 @@ int launch_prep_big(pyvb_lds* h) {
     a.warm = h->warm; a.status = h->status;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L;
     const size_t lds = ((size_t)BDP * BLD + 4 * BDP + 2 * GJB_BUF + BDP) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!h->big_attr_prep) {           // per handle: the attribute belongs to the device the handle lives on
         HIPCHK(hipFuncSetAttribute((const void*)k_prep_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        h->big_attr_prep = true;
     }
     {
         TimedLaunch tl(h, PYVB_K_PREP);
@@ -994,10 +993,9 @@ int launch_cols_big(pyvb_lds* h, int which, int c0, int c1, int fuse) {
     ParamArgs a = make_args(h);
     a.c0 = c0; a.c1 = c1; a.which0 = which == 1 ? 1 : 0; a.fuse = fuse;
     const size_t lds = ((size_t)BDP * BDP + 9 * BDP + 8) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!h->big_attr_cols) {
         HIPCHK(hipFuncSetAttribute((const void*)k_cols_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        h->big_attr_cols = true;
     }
     TimedLaunch tl(h, PYVB_K_PARAMS);
     hipLaunchKernelGGL(k_cols_big, dim3(h->N, which == 2 ? 2 : 1), dim3(256), lds, h->stream, a);

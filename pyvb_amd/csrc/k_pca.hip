@@ -1442,11 +1442,10 @@ int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
         size_t need = 3 * (size_t)h->DT * 256 + 2 * (size_t)h->DP + 16 + PR_NW * (16 * 17 + 16 * P12_XS);
         if (need < 4640) need = 4640;                   // the final reduction's buffer
         const size_t lds = need * sizeof(double);
-        static bool attr_set[64] = {};
-        if (h->device < 64 && !attr_set[h->device]) {
+        if (!h->rows_attr_set) {
             HIPCHK(hipFuncSetAttribute((const void*)k_pca_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIPCHK(hipFuncSetAttribute((const void*)k_pca_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set[h->device] = true;
+            h->rows_attr_set = true;
         }
         if (h->DT == 16) hipLaunchKernelGGL(k_pca_rows<true>, dim3(a.nchunk), dim3(64 * PR_NW), lds, h->stream, a);
         else hipLaunchKernelGGL(k_pca_rows<false>, dim3(a.nchunk), dim3(64 * PR_NW), lds, h->stream, a);

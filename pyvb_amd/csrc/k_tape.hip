@@ -375,6 +375,7 @@ __global__ void __launch_bounds__(64 * BW) k_tape_cached(TapeArgs t, const int* 
 
 struct pyvb_graph {
     int device;
+    bool lds_attr_set;                               // the dynamic-LDS limit of k_tape_cached is raised on this graph's device
     hipStream_t stream;
     double* arena; size_t arena_n;
     int* status;
@@ -751,12 +752,11 @@ int pyvb_graph_tape_run(pyvb_graph* g, int tape_id) {
     TapeArgs t; t.arena = g->arena; t.arena_n = g->arena_n; t.ops = g->tapes[tape_id]; t.nops = g->tape_len[tape_id]; t.status = g->status;
     if (g->c_ops[tape_id]) {
         // the window form: one workgroup per block, its working set in LDS
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!g->lds_attr_set) {            // per graph (= per device the graph lives on; a handle is used by one host thread)
             const int cap = (int)((TAPE_LDS_CAP + 2 + TAPE_CHUNK * 4) * sizeof(double));
             HIPCHK(hipFuncSetAttribute((const void*)k_tape_cached<TAPE_BUNDLE>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
             HIPCHK(hipFuncSetAttribute((const void*)k_tape_cached<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-            attr_set = true;
+            g->lds_attr_set = true;
         }
         t.ops = g->c_ops[tape_id];
         static const std::vector<int> single{0, 1};

@@ -63,6 +63,7 @@ struct pyvb_pca {
     bool rows_ok;                        // PYVB_PCA_SWEEP=rows at creation: the lazy sweep is k_pca_rows instead of k_pca_pass12<.., LAZY>
     int nchunkB; long chunk_rowsB;       // k_pca_rows' partition of the rows: a workgroup per CU
     int part_chunks;                     // chunks of the partial statistics in `part` now
+    bool rows_attr_set;
     pyvb_comm* comm; int rank, world;
 };
 

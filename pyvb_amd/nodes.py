@@ -315,14 +315,14 @@ class Gaussian(Node):
     def pass_up_m1_m2(self, requester):         # gaussian.py:179-183
         return _messages_of(self, requester)
 
-    def pass_down_Ex(self):
+    def pass_down_Ex(self):                     # gaussian.py:154-160: the posterior mean as it is
         return self.qmu
 
-    def pass_down_ExxT(self):
-        return np.dot(self.qmu, self.qmu.T) + self.qcov
+    def pass_down_ExxT(self):                   # gaussian.py:162-168, on the device (GenericPlan._exxt)
+        return _expectation_of(self, "ExxT")
 
-    def pass_down_ExTx(self):
-        return np.trace(self.pass_down_ExxT())
+    def pass_down_ExTx(self):                   # gaussian.py:170-177
+        return float(np.asarray(_expectation_of(self, "ExTx")).reshape(-1)[0])
 
 
 class DiagonalGaussian(Gaussian):               # gaussian.py:185-203
@@ -330,11 +330,11 @@ class DiagonalGaussian(Gaussian):               # gaussian.py:185-203
         Gaussian.__init__(self, dim, pmu, pprec)
         self.shape = (self.shape[0], self.shape[0])
 
-    def pass_down_Ex(self):
-        return np.diag(self.qmu[:, 0])
+    def pass_down_Ex(self):                     # gaussian.py:198-199
+        return _expectation_of(self, "Ex")
 
-    def pass_down_ExxT(self):
-        return np.diag(self.qmu[:, 0] * self.qmu[:, 0] + np.diag(self.qcov))
+    def pass_down_ExxT(self):                   # gaussian.py:200-201
+        return _expectation_of(self, "ExxT")
 
     def pass_down_ExTx(self):
         return self.pass_down_ExxT()
@@ -436,12 +436,8 @@ class Wishart(_NoiseNode):                      # nodes_todo.py:205-234
         for child in self.children:
             self.qv += 0.5
 
-    def _sym(self):
-        w = np.asarray(self.qw, dtype=float)
-        return 0.5 * (w + w.T)
-
-    def pass_down_Ex(self):
-        return self.qv * np.linalg.inv(self._sym())
+    def pass_down_Ex(self):                     # nodes_todo.py:233-234, on the device (GenericPlan._ex: the symmetric part of qw)
+        return _expectation_of(self, "Ex")
 
     def pass_down_lndet(self):                  # not in the reference (Q8): ln det of the expectation, as Gamma does (Q2)
-        return self.shape[0] * np.log(self.qv) - np.linalg.slogdet(self._sym())[1]
+        return float(np.asarray(_expectation_of(self, "lndet")).reshape(-1)[0])
