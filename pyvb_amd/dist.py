@@ -160,10 +160,20 @@ def _send(sock, obj):
     sock.sendall(tag + struct.pack("<I", len(data)) + data)
 
 
-def _recv(sock):
+HELLO_FRAME = 4096          # cap on a frame before the peer is admitted
+
+
+def _recv(sock, cap=MAX_FRAME, deadline=None):
+    """One frame.  cap: largest payload accepted; deadline: wall-clock time by which the WHOLE frame must have arrived (the
+    socket's own time-out applies per recv() call, so a peer that trickles bytes could otherwise hold a connection open)."""
     def exact(n):
         buf = bytearray()
         while len(buf) < n:
+            if deadline is not None:
+                left = deadline - time.time()
+                if left <= 0:
+                    raise TimeoutError("rendezvous frame not complete in time")
+                sock.settimeout(left)
             chunk = sock.recv(min(n - len(buf), 1 << 20))
             if not chunk:
                 raise ConnectionError("peer closed the rendezvous connection")
@@ -171,8 +181,8 @@ def _recv(sock):
         return bytes(buf)
     head = exact(5)
     (n,) = struct.unpack("<I", head[1:])
-    if n > MAX_FRAME:
-        raise ConnectionError("rendezvous frame of %d bytes exceeds the cap of %d" % (n, MAX_FRAME))
+    if n > cap:
+        raise ConnectionError("rendezvous frame of %d bytes exceeds the cap of %d" % (n, cap))
     return _unpack(head[:1], exact(n))
 
 
@@ -184,12 +194,16 @@ class SocketComm(object):
     """Rank 0 listens, the others connect (MASTER_ADDR; a port derived from MASTER_PORT, which the launcher's own store
     occupies); every collective is a gather to rank 0 and a broadcast back.  A few bytes per call, a few calls per run.
 
-    Admission: rank 0 sends a random challenge; the peer answers with a hello object (protocol token, run id, base port,
-    world size, its rank) and an HMAC-SHA256 of challenge + hello under a shared secret.  On the loopback interface the
-    secret defaults to a fixed string (any local process could read the environment anyway); for any other MASTER_ADDR it
-    must come from PYVB_RENDEZVOUS_SECRET, identical on every rank, or the constructor refuses to run."""
-    TOKEN = "pyvb-rendezvous-2"
-    HELLO_TIMEOUT = 5.0          # per connection attempt, until the peer has been admitted
+    Admission is mutual: rank 0 sends a random challenge; the peer answers with a hello object (protocol token, run id, base
+    port, world size, its rank), an HMAC-SHA256 of challenge + hello under a shared secret, and a challenge of its own; rank
+    0 admits it only on a correct MAC and answers with the verdict and the MAC of the peer's challenge, which the peer checks
+    before it trusts the listener (a rogue listener on one of the derived ports cannot admit ranks).  Every handshake has one
+    wall-clock deadline (HELLO_TIMEOUT) and frames before admission are capped at 4 KB.  Frames after admission carry no
+    MAC: integrity on a network that is not trusted is out of scope (one node, loopback, is what bench.py uses).  On the
+    loopback interface the secret defaults to a fixed string (any local process could read the environment anyway); for any
+    other MASTER_ADDR it must come from PYVB_RENDEZVOUS_SECRET, identical on every rank, or the constructor refuses to run."""
+    TOKEN = "pyvb-rendezvous-3"
+    HELLO_TIMEOUT = 5.0          # wall-clock limit of one handshake
 
     def __init__(self, world, rank, timeout=180.0):
         self.world, self.rank = int(world), int(rank)
@@ -235,17 +249,20 @@ class SocketComm(object):
                     continue
                 try:
                     c.settimeout(self.HELLO_TIMEOUT)
+                    until = time.time() + self.HELLO_TIMEOUT
                     challenge = os.urandom(32)
                     _send(c, challenge)
-                    msg, tag = _recv(c), _recv(c)
+                    msg, tag, theirs = (_recv(c, HELLO_FRAME, until), _recv(c, HELLO_FRAME, until), _recv(c, HELLO_FRAME, until))
                     r = msg.get("rank") if isinstance(msg, dict) else None
                     good = (isinstance(r, int) and 0 < r < self.world and r not in self.peers
                             and {k: msg.get(k) for k in hello} == hello
-                            and isinstance(tag, bytes) and hmac.compare_digest(tag, mac(challenge, msg)))
+                            and isinstance(tag, bytes) and hmac.compare_digest(tag, mac(challenge, msg))
+                            and isinstance(theirs, bytes) and len(theirs) == 32)
                     _send(c, 1 if good else 0)
                     if not good:
                         c.close()
                         continue
+                    _send(c, mac(theirs, dict(hello, rank=0)))         # proof that the listener knows the secret too
                     c.settimeout(timeout)
                     self.peers[r] = c
                 except Exception:               # a stranger, a garbled frame, a stalled peer: drop it, keep listening
@@ -262,12 +279,18 @@ class SocketComm(object):
                     try:
                         c = socket.create_connection((addr, p), timeout=2.0)
                         c.settimeout(self.HELLO_TIMEOUT)
-                        challenge = _recv(c)
+                        until = time.time() + self.HELLO_TIMEOUT
+                        challenge = _recv(c, HELLO_FRAME, until)
                         if not isinstance(challenge, bytes) or len(challenge) != 32:
                             raise ConnectionError("not a pyvb rendezvous")
+                        own = os.urandom(32)
                         _send(c, mine)
                         _send(c, mac(challenge, mine))
-                        if _recv(c) == 1:
+                        _send(c, own)
+                        if _recv(c, HELLO_FRAME, until) == 1:
+                            proof = _recv(c, HELLO_FRAME, until)
+                            if not (isinstance(proof, bytes) and hmac.compare_digest(proof, mac(own, dict(hello, rank=0)))):
+                                raise ConnectionError("the listener does not know the rendezvous secret")
                             c.settimeout(timeout)
                             self.sock = c
                             break

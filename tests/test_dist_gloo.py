@@ -163,9 +163,19 @@ def test_rendezvous_refuses_strangers_and_non_loopback_without_secret(monkeypatc
     ch = dist._recv(s)
     dist._send(s, {"token": dist.SocketComm.TOKEN, "run": "none", "base": base, "world": 2, "rank": 1})
     dist._send(s, b"\x00" * 32)                                     # right hello, wrong MAC
+    dist._send(s, b"\x01" * 32)                                     # (the peer's own challenge)
     assert dist._recv(s) == 0
     s.close()
+    # a stranger that trickles: half a frame header and then nothing -- the handshake has ONE deadline, the listener moves on
+    t0 = time.time()
+    s = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+    dist._recv(s)
+    s.sendall(b"J\x10")
+    # an oversized frame before admission is refused without being read
+    s2 = socket.create_connection(("127.0.0.1", port), timeout=10.0)
     peer = dist.SocketComm(2, 1, timeout=30.0)                      # the real rank 1 still gets in
+    assert time.time() - t0 < 3 * dist.SocketComm.HELLO_TIMEOUT + 5
+    s.close(); s2.close()
     th.join(60)
     assert not th.is_alive()
     t = threading.Thread(target=lambda: box.__setitem__("m", box["c"].max_float(1.0)))
@@ -175,3 +185,41 @@ def test_rendezvous_refuses_strangers_and_non_loopback_without_secret(monkeypatc
     assert box["m"] == 3.0
     peer.close()
     box["c"].close()
+
+
+def test_a_listener_that_does_not_know_the_secret_admits_nobody(monkeypatch):
+    """The handshake is mutual: a rogue listener on one of the derived ports can collect a hello and its MAC, but it cannot
+    answer the peer's own challenge, and the peer walks away from it."""
+    import socket
+    import threading
+    import time
+    from pyvb_amd import dist
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29561")
+    monkeypatch.delenv("PYVB_RENDEZVOUS_SECRET", raising=False)
+    base = 29561
+    port = 20000 + (base * 31) % 30000
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", port)); srv.listen(4); srv.settimeout(20.0)
+    seen = {}
+
+    def rogue():
+        try:
+            c, _ = srv.accept()
+            c.settimeout(5.0)
+            dist._send(c, b"\x07" * 32)
+            seen["hello"] = dist._recv(c); dist._recv(c); seen["theirs"] = dist._recv(c)
+            dist._send(c, 1)                         # "admitted" ...
+            dist._send(c, b"\x00" * 32)              # ... but no proof
+            time.sleep(0.5)
+            c.close()
+        except Exception as e:                       # noqa
+            seen["err"] = repr(e)
+    th = threading.Thread(target=rogue)
+    th.start()
+    with pytest.raises(TimeoutError):
+        dist.SocketComm(2, 1, timeout=4.0)           # never connected: the only listener failed the proof
+    th.join(30)
+    srv.close()
+    assert isinstance(seen.get("theirs"), bytes) and seen["hello"]["rank"] == 1
