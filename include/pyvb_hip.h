@@ -40,7 +40,7 @@ typedef struct pyvb_lds pyvb_lds;
 
 typedef enum {
     PYVB_OK = 0,
-    PYVB_E_ARG = 1,          /* bad argument (shape limits: 2 <= T, 1 <= D,K <= 128; with Wishart noise D,K <= 64) */
+    PYVB_E_ARG = 1,          /* bad argument (shape limits: 2 <= T, 1 <= D,K <= 128) */
     PYVB_E_HIP = 2,          /* HIP runtime error */
     PYVB_E_LINALG = 3,       /* a posterior precision was not positive definite (numpy LinAlgError in the reference) */
     PYVB_E_STALE = 4,        /* statistics requested while the X_t were updated under different parameters */
@@ -85,7 +85,9 @@ int pyvb_lds_set_priors(pyvb_lds* h, const double* x0_mean, const double* x0_pre
  * (whose Gamma arguments may then be NULL).  State: qv (fixed by the graph, update_v :224-227) and qw ([N][D][D] /
  * [N][K][K], update :228-231); E[Lambda] = qv * inv(qw) (:233-234).  The columns of A and C then have dense posterior
  * covariances A_cov[N][D][D][D] (column i: [D][D]) and C_cov[N][D][K][K]; pyvb_lds_set_state's A_colvar / C_colvar give
- * diagonal initial ones.  Deviations from the unfinished reference class (prior not mutated by update(), symmetric part
+ * diagonal initial ones.  Above 64 dimensions (k_wishart_big.hip) Wishart noise does not combine with known entries of A / C or
+ * with outputs that hold NaN: pyvb_lds_set_column_observations / pyvb_lds_set_observations return PYVB_E_UNSUPPORTED there.
+ * Deviations from the unfinished reference class (prior not mutated by update(), symmetric part
  * of qw in the expectation, a defined lower bound) are listed at the top of pyvb_amd/csrc/k_wishart.hip. */
 int pyvb_lds_set_wishart_priors(pyvb_lds* h, double Q_v0, const double* Q_w0, double R_v0, const double* R_w0);
 int pyvb_lds_set_wishart_state(pyvb_lds* h, const double* Q_w, const double* R_w);

@@ -649,8 +649,8 @@ def describe(start):
         _fail("the fused LDS kernels take D, K <= 128")
     big = D > 64 or K > 64          # the workgroup-per-replicate kernels (pyvb_amd/csrc/k_big.hip): the plain graph only
     Q, R = Xs[1].precision_parent, Ys[0].precision_parent
-    if big and isinstance(Q, N.Wishart):
-        _fail("above 64 dimensions the fused kernels serve Gamma / DiagonalGamma noise")
+    if big and isinstance(Q, N.Wishart) and (any(not y.observed for y in Ys) or any(c.observed or c.partially_observed for c in A.parents + C.parents)):
+        _fail("above 64 dimensions Wishart noise does not combine with known entries of A / C or outputs that hold NaN")
     if Q is R or any(x.precision_parent is not Q for x in Xs[1:]) or any(y.precision_parent is not R for y in Ys):
         _fail("noise precisions are not shared along the chain")
     if any(x.partially_observed or x.observed for x in Xs):

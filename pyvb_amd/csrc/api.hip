@@ -74,7 +74,6 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     ARGCHK(D >= 1 && D <= 128, "latent dimension D must be in 1..128");
     ARGCHK(K >= 1 && K <= 128, "observed dimension K must be in 1..128");
     ARGCHK(noise_kind == PYVB_NOISE_DIAGONAL_GAMMA || noise_kind == PYVB_NOISE_GAMMA || noise_kind == PYVB_NOISE_WISHART, "unknown noise kind");
-    ARGCHK(noise_kind != PYVB_NOISE_WISHART || (D <= 64 && K <= 64), "with Wishart noise D and K must be in 1..64");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     ARGCHK(device >= 0 && device < ndev, "no such device");
@@ -167,7 +166,7 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
         TRY(dev_alloc(&h->A_cov, n * D * cov_stride(D))); TRY(dev_alloc(&h->C_cov, n * D * cov_stride(K)));
         TRY(dev_alloc(&h->SyyF, n * K * K));
         TRY(dev_alloc(&h->RQ, n * D * D)); TRY(dev_alloc(&h->RR, n * K * K));
-        TRY(dev_alloc(&h->SG, n * 2 * 64 * 64));
+        TRY(dev_alloc(&h->SG, h->big ? n * 2 * 128 * 128 : n * 2 * 64 * 64));
         TRY(dev_alloc(&h->ldm, n * 2 * D));
     }
     TRYHIP(hipMemset(h->pri.A_obs, 0xFF, ((size_t)D * D + (size_t)K * D) * sizeof(double)));     // all-ones bytes = NaN = nothing observed
@@ -417,6 +416,10 @@ int pyvb_lds_get_column_cov(pyvb_lds* h, double* A_cov, double* C_cov) {
 
 int pyvb_lds_set_column_observations(pyvb_lds* h, const double* A_obs, const double* C_obs) {
     ENTER(h);
+    if (h->dense && h->big) {
+        pyvb_set_error("with Wishart noise, known entries of A / C are served for D, K <= 64 only (k_wishart_big.hip)");
+        return PYVB_E_UNSUPPORTED;
+    }
     int rc;
     if ((rc = h2d(h, h->pri.A_obs, A_obs, (size_t)h->D * h->D))) return rc;
     if ((rc = h2d(h, h->pri.C_obs, C_obs, (size_t)h->K * h->D))) return rc;
@@ -447,6 +450,10 @@ int pyvb_lds_set_observations(pyvb_lds* h, const double* Y) {
     bool missing = false;
     for (size_t i = 0; i < n && !missing; ++i) missing = Y[i] != Y[i];
     int rc;
+    if (missing && h->dense && h->big) {
+        pyvb_set_error("with Wishart noise, outputs that hold NaN are served for D, K <= 64 only (k_wishart_big.hip)");
+        return PYVB_E_UNSUPPORTED;
+    }
     if (missing) {
         if (!h->Yobs) {
             if ((rc = dev_alloc(&h->Yobs, n))) return rc;

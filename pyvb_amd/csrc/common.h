@@ -179,6 +179,12 @@ int launch_colvar_to_cov(pyvb_lds* h);              // A_var/C_var (diagonals) -
 int launch_cov_to_colvar(pyvb_lds* h);              // and back
 int launch_cov_observe(pyvb_lds* h);                // zero covariance of the fully known columns
 int launch_cov_convert(pyvb_lds* h, int which, double* dense, int n0, int count, int to_packed);   // dense [count][D][rows][rows] (device) <-> the tiles of replicates n0..
+// k_wishart_big.hip: the same on the second shape class (64 < max(D, K) <= 128)
+int launch_wexpect_big(pyvb_lds* h);
+int launch_dense_pre_big(pyvb_lds* h);
+int launch_cols_dense_big(pyvb_lds* h, int which, int c0, int c1);
+int launch_wresid_big(pyvb_lds* h, int which, int update);
+int launch_syy_full_big(pyvb_lds* h);
 // k_missing.hip
 int launch_missing_init(pyvb_lds* h, const double* Yq0, const double* Yrowvar0);     // device pointers or null
 int launch_impute(pyvb_lds* h);

@@ -205,3 +205,66 @@ __device__ static void gj_wave_subset(double (&v)[8][8], unsigned long long mask
     }
     gjw_sync();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 128-wide: the whole workgroup on one matrix (k_big.hip: k_prep_big; k_wishart_big.hip)
+// Inverse of the symmetric positive definite matrix held as 8 x 8 tiles by the 16 x 16 threads of the workgroup (thread
+// (a = tid / 16, b = tid % 16) owns elements (8a + ra, 8b + cb)), Gauss-Jordan without pivoting as gj.h; rc: [2][264] doubles
+// of LDS (row 128, column 128, 1/pivot), pivs: [128].
+#define GJB_BUF 264
+__device__ static void gj_wg128(double (&v)[8][8], int D, int tid, double* rc, double* pivs) {
+    const int a = tid >> 4, b = tid & 15;
+    if (a == 0) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) rc[8 * b + cb] = v[0][cb];
+    }
+    if (b == 0) {
+#pragma unroll
+        for (int ra = 0; ra < 8; ++ra) rc[128 + 8 * a + ra] = v[ra][0];
+    }
+    if (tid == 0) rc[256] = 1.0 / v[0][0];
+    int cur = 0;
+    for (int P = 0; 8 * P < D; ++P) {
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int p = 8 * P + pp;
+            if (p >= D) continue;                                   // block-uniform
+            const int P1 = (pp == 7) ? P + 1 : P, q1 = (pp + 1) & 7;
+            __syncthreads();
+            const double* row = rc + cur * GJB_BUF;
+            const double* col = row + 128;
+            double* nrow = rc + (cur ^ 1) * GJB_BUF;
+            double* ncol = nrow + 128;
+            const double d = row[256];
+            if (tid == 0) pivs[p] = row[p];
+            double rj[8], ci[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { rj[k] = row[8 * b + k] * d; ci[k] = col[8 * a + k]; }
+#pragma unroll
+            for (int ra = 0; ra < 8; ++ra)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) v[ra][cb] = __builtin_fma(-ci[ra], rj[cb], v[ra][cb]);
+            if (b == P) {
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) v[ra][pp] = -ci[ra] * d;
+            }
+            if (a == P) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) v[pp][cb] = (b == P && cb == pp) ? d : rj[cb];
+            }
+            if (a == P1) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) nrow[8 * b + cb] = v[q1][cb];
+            }
+            if (b == P1) {
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) ncol[8 * a + ra] = v[ra][q1];
+            }
+            if (a == P1 && b == P1) nrow[256] = 1.0 / v[q1][q1];
+            cur ^= 1;
+        }
+    }
+    __syncthreads();
+}
+

@@ -20,8 +20,10 @@
 // Reference methods as in the small kernels: Gaussian.update gaussian.py:102-123, Multiplication.pass_up_m1_m2 node.py:182-232,
 // hstack.pass_up_m1_m2 nodes_todo.py:43-62, Gamma / DiagonalGamma.update nodes_todo.py:130-138, :187-190.
 // Diagonal-Gamma and Gamma noise, known entries of A / C, outputs with NaN (k_missing.hip, two entries per lane) and single X_t
-// updates are served; Wishart noise stays on the 64-wide kernels (a larger graph of that kind runs node by node on the generic plan).
+// updates are served; Wishart noise too (k_wishart_big.hip: the dense expectations reach k_prep_big and the boundary nodes of the
+// sweeps as the products <Q><A>, <R><C>), though not together with known entries or outputs that hold NaN.
 #include "params.h"
+#include "gj.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -37,6 +39,7 @@
 struct BigSweepArgs {
     const double* Xold; double* Xnew; const double* Y; const double* gains; const int* warm;
     const double *A_mean, *C_mean;
+    const double *QA, *RC;      // Wishart noise: <Q><A> [D][D], <R><C> [K][D] per replicate (k_wishart_big.hip), else null
     double* U;          // [N][T][128]: c_t = R mu_{t-1} + G y_t of the interior nodes (MODE 1 writes, MODE 2 reads), accumulator order
     double* trash;      // [N][512]
     int N, T, D, K, dir;
@@ -47,11 +50,22 @@ struct BigSweepArgs {
 // nb(j): entry j of the one neighbour's mean.  vs: 128 doubles of LDS.  Every thread of the workgroup must call it.
 template <class NB>
 __device__ __forceinline__ double big_boundary(bool first, const double* g, const Layout& L, const double* Am, const double* Cm,
-                                               int D, int K, int tid, NB nb, const double* y, double* vs) {
+                                               int D, int K, int tid, NB nb, const double* y, double* vs,
+                                               const double* QA = nullptr, const double* RC = nullptr) {
     const double* qb = g + L.oqr;
     const double* rb = qb + BDP;
     double v = 0.0;
-    if (tid < D) {
+    if (QA) {                   // Wishart noise: dense expectations, QA = <Q><A>, RC = <R><C> (k_sweep.hip: boundary_update)
+        if (tid < D) {
+            if (first) {
+                v = g[L.ow0 + tid];
+                for (int i = 0; i < D; ++i) v += QA[(size_t)i * D + tid] * nb(i);
+            } else {
+                for (int j = 0; j < D; ++j) v += QA[(size_t)tid * D + j] * nb(j);
+            }
+            for (int k = 0; k < K; ++k) v += RC[(size_t)k * D + tid] * y[k];
+        }
+    } else if (tid < D) {
         if (first) {
             v = g[L.ow0 + tid];
             for (int i = 0; i < D; ++i) v += Am[(size_t)i * D + tid] * (qb[i] * nb(i));
@@ -182,11 +196,13 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
     const int t_first = fwd ? 0 : T - 1, t_last = fwd ? T - 1 : 0;
     const double* Am = a.A_mean + (size_t)n * D * D;
     const double* Cm = a.C_mean + (size_t)n * K * D;
+    const double* QAm = a.QA ? a.QA + (size_t)n * D * D : nullptr;
+    const double* RCm = a.RC ? a.RC + (size_t)n * K * D : nullptr;
 
     // ---- first boundary node: only the old neighbour
     {
         const double* xo = Xo + (size_t)(t_first + sgn) * BDP;
-        const double s = big_boundary(fwd, g, L, Am, Cm, D, K, tid, [&](int j) { return xo[xpos(j)]; }, Yn + (size_t)t_first * K, vs);
+        const double s = big_boundary(fwd, g, L, Am, Cm, D, K, tid, [&](int j) { return xo[xpos(j)]; }, Yn + (size_t)t_first * K, vs, QAm, RCm);
         if (tid < BDP) {
             Xn[(size_t)t_first * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
             xs[tid] = (tid < D) ? s : 0.0;
@@ -340,7 +356,7 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
     }
     // ---- closing boundary node: only the new neighbour
     {
-        const double s = big_boundary(!fwd, g, L, Am, Cm, D, K, tid, [&](int j) { return xs[j]; }, Yn + (size_t)t_last * K, vs);
+        const double s = big_boundary(!fwd, g, L, Am, Cm, D, K, tid, [&](int j) { return xs[j]; }, Yn + (size_t)t_last * K, vs, QAm, RCm);
         if (tid < BDP) Xn[(size_t)t_last * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
     }
 }
@@ -349,6 +365,7 @@ int launch_sweep_big(pyvb_lds* h, int direction) {
     BigSweepArgs a;
     a.Xold = h->X[h->cur]; a.Xnew = h->X[1 - h->cur]; a.Y = h->Y; a.gains = h->gains; a.warm = h->warm;
     a.A_mean = h->A_mean; a.C_mean = h->C_mean; a.trash = h->trash; a.U = h->U;
+    a.QA = h->dense ? h->QA : nullptr; a.RC = h->dense ? h->RC : nullptr;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
     // a backward sweep right behind a forward one (h->u_valid) reads c_t; anything else starts from G y_t
     const bool cached = direction == PYVB_BACKWARD && h->u_valid;
@@ -375,7 +392,7 @@ int launch_sweep_big(pyvb_lds* h, int direction) {
 
 // Xs[t].update() alone, in place in the current buffer (k_sweep.hip: k_step), thread = row
 struct BigStepArgs {
-    double* X; const double* Y; const double* gains; const double *A_mean, *C_mean;
+    double* X; const double* Y; const double* gains; const double *A_mean, *C_mean, *QA, *RC;
     int N, T, D, K, t;
     Layout L;
 };
@@ -392,7 +409,8 @@ __global__ void __launch_bounds__(128) k_step_big(BigStepArgs a) {
     if (cls != 1) {
         const double* nbr = X + (size_t)(cls == 0 ? 1 : T - 2) * BDP;
         const double s = big_boundary(cls == 0, g, L, a.A_mean + (size_t)n * D * D, a.C_mean + (size_t)n * K * D, D, K, tid,
-                                      [&](int j) { return nbr[xpos(j)]; }, y, vs);
+                                      [&](int j) { return nbr[xpos(j)]; }, y, vs,
+                                      a.QA ? a.QA + (size_t)n * D * D : nullptr, a.RC ? a.RC + (size_t)n * K * D : nullptr);
         X[(size_t)t * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
         return;
     }
@@ -410,6 +428,7 @@ __global__ void __launch_bounds__(128) k_step_big(BigStepArgs a) {
 int launch_step_big(pyvb_lds* h, int t) {
     BigStepArgs a;
     a.X = h->X[h->cur]; a.Y = h->Y; a.gains = h->gains; a.A_mean = h->A_mean; a.C_mean = h->C_mean;
+    a.QA = h->dense ? h->QA : nullptr; a.RC = h->dense ? h->RC : nullptr;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.t = t; a.L = h->L;
     TimedLaunch tl(h, PYVB_K_STEP);
     hipLaunchKernelGGL(k_step_big, dim3(h->N), dim3(128), 0, h->stream, a);
@@ -519,8 +538,10 @@ int launch_stats_big(pyvb_lds* h) {
 struct BigPrepArgs {
     const double *A_mean, *A_var, *C_mean, *C_var, *Q_a, *Q_b, *R_a, *R_b, *x0_mean, *x0_prec;
     double *Sigma, *qld, *gains, *scratch;      // scratch: [N][2][128][128]
+    // Wishart noise (dense): E[Q] [D][D], E[Q]<A> [D][D], E[R]<C> [K][D], tr(S_i E[Q]) [D], tr(S'_i E[R]) [D] per replicate
+    const double *Qbar, *QA, *RC, *trA, *trC;
     int *warm, *status;
-    int N, T, D, K, noise;
+    int N, T, D, K, noise, dense;
     Layout L;
 };
 
@@ -635,65 +656,6 @@ __device__ static int warmup128(double* W, int tid, double* red) {
     return best;
 }
 
-// Inverse of the symmetric positive definite matrix held as 8 x 8 tiles by the 16 x 16 threads of the workgroup (thread
-// (a = tid / 16, b = tid % 16) owns elements (8a + ra, 8b + cb)), Gauss-Jordan without pivoting as gj.h; rc: [2][264] doubles
-// of LDS (row 128, column 128, 1/pivot), pivs: [128].
-#define GJB_BUF 264
-__device__ static void gj_wg128(double (&v)[8][8], int D, int tid, double* rc, double* pivs) {
-    const int a = tid >> 4, b = tid & 15;
-    if (a == 0) {
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) rc[8 * b + cb] = v[0][cb];
-    }
-    if (b == 0) {
-#pragma unroll
-        for (int ra = 0; ra < 8; ++ra) rc[128 + 8 * a + ra] = v[ra][0];
-    }
-    if (tid == 0) rc[256] = 1.0 / v[0][0];
-    int cur = 0;
-    for (int P = 0; 8 * P < D; ++P) {
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            const int p = 8 * P + pp;
-            if (p >= D) continue;                                   // block-uniform
-            const int P1 = (pp == 7) ? P + 1 : P, q1 = (pp + 1) & 7;
-            __syncthreads();
-            const double* row = rc + cur * GJB_BUF;
-            const double* col = row + 128;
-            double* nrow = rc + (cur ^ 1) * GJB_BUF;
-            double* ncol = nrow + 128;
-            const double d = row[256];
-            if (tid == 0) pivs[p] = row[p];
-            double rj[8], ci[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { rj[k] = row[8 * b + k] * d; ci[k] = col[8 * a + k]; }
-#pragma unroll
-            for (int ra = 0; ra < 8; ++ra)
-#pragma unroll
-                for (int cb = 0; cb < 8; ++cb) v[ra][cb] = __builtin_fma(-ci[ra], rj[cb], v[ra][cb]);
-            if (b == P) {
-#pragma unroll
-                for (int ra = 0; ra < 8; ++ra) v[ra][pp] = -ci[ra] * d;
-            }
-            if (a == P) {
-#pragma unroll
-                for (int cb = 0; cb < 8; ++cb) v[pp][cb] = (b == P && cb == pp) ? d : rj[cb];
-            }
-            if (a == P1) {
-#pragma unroll
-                for (int cb = 0; cb < 8; ++cb) nrow[8 * b + cb] = v[q1][cb];
-            }
-            if (b == P1) {
-#pragma unroll
-                for (int ra = 0; ra < 8; ++ra) ncol[8 * a + ra] = v[ra][q1];
-            }
-            if (a == P1 && b == P1) nrow[256] = 1.0 / v[q1][q1];
-            cur ^= 1;
-        }
-    }
-    __syncthreads();
-}
-
 __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     extern __shared__ double lds[];
     double* Pm = lds;                       // [128][BLD]
@@ -712,18 +674,27 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     const double* Cv = a.C_var + (size_t)n * D * K;
     double* g = a.gains + (size_t)n * L.gains_total;
     double* S1 = a.scratch + (size_t)n * 2 * BDP * BDP;     // M_C, then F (zero padded)
+    const bool dense = a.dense != 0;            // Wishart noise: the products with the noise expectations come from k_dense_pre_big
     if (tid < BDP) {
-        qbar[tid] = tid < D ? a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid] : 0.0;
-        rbar[tid] = tid < K ? a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid] : 0.0;
+        qbar[tid] = (!dense && tid < D) ? a.Q_a[(size_t)n * D + tid] / a.Q_b[(size_t)n * D + tid] : 0.0;
+        rbar[tid] = (!dense && tid < K) ? a.R_a[(size_t)n * K + tid] / a.R_b[(size_t)n * K + tid] : 0.0;
     }
+    const double* Qd = dense ? a.Qbar + (size_t)n * D * D : nullptr;
+    const double* QAd = dense ? a.QA + (size_t)n * D * D : nullptr;
+    const double* RCd = dense ? a.RC + (size_t)n * K * D : nullptr;
+    auto QA_at = [&](int k, int j) { const double v = QAd[(size_t)(k < D ? k : D - 1) * D + (j < D ? j : D - 1)]; return (k < D && j < D) ? v : 0.0; };
+    auto RC_at = [&](int k, int j) { const double v = RCd[(size_t)(k < K ? k : K - 1) * D + (j < D ? j : D - 1)]; return (k < K && j < D) ? v : 0.0; };
     auto A_at = [&](int i, int j) { const double v = Am[(size_t)(i < D ? i : D - 1) * D + (j < D ? j : D - 1)]; return (i < D && j < D) ? v : 0.0; };
     auto C_at = [&](int k, int j) { const double v = Cm[(size_t)(k < K ? k : K - 1) * D + (j < D ? j : D - 1)]; return (k < K && j < D) ? v : 0.0; };
     __syncthreads();
     if (tid < BDP) {        // traces of the column covariances against the noise expectations (diagonal of node.py:223-227)
         double tc = 0.0, ta = 0.0;
         if (tid < D) {
-            for (int k = 0; k < K; ++k) tc += Cv[(size_t)tid * K + k] * rbar[k];
-            for (int k = 0; k < D; ++k) ta += Av[(size_t)tid * D + k] * qbar[k];
+            if (dense) { tc = a.trC[(size_t)n * D + tid]; ta = a.trA[(size_t)n * D + tid]; }
+            else {
+                for (int k = 0; k < K; ++k) tc += Cv[(size_t)tid * K + k] * rbar[k];
+                for (int k = 0; k < D; ++k) ta += Av[(size_t)tid * D + k] * qbar[k];
+            }
         }
         rowp[tid] = tc; colp[tid] = ta;
     }
@@ -734,11 +705,19 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     double* S2 = S1 + BDP * BDP;
     for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = C_at(k, j); }
     __syncthreads();
+    if (dense)      // <C>^T (E[R]<C>): the second operand straight from the array (the rare, untuned case)
+        mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i]; }, [&](int k, int j) { return RC_at(k, j); },
+              [&](int i, int j, double v) { S1[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? rowp[i] : 0.0) : 0.0; });
+    else
     mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i] * rbar[k]; }, [&](int k, int j) { return Pm[k * BLD + j]; },
           [&](int i, int j, double v) { S1[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? rowp[i] : 0.0) : 0.0; });
     __syncthreads();
     for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = A_at(k, j); }
     __syncthreads();
+    if (dense)
+        mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i]; }, [&](int k, int j) { return QA_at(k, j); },
+              [&](int i, int j, double v) { S2[(size_t)i * BDP + j] = (i < D && j < D) ? S1[(size_t)i * BDP + j] + v + (i == j ? colp[i] : 0.0) : 0.0; });
+    else
     mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i] * qbar[k]; }, [&](int k, int j) { return Pm[k * BLD + j]; },
           [&](int i, int j, double v) { S2[(size_t)i * BDP + j] = (i < D && j < D) ? S1[(size_t)i * BDP + j] + v + (i == j ? colp[i] : 0.0) : 0.0; });
     __syncthreads();
@@ -756,7 +735,7 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
             for (int cb = 0; cb < 8; ++cb) {
                 const int i = 8 * ta + ra, j = 8 * tb + cb;
                 const bool in = i < D && j < D;
-                const double qd = (in && i == j) ? qbar[i] : 0.0;
+                const double qd = dense ? (in ? Qd[(size_t)i * D + j] : 0.0) : ((in && i == j) ? qbar[i] : 0.0);
                 const double pad = (!in && i == j) ? 1.0 : 0.0;
                 double x;
                 if (c == 0) x = (in ? a.x0_prec[(size_t)i * D + j] : 0.0) + Pm[i * BLD + j];
@@ -796,19 +775,19 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
         g[L.ow0 + tid] = s;
     }
     // gains of the interior class: F = Sigma <Q><A>, B = Sigma <A>^T<Q>, G = Sigma <C>^T<R>
-    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; S2[idx] = qbar[k] * A_at(k, j); }
+    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; S2[idx] = dense ? QA_at(k, j) : qbar[k] * A_at(k, j); }
     __syncthreads();
     mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return S2[(size_t)k * BDP + j]; },
           [&](int i, int j, double v) { const bool in = i < D && j < D; g[L.oFn + pos_nat(i, j, BDS)] = in ? v : 0.0; S1[(size_t)i * BDP + j] = in ? v : 0.0; });
     __syncthreads();
     // the B operands of the next two products are transposes of row-major matrices: written out once, transposed and scaled,
     // so that the products read them along rows like the others (a lane per matrix row would touch a cache line per element)
-    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int j = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + j] = A_at(j, k) * qbar[j]; }
+    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int j = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + j] = dense ? QA_at(j, k) : A_at(j, k) * qbar[j]; }
     __syncthreads();
     mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return S2[(size_t)k * BDP + j]; },
           [&](int i, int j, double v) { g[L.oBn + pos_nat(i, j, BDS)] = (i < D && j < D) ? v : 0.0; });
     __syncthreads();
-    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int l = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + l] = C_at(l, k) * rbar[l]; }
+    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int l = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + l] = dense ? RC_at(l, k) : C_at(l, k) * rbar[l]; }
     __syncthreads();
     mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int l) { return S2[(size_t)k * BDP + l]; },
           [&](int i, int l, double v) { g[L.oGp + pos_perm(i, l, BDS)] = (i < D && l < K) ? v : 0.0; });
@@ -836,6 +815,7 @@ int launch_prep_big(pyvb_lds* h) {
     a.Sigma = h->Sigma_new; a.qld = h->qld_x_new; a.gains = h->gains; a.scratch = h->scratch;
     a.warm = h->warm; a.status = h->status;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.noise = h->noise; a.L = h->L;
+    a.dense = h->dense ? 1 : 0; a.Qbar = h->Qbar; a.QA = h->QA; a.RC = h->RC; a.trA = h->trA; a.trC = h->trC;
     const size_t lds = ((size_t)BDP * BLD + 4 * BDP + 2 * GJB_BUF + BDP) * sizeof(double);
     if (!h->big_attr_prep) {           // per handle: the attribute belongs to the device the handle lives on
         HIPCHK(hipFuncSetAttribute((const void*)k_prep_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256) k_colvar_to_cov(WArgs a) {
 }
 
 // ... and back: the diagonals (what the lower bound reads) of column covariances the caller supplied
-__global__ void __launch_bounds__(64) k_cov_to_colvar(WArgs a) {
+__global__ void __launch_bounds__(128) k_cov_to_colvar(WArgs a) {
     const int WHICH = blockIdx.z, n = blockIdx.x, i = blockIdx.y, D = a.D, k = threadIdx.x;
     const int rows = WHICH == 0 ? a.D : a.K;
     const double* cov = (WHICH == 0 ? a.A_cov : a.C_cov) + ((size_t)n * D + i) * cov_stride(rows);
@@ -547,13 +547,13 @@ __global__ void __launch_bounds__(64) k_elbo_dense(WArgs a) {
     const double* RQ = a.RQ + (size_t)n * D * D;
     const double* RR = a.RR + (size_t)n * K * K;
     const double* ln = a.lnd + (size_t)n * 4;
+    // (a lane takes the entries lane, lane + 64: D, K <= 128)
     double tq = 0.0, tr = 0.0, tq0 = 0.0, tr0 = 0.0;
-    if (lane < D) for (int l = 0; l < D; ++l) { tq += Qb[lane * D + l] * RQ[l * D + lane]; tq0 += a.pri.Q_w0[lane * D + l] * Qb[l * D + lane]; }
-    if (lane < K) for (int l = 0; l < K; ++l) { tr += Rb[lane * K + l] * RR[l * K + lane]; tr0 += a.pri.R_w0[lane * K + l] * Rb[l * K + lane]; }
+    for (int i = lane; i < D; i += 64) for (int l = 0; l < D; ++l) { tq += Qb[i * D + l] * RQ[l * D + i]; tq0 += a.pri.Q_w0[i * D + l] * Qb[l * D + i]; }
+    for (int i = lane; i < K; i += 64) for (int l = 0; l < K; ++l) { tr += Rb[i * K + l] * RR[l * K + i]; tr0 += a.pri.R_w0[i * K + l] * Rb[l * K + i]; }
     const double trQ = wave_sum(tq), trR = wave_sum(tr), trQ0 = wave_sum(tq0), trR0 = wave_sum(tr0);
     double e0 = 0.0;
-    if (lane < D) {
-        const int i = lane;
+    for (int i = lane; i < D; i += 64) {
         for (int j = 0; j < D; ++j) {
             const double xj = x0[xpos(j)];
             const double ex = xj * x0[xpos(i)] + S0[j * D + i] + a.pri.x0_mean[j] * a.pri.x0_mean[i] - 2.0 * xj * a.pri.x0_mean[i];
@@ -568,8 +568,7 @@ __global__ void __launch_bounds__(64) k_elbo_dense(WArgs a) {
     double LY = (double)T * (-0.5 * K * LN2PI + 0.5 * ln[1]) - trR;
     if (a.Yent) LY -= a.Yent[n];
     double la = 0.0, lc = 0.0;
-    if (lane < D) {
-        const int i = lane;
+    for (int i = lane; i < D; i += 64) {
         // the last term depends on how much of the column is known (gaussian.py:145-150, as k_elbo in k_params.hip): nothing ->
         // the q_ln_det form, some entries -> ln det of the covariance of the rest (ldm, from k_cols_wishart), all -> no term
         auto column = [&](int rows, const double* pp, const double* pm, const double* M, const double* V, double qld, double lndet,
@@ -586,10 +585,10 @@ __global__ void __launch_bounds__(64) k_elbo_dense(WArgs a) {
             else if (missing > 0) r -= 0.5 * missing * LN2PI - 0.5 * ldmv - 0.5 * missing;
             return r;
         };
-        la = column(D, a.pri.A_pp, a.pri.A_pm, a.A_mean + (size_t)n * D * D, a.A_var + (size_t)n * D * D, a.qld_A[(size_t)n * D + i], a.pri.A_pld[i],
-                    a.pri.A_obs, a.ldm[((size_t)n * 2 + 0) * D + i]);
-        lc = column(K, a.pri.C_pp, a.pri.C_pm, a.C_mean + (size_t)n * K * D, a.C_var + (size_t)n * D * K, a.qld_C[(size_t)n * D + i], a.pri.C_pld[i],
-                    a.pri.C_obs, a.ldm[((size_t)n * 2 + 1) * D + i]);
+        la += column(D, a.pri.A_pp, a.pri.A_pm, a.A_mean + (size_t)n * D * D, a.A_var + (size_t)n * D * D, a.qld_A[(size_t)n * D + i], a.pri.A_pld[i],
+                     a.pri.A_obs, a.ldm[((size_t)n * 2 + 0) * D + i]);
+        lc += column(K, a.pri.C_pp, a.pri.C_pm, a.C_mean + (size_t)n * K * D, a.C_var + (size_t)n * D * K, a.qld_C[(size_t)n * D + i], a.pri.C_pld[i],
+                     a.pri.C_obs, a.ldm[((size_t)n * 2 + 1) * D + i]);
     }
     const double LA = wave_sum(la), LC = wave_sum(lc);
     if (lane == 0) {
@@ -609,6 +608,7 @@ __global__ void __launch_bounds__(64) k_elbo_dense(WArgs a) {
 
 // ---- launchers
 int launch_wexpect(pyvb_lds* h) {
+    if (h->big) return launch_wexpect_big(h);
     WArgs a = make_wargs(h);
     TimedLaunch tl(h, PYVB_K_PREP);
     hipLaunchKernelGGL(k_wexpect, dim3(h->N), dim3(256), 0, h->stream, a);
@@ -617,6 +617,7 @@ int launch_wexpect(pyvb_lds* h) {
 }
 
 int launch_dense_pre(pyvb_lds* h) {
+    if (h->big) return launch_dense_pre_big(h);
     WArgs a = make_wargs(h);
     TimedLaunch tl(h, PYVB_K_PREP);
     hipLaunchKernelGGL(k_dense_pre, dim3(h->N, 2), dim3(256), 0, h->stream, a);
@@ -625,6 +626,7 @@ int launch_dense_pre(pyvb_lds* h) {
 }
 
 int launch_cols_dense(pyvb_lds* h, int which, int c0, int c1) {
+    if (h->big) return launch_cols_dense_big(h, which, c0, c1);
     WArgs a = make_wargs(h);
     a.which0 = which == 1 ? 1 : 0; a.c0 = c0; a.c1 = c1;
     const int nw = which == 2 ? 2 : 1;
@@ -641,6 +643,7 @@ int launch_cols_dense(pyvb_lds* h, int which, int c0, int c1) {
 }
 
 int launch_wresid(pyvb_lds* h, int which, int update) {
+    if (h->big) return launch_wresid_big(h, which, update);
     WArgs a = make_wargs(h);
     a.which0 = which == 1 ? 1 : 0; a.update = update;
     const bool need0 = which != 1, need1 = which != 0;
@@ -652,6 +655,7 @@ int launch_wresid(pyvb_lds* h, int which, int update) {
 }
 
 int launch_syy_full(pyvb_lds* h) {
+    if (h->big) return launch_syy_full_big(h);
     WArgs a = make_wargs(h);
     hipLaunchKernelGGL(k_syy_full, dim3(h->N), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
@@ -667,7 +671,7 @@ int launch_colvar_to_cov(pyvb_lds* h) {
 
 int launch_cov_to_colvar(pyvb_lds* h) {
     WArgs a = make_wargs(h);
-    hipLaunchKernelGGL(k_cov_to_colvar, dim3(h->N, h->D, 2), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(k_cov_to_colvar, dim3(h->N, h->D, 2), dim3(128), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }

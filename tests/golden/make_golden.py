@@ -531,6 +531,9 @@ CASES = [
     # a second data set of the example's shape and priors: two reference runs that share one device handle when their graphs
     # are built side by side (tests/test_groups_gpu.py)
     ("example_b_d2k5_t200", 200, 2, 5, "diagonal_gamma", (1, 2, 5), 20270, True),
+    # Wishart noise on the second shape class (64 < max(D, K) <= 128): the first update, many states / many outputs
+    ("wishart_d66k3_t3", 3, 66, 3, "wishart", (1,), 20271, True),
+    ("wishart_d3k70_t3", 3, 3, 70, "wishart", (1,), 20272, True),
 ]
 
 

@@ -250,8 +250,16 @@ def test_beyond_64_iterate_matches_the_staged_calls_and_single_updates():
         O.update_x(st, pri, Y, t); c.update_x(t)
     _close(c.get_state(("X",))["X"], st["X"], "X after single updates of every node")
     c.close()
+    # Wishart noise is served up to 128 dimensions since round 4 (k_wishart_big.hip) -- alone: with known entries of A / C or
+    # with outputs that hold NaN it stops at 64, and says so
+    wb = LDSBatch(1, 10, 65, 4, "wishart")
+    with pytest.raises(_capi.PyvbHipError, match="64"):
+        wb.set_column_observations(np.full((65, 65), np.nan), np.full((4, 65), np.nan))
+    with pytest.raises(_capi.PyvbHipError, match="64"):
+        wb.set_observations(np.full((1, 10, 4), np.nan))
+    wb.close()
     with pytest.raises(_capi.PyvbHipError):
-        LDSBatch(1, 10, 65, 4, "wishart")
+        LDSBatch(1, 10, 129, 4, "wishart")
 
 
 @pytest.mark.parametrize("T", [2, 3, 4, 5, 16, 17, 18, 19, 33, 34, 129])
@@ -279,12 +287,14 @@ def _wishart_priors(pri, D, K, rng=None):
         W = rng.standard_normal((K, K)); pri["R_b0"] = 0.05 * (W @ W.T + K * np.eye(K)); pri["R_a0"] = np.float64(0.5 * K + 0.5)
 
 
-@pytest.mark.parametrize("T,D,K,N,proper", [(40, 3, 4, 2, False), (120, 16, 16, 2, True), (90, 33, 17, 2, True), (30, 64, 64, 1, False)])
+@pytest.mark.parametrize("T,D,K,N,proper", [(40, 3, 4, 2, False), (120, 16, 16, 2, True), (90, 33, 17, 2, True), (30, 64, 64, 1, False),
+                                            (6, 96, 96, 2, True), (5, 128, 128, 1, False), (20, 70, 9, 2, True), (12, 5, 100, 1, True)])
 def test_wishart_noise_vs_oracle(T, D, K, N, proper):
     """Wishart Q and R (Linear_Dynamic_System.py:55-56; nodes_todo.py:205-234): dense expected precisions, dense
     column covariances; three iterations stage by stage against the oracle, which is pinned to the reference for
     the first one (fixture lds_wishart_d3k4_t40) and follows the deviations listed in k_wishart.hip afterwards.
-    The lower bound with Wishart parents does not exist in the reference: both sides use the derived one."""
+    The lower bound with Wishart parents does not exist in the reference: both sides use the derived one.
+    From 65 dimensions on the kernels are those of k_wishart_big.hip (fixtures lds_wishart_d66k3_t3, lds_wishart_d3k70_t3)."""
     Y, st0, pri = synth.make_problem(T, D, K, N, seed=300 + T + D)
     _wishart_priors(pri, D, K, np.random.default_rng(T) if proper else None)
     _stagewise(Y, st0, pri, iters=3)
