@@ -33,7 +33,7 @@ def test_error_string_and_argument_checks_without_gpu():
     assert b"T must be" in _capi.lib.pyvb_last_error()
     rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 10, 129, 4, 0)        # D, K <= 128
     assert rc == _capi.E_ARG
-    rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 10, 65, 4, _capi.NOISE_WISHART)     # Wishart noise: D, K <= 64
+    rc = _capi.lib.pyvb_lds_create(ctypes.byref(h), 0, 1, 10, 4, 129, _capi.NOISE_WISHART)    # the same with Wishart noise (<= 64 until round 4)
     assert rc == _capi.E_ARG
 
 
