@@ -110,7 +110,6 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     TRY(dev_alloc(&h->qld_x, n * 3)); TRY(dev_alloc(&h->qld_x_new, n * 3));
     TRY(dev_alloc(&h->gains, n * L.gains_total));
     TRY(dev_alloc(&h->scratch, h->big ? n * 2 * L.DP * L.DP : n * 2 * D * D));
-    TRY(dev_alloc(&h->trash, n * 512));
     TRY(dev_alloc(&h->zeros, 128));
     TRY(dev_alloc(&h->U, n * T * L.DP));                        // the c_t cache between a forward sweep and the backward one behind it
     TRYHIP(hipMalloc((void**)&h->warm, n * 2 * sizeof(int)));
@@ -129,17 +128,20 @@ int pyvb_lds_create(pyvb_lds** out, int device, int N, int T, int D, int K, int 
     // The sweeps may split the time axis over W wavefronts per replicate (k_sweep.hip).  A wavefront takes
     // ceil(part/16) + J steps (J ~ 32 warm-up steps), the chip runs 1024 of them at a time: W minimises
     // rounds x steps, with parts of at least 64 nodes.  At N >= 1024 that is W = 1.
+    // (The 128-wide class: a part is a workgroup of four wavefronts, one per CU at a time.)
     h->W = 1;
-    if (!h->big) {
-        const long Tint = T - 2;
+    {
+        const long Tint = T - 2, slots = h->big ? 256 : 1024;
         double best = 1e300;
         for (int W = 1; W <= 128 && (W == 1 || Tint / W >= 64); ++W) {
             const long part = (((Tint + W - 1) / W) + 15) & ~15L;
-            const double cost = (double)(((long)N * W + 1023) / 1024) * (double)((part + 15) / 16 + 32);
+            const double cost = (double)(((long)N * W + slots - 1) / slots) * (double)((part + 15) / 16 + 32);
             if (cost < best * 0.97) { best = cost; h->W = W; }      // prefer fewer wavefronts unless clearly better
         }
     }
-    TRY(dev_alloc(&h->sxx, n * (size_t)h->W * L.DP * L.DP));
+    TRY(dev_alloc(&h->sxx, h->big ? 8 : n * (size_t)h->W * L.DP * L.DP));        // (the 128-wide sweeps fuse no statistics)
+    if (h->big && h->W > 1) TRY(dev_alloc(&h->U2, n * T * L.DP));
+    TRY(dev_alloc(&h->trash, n * (size_t)(h->big ? h->W : 1) * 512));      // 128-wide class: per (replicate, part of the time axis)
     TRY(dev_alloc(&h->resQ, n * D)); TRY(dev_alloc(&h->resR, n * K));
     TRY(dev_alloc(&h->elbo, n * 6)); TRY(dev_alloc(&h->elbo_sum, 8));
     TRY(dev_alloc(&h->elbo_hist, (size_t)PYVB_ELBO_HISTORY * 8));
@@ -199,7 +201,7 @@ int pyvb_lds_destroy(pyvb_lds* h) {
                       h->qld_A, h->qld_C, h->Sigma, h->Sigma_new, h->qld_x, h->qld_x_new, h->gains, h->scratch, h->stats,
                       h->resQ, h->resR, h->elbo, h->elbo_sum, h->pri_block, h->trash, h->zeros, h->mom, h->sxx, h->U,
                       h->Q_w, h->R_w, h->Qbar, h->Rbar, h->lnd, h->QA, h->RC, h->trA, h->trC, h->A_cov, h->C_cov, h->SyyF, h->RQ, h->RR, h->SG, h->ldm,
-                      h->Yobs, h->Yvar, h->Yqld, h->Yent, h->Yld, h->YcovS};
+                      h->Yobs, h->Yvar, h->Yqld, h->Yent, h->Yld, h->YcovS, h->U2};
     for (double* b : bufs) if (b) (void)hipFree(b);
     if (h->warm) (void)hipFree(h->warm);
     if (h->status) (void)hipFree(h->status);
@@ -625,12 +627,18 @@ int pyvb_lds_set_time_split(pyvb_lds* h, int W) {
     ENTER(h);
     ARGCHK(W >= 1 && W <= 128, "W must be in 1..128");
     ARGCHK(W == 1 || (h->T - 2) / W >= 16, "parts of fewer than 16 nodes");
-    ARGCHK(W == 1 || !h->big, "the time split exists for D, K <= 64 only");
     HIPCHK(hipStreamSynchronize(h->stream));
     if (W != h->W) {
         double* p = nullptr;
-        int rc = dev_alloc(&p, (size_t)h->N * W * h->L.DP * h->L.DP);
+        int rc = dev_alloc(&p, h->big ? 8 : (size_t)h->N * W * h->L.DP * h->L.DP);
         if (rc) return rc;
+        if (h->big && W > 1 && !h->U2 && (rc = dev_alloc(&h->U2, (size_t)h->N * h->T * h->L.DP))) { (void)hipFree(p); return rc; }
+        if (h->big) {
+            double* tr = nullptr;
+            if ((rc = dev_alloc(&tr, (size_t)h->N * W * 512))) { (void)hipFree(p); return rc; }
+            (void)hipFree(h->trash);
+            h->trash = tr;
+        }
         (void)hipFree(h->sxx);
         h->sxx = p; h->W = W;
         h->sxx_valid = false; h->u_valid = false;

@@ -88,6 +88,7 @@ struct pyvb_lds {
     int device, N, T, D, K, noise;
     bool big;                       // 64 < max(D, K) <= 128: the workgroup-per-replicate kernels of k_big.hip
     bool big_attr_prep, big_attr_cols;      // their dynamic-LDS limits have been raised on this handle's device
+    double* U2;                     // 128-wide class with the time axis split (W > 1): the c_t of a forward sweep (k_big.hip: BigSweepArgs.Uc)
     Layout L;
     hipStream_t stream;
     struct EventPair* pool; int pool_used;

@@ -41,8 +41,11 @@ struct BigSweepArgs {
     const double *A_mean, *C_mean;
     const double *QA, *RC;      // Wishart noise: <Q><A> [D][D], <R><C> [K][D] per replicate (k_wishart_big.hip), else null
     double* U;          // [N][T][128]: c_t = R mu_{t-1} + G y_t of the interior nodes (MODE 1 writes, MODE 2 reads), accumulator order
-    double* trash;      // [N][512]
-    int N, T, D, K, dir;
+    double* Uc;         // where a forward sweep stores c_t: U itself, or, when the time axis is split over several workgroups
+                        // (W > 1), a buffer of its own -- a part's warm-up reads G y_t rows of the part before it, which that part's
+                        // workgroup overwrites with c_t on its own schedule (within a workgroup a barrier orders the two)
+    double* trash;      // [N][W][512]
+    int N, T, D, K, dir, W;
     Layout L;
 };
 
@@ -168,6 +171,7 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
     double* xs = lds + 2 * BDS * 64;                // [128] boundary state exchange
     double* vs = xs + BDP;                          // [128] boundary scratch
     const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int part = blockIdx.y;            // the time axis is dealt out to a.W workgroups per replicate when there are few replicates (k_sweep.hip: SPLIT)
     const int T = a.T, D = a.D, K = a.K;
     const bool fwd = (a.dir == 0);
     const int sgn = fwd ? 1 : -1;
@@ -193,40 +197,46 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
     }
     const int Tint = T - 2;
     const int J = a.warm[n * 2 + a.dir];
+    // this workgroup's part of the interior: Lw nodes from interior node ow on (counted from the side the sweep starts at), again
+    // cut into 16 segments; all columns but those that reach the chain's first node within J steps warm up from zero
+    const int Lw = a.W > 1 ? ((((Tint + a.W - 1) / a.W) + 15) & ~15) : Tint;
+    const int ow = part * Lw;
+    const int Tw = (Tint - ow < Lw) ? Tint - ow : Lw;
     const int t_first = fwd ? 0 : T - 1, t_last = fwd ? T - 1 : 0;
     const double* Am = a.A_mean + (size_t)n * D * D;
     const double* Cm = a.C_mean + (size_t)n * K * D;
     const double* QAm = a.QA ? a.QA + (size_t)n * D * D : nullptr;
     const double* RCm = a.RC ? a.RC + (size_t)n * K * D : nullptr;
 
-    // ---- first boundary node: only the old neighbour
-    {
+    // ---- first boundary node: only the old neighbour.  Every part whose warm-up can reach it computes it; the first one stores it.
+    if (ow <= J) {               // block-uniform
         const double* xo = Xo + (size_t)(t_first + sgn) * BDP;
         const double s = big_boundary(fwd, g, L, Am, Cm, D, K, tid, [&](int j) { return xo[xpos(j)]; }, Yn + (size_t)t_first * K, vs, QAm, RCm);
         if (tid < BDP) {
-            Xn[(size_t)t_first * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
+            if (part == 0) Xn[(size_t)t_first * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
             xs[tid] = (tid < D) ? s : 0.0;
         }
     }
     __syncthreads();
 
-    if (Tint > 0) {
-        const int Lseg = (Tint + 15) >> 4;
+    if (Tw > 0) {
+        const int Lseg = (Tw + 15) >> 4;
         const int cL = c * Lseg;
-        const int jc = -(J < cL ? J : cL);                                   // first loop index of this column
-        const int jstart = -((J < 15 * Lseg) ? J : 15 * Lseg);               // of the workgroup
+        const int before = ow + cL;                                          // interior nodes between the chain's start and this column
+        const int jc = -(J < before ? J : before);                           // first loop index of this column
+        const int jstart = -((J < ow + 15 * Lseg) ? J : ow + 15 * Lseg);     // of the workgroup
         // xb[4m + r][lane] = row 16m + 4r + q of column c: the registers go to the matrices and to the operands fetched a step ahead
         if (w == 0) {
 #pragma unroll
             for (int m = 0; m < BDT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xb0[(4 * m + r) * 64 + lane] = (jc == -cL) ? xs[16 * m + 4 * r + q] : 0.0;
+                for (int r = 0; r < 4; ++r) xb0[(4 * m + r) * 64 + lane] = (jc == -before) ? xs[16 * m + 4 * r + q] : 0.0;
         }
         __syncthreads();
-        const int tbase = fwd ? (1 + cL) : (T - 2 - cL);
+        const int tbase = fwd ? (1 + before) : (T - 2 - before);
         const int tsafe = fwd ? 1 : T - 2;
-        auto active = [&](int j) { int tt = cL + j; return j >= jc && j < Lseg && tt < Tint; };
-        double* const trash = a.trash + (size_t)n * 512;
+        auto active = [&](int j) { int tt = cL + j; return j >= jc && j < Lseg && tt < Tw; };
+        double* const trash = a.trash + ((size_t)n * a.W + part) * 512;
         // Operands of a step from global memory.  (a) This wavefront's rows of U (G y_t, or c_t for the cached backward sweep): three
         // register sets, a row is requested two steps before it is used.  (b) The old neighbour mu_{t+dir}: the same 128 x 16 block
         // for all four wavefronts -- each fetches the two row tiles it also owns of the state (a quarter of the block) and puts
@@ -250,7 +260,8 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st[(4 * (NTW * w + mm) + r) * 64 + lane] = gq[mm][r];
         };
-        double* const Un = a.U + (size_t)n * T * BDP;
+        const double* const Un = (MODE == 2 ? a.Uc : a.U) + (size_t)n * T * BDP;     // what a step starts from: G y_t, or the cached c_t
+        double* const Uw = a.Uc + (size_t)n * T * BDP;                               // where a forward sweep leaves c_t
         d4 cvA[NTW], cvB[NTW], cvC[NTW];
         auto load_c = [&](d4 (&cv)[NTW], int j) {
             const double* cp = Un + (size_t)row_of(j) * BDP;
@@ -286,7 +297,7 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
                 for (int s = 0; s < BDS; ++s) acc[mm] = MFMA(rn[mm][s], xr[s * 64 + lane], acc[mm]);
             if constexpr (MODE != 2) {
                 if (fwd) {                      // c_t for the backward sweep, this wavefront's rows
-                    double* ur = (act && j >= 0) ? Un + (size_t)(tbase + sgn * j) * BDP : trash + 256;
+                    double* ur = (act && j >= 0) ? Uw + (size_t)(tbase + sgn * j) * BDP : trash + 256;
 #pragma unroll
                     for (int mm = 0; mm < NTW; ++mm) *reinterpret_cast<d4*>(ur + ((NTW * w + mm) * 4 + q) * 4) = acc[mm];
                 }
@@ -345,7 +356,7 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
             step(j + 5, xb1, xb0, cvC, cvC); xfin = xb0;
         }
         // the column that holds the last interior node hands its state to the closing boundary step
-        const int clast = (Tint - 1) / Lseg;
+        const int clast = (Tw - 1) / Lseg;
         if (w == 0 && c == clast) {
 #pragma unroll
             for (int m = 0; m < BDT; ++m)
@@ -354,8 +365,8 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
         }
         __syncthreads();
     }
-    // ---- closing boundary node: only the new neighbour
-    {
+    // ---- closing boundary node: only the new neighbour; done by the part that owns the last interior node
+    if (part == ((Tint > 0) ? (Tint - 1) / Lw : 0)) {
         const double s = big_boundary(!fwd, g, L, Am, Cm, D, K, tid, [&](int j) { return xs[j]; }, Yn + (size_t)t_last * K, vs, QAm, RCm);
         if (tid < BDP) Xn[(size_t)t_last * BDP + xpos(tid)] = (tid < D) ? s : 0.0;
     }
@@ -367,6 +378,7 @@ int launch_sweep_big(pyvb_lds* h, int direction) {
     a.A_mean = h->A_mean; a.C_mean = h->C_mean; a.trash = h->trash; a.U = h->U;
     a.QA = h->dense ? h->QA : nullptr; a.RC = h->dense ? h->RC : nullptr;
     a.N = h->N; a.T = h->T; a.D = h->D; a.K = h->K; a.dir = direction; a.L = h->L;
+    a.W = h->W; a.Uc = h->W > 1 ? h->U2 : h->U;
     // a backward sweep right behind a forward one (h->u_valid) reads c_t; anything else starts from G y_t
     const bool cached = direction == PYVB_BACKWARD && h->u_valid;
     const size_t lds = ((size_t)2 * BDS * 64 + 2 * BDP + (cached ? 0 : 3 * BDS * 64)) * sizeof(double);        // MODE 3: + the neighbour ring
@@ -383,8 +395,8 @@ int launch_sweep_big(pyvb_lds* h, int direction) {
     }
     {
         TimedLaunch tl(h, direction == PYVB_FORWARD ? PYVB_K_SWEEP_FWD : PYVB_K_SWEEP_BWD);
-        if (cached) hipLaunchKernelGGL((k_sweep_big<2, 2>), dim3(h->N), dim3(256), lds, h->stream, a);
-        else hipLaunchKernelGGL((k_sweep_big<3, 2>), dim3(h->N), dim3(256), lds, h->stream, a);
+        if (cached) hipLaunchKernelGGL((k_sweep_big<2, 2>), dim3(h->N, h->W), dim3(256), lds, h->stream, a);
+        else hipLaunchKernelGGL((k_sweep_big<3, 2>), dim3(h->N, h->W), dim3(256), lds, h->stream, a);
     }
     HIPCHK(hipGetLastError());
     return PYVB_OK;

@@ -595,6 +595,35 @@ def test_headline_instantiation_one_wavefront_per_replicate_warmup():
     b.close()
 
 
+def test_time_split_of_the_128_wide_class():
+    """Few replicates at 64 < D <= 128: the interior time range is dealt out to W workgroups per replicate (k_sweep_big, as SPLIT
+    in k_sweep.hip; round 3 ran one chain as ONE workgroup).  The library's own choice of W, two iterations stage by stage
+    against the oracle; W = 1 and W = 3 forced on the same problem end at the same states (to rounding: the parts warm up
+    across their borders)."""
+    T, D, K, N = 1500, 100, 70, 2
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=4242)
+    b = _batch(Y, st0, pri)
+    W = b.get_time_split()
+    assert W > 1, W
+    b.close()
+    _stagewise(Y, st0, pri, iters=2)
+    out = {}
+    for w in (1, 3, W):
+        b = _batch(Y, st0, pri)
+        b.set_time_split(w)
+        assert b.get_time_split() == w
+        b.iterate(2)
+        out[w] = (b.get_state(), b.elbo())
+        b.close()
+    for w in (3, W):
+        for k in ("X", "A_mean", "C_mean", "Q_b", "R_b"):
+            _close(out[w][0][k], out[1][0][k], "W = %d against W = 1: %s" % (w, k), 1e-11)
+        assert np.all(np.abs(out[w][1] - out[1][1]) <= 1e-10 * np.abs(out[1][1]).sum(axis=1, keepdims=True))
+    # Wishart noise on the split sweep (dense boundary nodes in every part that can reach them)
+    _wishart_priors(pri, D, K, np.random.default_rng(3))
+    _stagewise(Y[:, :400], {k: (v[:, :400] if k == "X" else v) for k, v in st0.items()}, pri, iters=1)
+
+
 def test_headline_batch_1024_replicates():
     """BASELINE configs[2] as bench.py runs it: N = 1024 replicates (the library itself chooses one wavefront per
     replicate), T = 10^4, D = K = 64.  Two distinct problems tiled 512 times: replicates 0 and 1 against the oracle,
