@@ -37,10 +37,12 @@ class LDSGroup(object):
     one loop.  The kernels' parallel axis is the replicate axis of pyvb_amd.lds.LDSBatch; graphs that agree in everything
     a handle shares between its replicates -- T, D, K, the noise family, the Constant parents (priors), the known entries of
     A / C, which outputs are unobserved -- therefore share one handle.  The queued update() requests of the members are
-    carried out in lock step: while every live member asks for the same thing (a forward sweep, the columns 0..D-1 of A ...)
-    it is one launch for all of them.  A member whose queue says something else than the majority's leaves the group
-    with its state (its replicate stays behind as a dead row that nobody reads) and is bound anew -- on its own, with
-    others that left the same way, or, for a request no fused kernel serves, node by node."""
+    carried out in lock step: when a member needs its queue run (something of it is read), every operation of that queue
+    is one launch for all members that ask for the same thing at that point (a forward sweep, the columns 0..D-1 of A ...);
+    what the others have queued beyond it waits for their own reads.  Where the member and the others part ways the
+    smaller side leaves the handle with its state (the replicates stay behind as dead rows that nobody reads) and is bound
+    anew -- on its own, or together with the others that left the same way.  A request no fused kernel serves sends only
+    the graph that made it to the node-by-node plan."""
 
     def __init__(self, members):
         from .lds import LDSBatch
@@ -108,36 +110,40 @@ class LDSGroup(object):
         self.ran = True
         self.invalidate()
 
-    def flush(self):
-        """Carry out the members' queued requests (see the class comment)."""
+    def flush(self, who):
+        """Carry out the queued requests of member `who` -- and, in the same launches, those of every member that is asking for
+        the same things (see the class comment).  Nothing else is run: what the other members have queued beyond that waits
+        for their own reads.  When `who` and the others part ways the smaller side leaves the handle: `who` and the members
+        that go with it, or everybody else."""
         try:
-            while True:
-                heads, idle = {}, []
+            while who.group is self:
+                op, n = who._peek()
+                if n == 0:
+                    return
+                if op is None:                      # a request no fused kernel serves: this graph goes node by node
+                    who._depart(fused=False)
+                    return
+                same, rest = [(who, n)], []
                 for m in self.members:
-                    if m is None:
+                    if m is None or m is who:
                         continue
-                    op, n = m._peek()
-                    if n == 0:
-                        idle.append(m)
+                    o2, n2 = m._peek()
+                    if n2 and o2 == op:
+                        same.append((m, n2))
                     else:
-                        heads.setdefault(op, []).append((m, n))
-                if not heads:
+                        rest.append((m, n2))
+                if len(same) < len(rest):
+                    for m, _ in same:               # `who` among them: the loop ends, the caller goes on with its new plan
+                        m._depart(fused=True)
                     return
-                best, best_n = None, len(idle)      # best None: the members without requests are the majority, the others leave
-                for op, lst in heads.items():
-                    if op is not None and (len(lst) > best_n or (len(lst) == best_n and best is None)):
-                        best, best_n = op, len(lst)
-                for op, lst in heads.items():
-                    if op != best or op is None:
-                        for m, _ in lst:
-                            m._depart(fused=op is not None)
-                if best is None:
-                    return
-                for m in idle:
-                    m._leave()
-                self.execute(best)
-                for m, n in heads[best]:
-                    m._pos += n
+                for m, n2 in rest:
+                    if n2:
+                        m._depart(fused=True)
+                    else:
+                        m._leave()
+                self.execute(op)
+                for m, k in same:
+                    m._pos += k
         finally:
             for m in self.members:
                 if m is not None and m._pos:
@@ -351,7 +357,7 @@ class LDSPlan(object):
         """Run the queued update() requests (LDSGroup.flush: in lock step with the other graphs on this handle)."""
         if self._pos >= len(self.pending):
             return
-        self._materialize().flush()
+        self._materialize().flush(self)
 
     def _rest(self):
         rest, self.pending, self._pos = self.pending[self._pos:], [], 0
@@ -439,7 +445,7 @@ class LDSPlan(object):
             return node.__dict__.get("_h_" + name)          # observations: host copy
         self.flush()
         if node._plan is not self:
-            return node._plan.read(node, name)
+            return N._plan_of(node).read(node, name)
         if not self.ran:
             return node.__dict__.get("_h_" + name)          # nothing has run on the device: the host attributes are the state
         if kind == "x" and name != "qmu" and not self.x_updated:
@@ -473,8 +479,8 @@ class LDSPlan(object):
         """A user assignment to a posterior attribute after binding: push it to the device.  False: not something this plan
         can patch in place (an observation, a state covariance): the caller releases the plan and the graph is bound anew."""
         self.flush()
-        if node._plan is not self:              # the queue held something only the node-by-node plan serves
-            return node._plan.write(node, name, value)
+        if node._plan is not self:              # the queue held something only the node-by-node plan serves, or the graph left its handle
+            return N._plan_of(node).write(node, name, value)
         if name not in ("qmu", "qcov", "qb", "qw"):
             return True                         # q_ln_det, qprec: host-only bookkeeping
         kind, i = self.index[id(node)]
@@ -517,17 +523,20 @@ class LDSPlan(object):
     # -- lower bound -----------------------------------------------------------------------------
     def elbo_parts(self):
         self.flush()
-        if self.Xs[0]._plan is not self:        # the queue held something only the generic plan executes
+        if self.Xs[0]._plan is not self:        # the graph has moved: to a handle of its own, or to the node-by-node plan
+            plan = N._plan_of(self.Xs[0])
+            if isinstance(plan, LDSPlan):
+                return plan.elbo_parts()
             raise NotImplementedError("the graph runs node by node now: use Network.learn or the nodes' log_lower_bound()")
         return self._materialize().elbo()[self.r]
 
     def node_llb(self, node):
         self.flush()
         if node._plan is not self:
-            return node._plan.node_llb(node)
+            return N._plan_of(node).node_llb(node)
         if not self.x_updated:                  # single terms before any sweep: only the generic plan knows the initial covariances
             self._demote(self._rest())
-            return node._plan.node_llb(node)
+            return N._plan_of(node).node_llb(node)
         kind, _ = self.index[id(node)]
         if kind == "q":
             return float(self.elbo_parts()[4])

@@ -33,6 +33,11 @@ class _Schedule(object):
             return all(_bound(g[k][0], g[k][1]) for k in self.lds)
         return all(h[0].epoch == h[4] for h in self.handles)
 
+    def settle(self):
+        """Whatever the plans have queued is carried out."""
+        for p, _, _ in self.groups:
+            p.flush()
+
     def _summarise(self):
         """The LDS graphs per handle, once they are all on the device."""
         by = {}
@@ -172,8 +177,15 @@ class Network(object):
                 if sched is None or not sched.valid():
                     sched = _Schedule(self._groups())
                 sched.update()                                  # network.py:46-48
-                if not sched.valid():
+                for _ in range(8):
+                    # carrying out the requests can move a graph to another plan (a handle of its own, the node-by-node plan,
+                    # back to the fused one), with requests still queued: group again and settle those too
+                    if sched.valid():
+                        break
                     sched = _Schedule(self._groups())
+                    sched.settle()
+                else:
+                    raise RuntimeError("the graphs kept changing plans")
                 self.llb = sched.llb()                          # network.py:49
                 if verbose:
                     print(niters - i, self.llb)

@@ -191,3 +191,19 @@ def test_assignments_reach_the_right_replicate(host_only):
     more["As"][1].qmu = np.array([[2.0], [3.0]])                # after the queued sweep
     assert len(host_only.instances) == n + 1
     assert np.array_equal(more["As"][1].qmu, np.array([[2.0], [3.0]]))
+
+
+def test_random_interleavings_over_graphs_that_share_a_handle(host_only, capsys):
+    """profiles/fuzz_groups.py on the host-only stand-ins: random operations to one, some or all of M graphs of one structure,
+    every read against a twin on the node-by-node plan.  (The GPU box runs the same script on the HIP library with all noise
+    kinds: profiles/r04/fuzz_groups.txt.)"""
+    import importlib.util, sys
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    sys.path.insert(0, prof)
+    try:
+        spec = importlib.util.spec_from_file_location("fuzz_groups", os.path.join(prof, "fuzz_groups.py"))
+        F = importlib.util.module_from_spec(spec); spec.loader.exec_module(F)
+        worst, shared, left = F.main(cases=12, seed=5, noises=("gamma", "diagonal_gamma"), noise_p=(0.5, 0.5), allow_missing=False)
+    finally:
+        sys.path.remove(prof)
+    assert worst < 1e-8 and shared > 20 and left > 0
