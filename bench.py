@@ -86,7 +86,7 @@ def cpu_baseline_and_parity(sample, pri, iters, got_elbo, got_X):
     # the reference itself cannot run on the GPU box (Python 2 source, never shipped); its rate is measured in the build
     # container by profiles/reference_cpu.py at the same D, K and a short chain, and extrapolated (cost is linear in T
     # and in the number of replicates): reported next to the port, from the committed file
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         path = os.path.join(REPO, "profiles", tag, "reference_cpu.json")
         if os.path.exists(path):
             base["reference_extrapolated"] = json.load(open(path))
@@ -242,13 +242,23 @@ def d128_workload(steps, warmup, with_cpu):
     nt = float(N) * T
     alg = nt * (8 * D * D + 4 * D * K) + nt * (4 * D * D + 2 * D * K + 2 * K)      # two sweeps + all statistics, as the headline's roofline.iteration
     step_s = dt / steps
+    # HBM bytes of an iteration: the PMC passes over this workload committed with the round's profiles (NOT measured in this run)
+    traffic, tsrc, tparts = None, None, None
+    tpath = os.path.join(REPO, "profiles", "r04", "traffic_d128_pmc.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        tparts = {k.split("(")[0].replace("void ", ""): v["hbm_bytes_per_launch"] for k, v in tj.items()}
+        traffic = float(sum(tparts.values()))
+        tsrc = "profiles/r04/traffic_d128_pmc.json: one launch each of k_gy_big, k_sweep_big<3,2>, k_sweep_big<2,2>, k_stats_big, k_prep_big, k_cols_big (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; not measured in this run)"
     return {"workload": "LDS T=%d D=%d K=%d, %d replicates (second shape class of the fused kernels)" % (T, D, K, N),
             "metric": "VB iterations/sec per 1024 replicates", "value": steps / dt, "unit": "VB iterations/s", "steps": steps, "warmup": warmup,
             "ms_per_step": step_s * 1e3, "dtype": "f64", "rel_err_vs_numpy": parity,
             "parity_checked_on": "a T=%d, %d-replicate problem of the same shape class, %d iterations, same kernels" % (Ts, Ns, its),
             "elbo_total": float(elbo.sum()),
             "roofline": {"bound": "mfma", "achieved": alg / step_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": alg / step_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops": alg, "traffic": None,
+                         "frac": alg / step_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops": alg, "traffic": traffic, "traffic_source": tsrc,
+                         "traffic_by_kernel": tparts, "algorithmic_bytes": nt * 16 * (K + 2 * D),
+                         "hbm_GBs_at_measured_traffic": (traffic / step_s / 1e9) if traffic else None,
                          "kernel": "whole iteration (k_gy_big, k_sweep_big, k_stats_big, k_prep_big, k_cols_big)"},
             "cpu_baseline": cpu}
 
@@ -469,7 +479,7 @@ def main():
     # HBM bytes per launch: PMC passes over this workload, committed with the round's profiles (NOT measured in this run)
     traffic, traffic_source = {}, None
     if (N, T, D, K) == (1024, 10000, 64, 64):
-        for tag in ("r03", "r02", "r01"):
+        for tag in ("r04", "r03", "r02", "r01"):
             tpath = os.path.join(REPO, "profiles", tag, "traffic_pmc.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))

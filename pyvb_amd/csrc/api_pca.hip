@@ -58,6 +58,14 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     h->SL = pca_stats_layout(h->DP, h->QP);
     h->world = 1;
     long nchunk = (16384 + h->DT - 1) / h->DT;      // pass 2 runs nchunk workgroups of ceil(DT / 2) wavefronts, pass 1 nchunk x 4
+    if (h->DT >= 13) {
+        // the sweep's workgroup (seven or eight wavefronts, 120 KB of LDS) has a CU to itself: ONE chunk per CU, so that every
+        // workgroup pays its prologue (operands, first tiles) and its partial sums once -- measured at N = 10^6 x 256:
+        // 1024 chunks (four rounds) 1.040 ms per iteration, 768: 1.028, 512: 1.009, 256: 0.990 (profiles/r04/pca_chunks.txt)
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) nchunk = ncu;
+    }
+    { const char* e = getenv("PYVB_PCA_CHUNKS"); if (e && atol(e) > 0) nchunk = atol(e); }      // (experiments)
     const long ntile = (N + 15) / 16;
     if (nchunk > ntile) nchunk = ntile;
     if (nchunk < 1) nchunk = 1;
