@@ -15,7 +15,7 @@
 // whose logs sum to 2 * sum log diag(chol(P)).
 #define GJ_BUF 136      // row (64), column (64), 1/pivot, padding
 template <int NP>
-__device__ static void gj_inverse(double (&v)[NP][16], int D, int tid, double* rc, double* pivs) {
+__device__ __forceinline__ void gj_inverse(double (&v)[NP][16], int D, int tid, double* rc, double* pivs) {
     const int a = tid >> 4, b = tid & 15;
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
@@ -101,7 +101,7 @@ __device__ __forceinline__ void gjw_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ static void gj_wave(double (&v)[8][8], int D, int lane, double* rc, double* pivs) {
+__device__ __forceinline__ void gj_wave(double (&v)[8][8], int D, int lane, double* rc, double* pivs) {
     const int a = lane >> 3, b = lane & 7;
     {
         double* row = rc;
@@ -165,7 +165,7 @@ __device__ static void gj_wave(double (&v)[8][8], int D, int lane, double* rc, d
 // of the ORIGINAL matrix P -- the conditional covariance and the regression of a Gaussian conditioned on the entries o
 // (gaussian.py:125-134), and sum_o ln(pivot) + ln det P = ln det P_uu.  The pivots need not be consecutive, so every step
 // publishes its own row, column and reciprocal first (two wave-level syncs per step); pivs2 [64] gets the pivots met.
-__device__ static void gj_wave_subset(double (&v)[8][8], unsigned long long mask, int lane, double* rc, double* pivs2) {
+__device__ __forceinline__ void gj_wave_subset(double (&v)[8][8], unsigned long long mask, int lane, double* rc, double* pivs2) {
     const int a = lane >> 3, b = lane & 7;
     for (int P = 0; P < 8; ++P) {
 #pragma unroll
@@ -213,7 +213,7 @@ __device__ static void gj_wave_subset(double (&v)[8][8], unsigned long long mask
 // (a = tid / 16, b = tid % 16) owns elements (8a + ra, 8b + cb)), Gauss-Jordan without pivoting as gj.h; rc: [2][264] doubles
 // of LDS (row 128, column 128, 1/pivot), pivs: [128].
 #define GJB_BUF 264
-__device__ static void gj_wg128(double (&v)[8][8], int D, int tid, double* rc, double* pivs) {
+__device__ __forceinline__ void gj_wg128(double (&v)[8][8], int D, int tid, double* rc, double* pivs) {
     const int a = tid >> 4, b = tid & 15;
     if (a == 0) {
 #pragma unroll

@@ -597,22 +597,40 @@ __device__ __forceinline__ void mm128(int wave, int lane, FA a_at, FB b_at, FS s
     }
 }
 
-// W <- W * W in place (LDS, stride BLD): both row tiles of every wavefront into registers (chains as in mm128), a barrier, then out
-__device__ static void square128(double* W, int wave, int lane) {
+// W <- W * W in place (LDS, stride BLD): both row tiles of every wavefront into registers, a barrier, then out.  Chains as in mm128:
+// a column tile is one chain of 32 dependent MFMAs whose 32 B operands were requested while the chain before it ran (read inside
+// the chain, each MFMA waited for its own LDS round trip: 170 cycles per MFMA instead of 70 -- the ten squarings of the two warm-up
+// bounds were 0.9 M of k_prep_big's 2.9 M cycles per workgroup).
+__device__ __forceinline__ void square128(double* W, int wave, int lane) {
     const int r = lane & 15, q = lane >> 4;
     d4 acc[2][BDT];
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
         const int m = wave + 4 * h2;
-        double av[BDS];
+        double av[BDS], bA[BDS], bB[BDS];
 #pragma unroll
         for (int s = 0; s < BDS; ++s) av[s] = W[(16 * m + r) * BLD + 4 * s + q];
+        auto fetch = [&](double (&bv)[BDS], int nn) {
+            const int nc = nn < BDT ? nn : BDT - 1;
 #pragma unroll
-        for (int nn = 0; nn < BDT; ++nn) {          // B operands straight from LDS: the compiler keeps a few reads ahead of the chain
-            d4 c = d4{0.0, 0.0, 0.0, 0.0};
+            for (int s = 0; s < BDS; ++s) bv[s] = W[(4 * s + q) * BLD + 16 * nc + r];
+        };
+        auto chain = [&](const double (&bv)[BDS], d4& c) {
+            c = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < BDS; ++s) c = MFMA(av[s], W[(4 * s + q) * BLD + 16 * nn + r], c);
-            acc[h2][nn] = c;
+            for (int s = 0; s < BDS; ++s) c = MFMA(av[s], bv[s], c);
+        };
+        fetch(bA, 0);
+#pragma unroll
+        for (int nn = 0; nn < BDT; nn += 2) {
+            fetch(bB, nn + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            chain(bA, acc[h2][nn]);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(bA, nn + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            chain(bB, acc[h2][nn + 1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
@@ -626,7 +644,7 @@ __device__ static void square128(double* W, int wave, int lane) {
 }
 
 // max_i sum_j |W_ij| over the 128 x 128 matrix: two threads per row
-__device__ static double inf_norm128(const double* W, int tid, double* red) {
+__device__ __forceinline__ double inf_norm128(const double* W, int tid, double* red) {
     const int row = tid >> 1, part = tid & 1;
     double s = 0.0;
 #pragma unroll 8
@@ -642,7 +660,9 @@ __device__ static double inf_norm128(const double* W, int tid, double* red) {
 }
 
 // k_prep.hip: warmup_length, for the 128 x 128 recurrence matrix in W (clobbered)
-__device__ static int warmup128(double* W, int tid, double* red) {
+// (forced inline: as a called function its squarings ran with ~1000 scratch accesses each -- the calling convention's saved registers
+// and the spills they cause -- and took 2.7x the matrix pipe's time)
+__device__ __forceinline__ int warmup128(double* W, int tid, double* red) {
     const double lntol = -41.4465316738928;   // ln(1e-18)
     const int wave = tid >> 6, lane = tid & 63;
     double l2 = 1.0, l3 = 1.0, l4 = 1.0, l5 = 1.0;

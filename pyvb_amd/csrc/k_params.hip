@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64 * NW) k_noise(ParamArgs a) {
 }
 
 // log_lower_bound of one Gamma-family entry  nodes_todo.py:149-157 / :199-204
-__device__ static double gamma_llb(double a0, double b0, double qa, double qb) {
+__device__ __forceinline__ double gamma_llb(double a0, double b0, double qa, double qb) {
     const double Elnx = digamma_pos(qa) - log(qb);
     double ret = (a0 - 1.0) * Elnx - lgamma(a0) + a0 * log(b0) - b0 * (qa / qb);
     ret -= (qa - 1.0) * Elnx - lgamma(qa) + qa * log(qb) - qb * (qa / qb);

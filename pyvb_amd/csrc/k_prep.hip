@@ -76,7 +76,7 @@ __device__ __forceinline__ void mm_out(int m, int lane, const d4 (&acc)[NT], FS 
 
 // max_i sum_j |A_ij|: four threads per row (16 columns each), rows and then wavefronts combined by
 // shuffles; two barriers.  red: 4 doubles of LDS.
-__device__ static double inf_norm(const double* A, int LD, int D, int tid, double* red) {
+__device__ __forceinline__ double inf_norm(const double* A, int LD, int D, int tid, double* red) {
     const int row = tid >> 2, part = tid & 3;
     double s = 0.0;
     if (row < D) {
@@ -102,8 +102,10 @@ __device__ static double inf_norm(const double* A, int LD, int D, int tid, doubl
 // n_k = ||M^(2^k)|| (k = 2..5, from repeated squaring) every J = 4 a + 8 b + 16 c + 32 d has
 // ||M^J|| <= n_2^a n_3^b n_4^c n_5^d; the smallest such J under the tolerance is taken.
 // M is in W1 (padded with zeros) on entry; W1/W2 are clobbered.
+// (Forced inline, as everything on the hot path of this kernel: as a called function it is subject to the calling convention --
+// saved registers, operands through memory; k_big.hip's warmup128 ran with ~1000 scratch accesses per squaring that way.)
 template <int DT>
-__device__ static int warmup_length(double* W1, double* W2, int LD, int D, int tid, double* red) {
+__device__ __forceinline__ int warmup_length(double* W1, double* W2, int LD, int D, int tid, double* red) {
     constexpr int DS = 4 * DT;
     const double lntol = -41.4465316738928;   // ln(1e-18)
     const int wave = tid >> 6, lane = tid & 63;

@@ -525,12 +525,12 @@ int launch_cov_convert(pyvb_lds* h, int which, double* dense, int n0, int count,
     return PYVB_OK;
 }
 
-__device__ static double psi_multi(double x, int D) {       // sum_{i<D} psi(x - i/2)
+__device__ __forceinline__ double psi_multi(double x, int D) {       // sum_{i<D} psi(x - i/2)
     double s = 0.0;
     for (int i = 0; i < D; ++i) s += digamma_pos(x - 0.5 * i);
     return s;
 }
-__device__ static double lgamma_multi(double x, int D) {    // ln |Gamma_D(x)|
+__device__ __forceinline__ double lgamma_multi(double x, int D) {    // ln |Gamma_D(x)|
     double s = 0.25 * D * (D - 1) * 1.1447298858494002;     // ln pi
     for (int i = 0; i < D; ++i) s += lgamma(x - 0.5 * i);
     return s;
