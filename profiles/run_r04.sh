@@ -15,7 +15,7 @@ if [ "$PART" = A ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C -d $OUT/tr/$C -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/tr_$C.log 2>&1
   done
-  python3 $ROOT/profiles/traffic_summary.py $OUT/tr k_sweep k_stats k_prep k_cols k_gy_big k_pca_pass12 k_pca_small k_pca_reduce k_pca_rowvar > $OUT/traffic_pmc.json
+  python3 $ROOT/profiles/traffic_summary.py $OUT/tr k_sweep k_stats k_prep k_cols k_gy_big k_pca_pass12 k_pca_pairs k_pca_small k_pca_reduce k_pca_rowvar > $OUT/traffic_pmc.json
   rm -rf $OUT/stats/*.db $OUT/tr/*/*.db 2>/dev/null || true
   ls -l $OUT
 fi
@@ -32,13 +32,22 @@ if [ "$PART" = B ]; then
   python3 $ROOT/profiles/pca_trace_summary.py $OUT/pca_stats/p_kernel_trace.csv > $OUT/pca_iteration_timeline.txt || true
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $OUT/pmc -o p --output-format csv -- python3 $ROOT/profiles/headline_probe.py 3 > $OUT/pmc.log 2>&1
   python3 $ROOT/profiles/pmc_summary.py $OUT/pmc/p_counter_collection.csv $OUT/pmc/p_kernel_trace.csv > $OUT/pmc_clock_mfma.txt || true
-  rm -rf $OUT/pca_stats/*.db $OUT/pmc/*.db 2>/dev/null || true
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $OUT/pmc_pca -o p --output-format csv -- python3 $ROOT/profiles/pca_probe.py 1000000 256 16 5 > $OUT/pmc_pca.log 2>&1
+  python3 $ROOT/profiles/pmc_summary.py $OUT/pmc_pca/p_counter_collection.csv $OUT/pmc_pca/p_kernel_trace.csv > $OUT/pmc_clock_mfma_pca.txt || true
+  rm -rf $OUT/pca_stats/*.db $OUT/pmc/*.db $OUT/pmc_pca/*.db 2>/dev/null || true
+  cd $ROOT
+  for s in columns rows pairs; do echo -n "$s: " >> $OUT/pca_sweeps.txt; PYVB_PCA_SWEEP=$s python3 profiles/bench_pca.py --no-cpu-baseline --steps 100 | grep -o '"ms_per_step": [0-9.]*' >> $OUT/pca_sweeps.txt; done
+  (PYVB_PCA_WRITEBACK=1 python3 profiles/bench_pca.py --no-cpu-baseline --steps 100 | grep -o '"ms_per_step": [0-9.]*' | sed 's/^/write-back: /') >> $OUT/pca_sweeps.txt
+  $ROOT/build/hbm_read > $OUT/hbm_read_microbench.txt 2>&1 || true
 fi
 if [ "$PART" = C ]; then
   cd $ROOT
   mkdir -p $OUT/fuzz
   for f in fuzz_batch fuzz_batch_pca fuzz_generic fuzz_more soak; do
     timeout -k 10 180 python3 profiles/$f.py > $OUT/fuzz/$f.txt 2>&1; echo "$f rc=$? : $(tail -1 $OUT/fuzz/$f.txt)"
+  done
+  for f in fuzz_batch_pca fuzz_ops_pca; do          # the VB-PCA fuzzers again through the pair-owning sweep (small problems default to the column-owning one)
+    PYVB_PCA_SWEEP=pairs timeout -k 10 180 python3 profiles/$f.py > $OUT/fuzz/${f}_pairs.txt 2>&1; echo "$f (pairs) rc=$? : $(tail -1 $OUT/fuzz/${f}_pairs.txt)"
   done
   timeout -k 10 200 python3 profiles/fuzz_shapes.py 30 3 > $OUT/fuzz/fuzz_shapes.txt 2>&1; echo "fuzz_shapes rc=$? : $(tail -1 $OUT/fuzz/fuzz_shapes.txt)"
 fi

@@ -88,7 +88,6 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
     TRY(alloc_d(&h->W_pm, (size_t)d * q)); TRY(alloc_d(&h->W_pp, (size_t)q * d)); TRY(alloc_d(&h->Mu_pm, d)); TRY(alloc_d(&h->Mu_pp, d));
     TRY(alloc_d(&h->W_x, (size_t)d * q)); TRY(alloc_d(&h->Mu_x, d));
     { const char* e = getenv("PYVB_PCA_WRITEBACK"); h->lazy_ok = !(e && e[0] == '1'); }
-    { const char* e = getenv("PYVB_PCA_SWEEP"); h->rows_ok = e && e[0] == 'r'; }       // "rows": k_pca_rows (measured slower: k_pca.hip)
     {   // k_pca_rows: one workgroup of four wavefronts per CU, the rows dealt out in multiples of 16
         int ncu = 0;
         TRYHIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -99,6 +98,14 @@ int pyvb_pca_create(pyvb_pca** out, int device, long N, int d, int q, long N_tot
         long ncB = (N + rowsB - 1) / rowsB;
         if (ncB > nchunk) { ncB = nchunk; rowsB = ((N + ncB - 1) / ncB + 15) & ~15L; ncB = (N + rowsB - 1) / rowsB; }
         h->nchunkB = (int)ncB; h->chunk_rowsB = rowsB;
+        // which kernel the lazy sweep is (k_pca.hip): PYVB_PCA_SWEEP = columns (k_pca_pass12<.., LAZY>) / rows (k_pca_rows) / pairs
+        // (k_pca_pairs); unset: pairs where a CU's share is long enough to stream (measured at 10^6 x 256: 0.95 against 0.97 ms per
+        // iteration), columns otherwise
+        const char* e = getenv("PYVB_PCA_SWEEP");
+        if (e && e[0] == 'r') h->rows_ok = 1;
+        else if (e && e[0] == 'p') h->rows_ok = 2;
+        else if (e && e[0] == 'c') h->rows_ok = 0;
+        else h->rows_ok = (h->DT >= 13 && N >= 512L * ncu) ? 2 : 0;
     }
     TRY(alloc_d(&h->scal, PS_COUNT));
     TRY(alloc_d(&h->Gz, (size_t)h->QT * (DP / 4) * 64)); TRY(alloc_d(&h->g0, QP));

@@ -935,6 +935,293 @@ __global__ void __launch_bounds__(64 * PR_NW) k_pca_rows(PcaArgs a) {
     if (tid < a.DT) P[a.SL.total + tid] = tid == 0 ? red[4624] : 0.0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Third form (round 4): a PAIR of wavefronts owns a 16-row tile, each wavefront one half of the columns.
+//
+// k_pca_rows showed that the barrier-free ownership computes the right thing but cannot keep the matrix pipe fed with one wavefront
+// per SIMD -- and one is all that fits while a wavefront carries the whole 256 x 16 sum x z^T (128 accumulator registers).  Split
+// over two wavefronts (columns [128 h, 128 h + 128), h = 0, 1) everything per wavefront halves -- accumulators, operands, the ring
+// of X -- and eight wavefronts fit a CU, two to a SIMD (252 registers), four pairs walking through their tiles independently.
+// What the pair has to exchange per tile is ONE 16 x 16 partial of Z: each wavefront leaves its partial in LDS, raises a flag, waits
+// for the partner's (a spin on an LDS word, both are resident: no deadlock), and both form z = part_0 + part_1 - g0 in that order.
+// No workgroup barrier between the prologue and the final reduction.  Everything else as k_pca_rows (phases A, B, C; LAZY).
+#define PP_NW 8
+#ifndef PP_ROT
+#define PP_ROT 0
+#endif
+template <bool FULL>
+__global__ void __launch_bounds__(64 * PP_NW) k_pca_pairs(PcaArgs a) {
+    extern __shared__ double ldsr[];
+    constexpr int QS = 4, NB = 4, RING = 4, AHEAD = 3;      // NB: the 32-column blocks of a wavefront (half a row)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, qk = lane >> 4;
+    const int pair = wave >> 1, half = wave & 1;
+    const int DP = a.DP, d = a.d, q = a.q, DT = a.DT;
+    constexpr int QP = 16;
+    double* const gzL = ldsr;                               // [DT][4][64]   B operands of Z = X Gz^T (a.Gz as it is)
+    double* const waL = gzL + (size_t)DT * 256;             // [DT][4][64]   <W> tiles, rows permuted (k_pca_pass12, 3.)
+    double* const wxL = waL + (size_t)DT * 256;             // the same of <W>_x
+    double* const muL = wxL + (size_t)DT * 256;             // [DP]
+    double* const mxL = muL + DP;                           // [DP]
+    double* const g0L = mxL + DP;                           // [16]
+    double* const xtw = g0L + 32 + (size_t)wave * (16 * P12_XS);                // this wavefront's: the 32-column piece [16][P12_XS] ...
+    double* const zTw = xtw;                                                     // ... and, before phase C needs it, z transposed [16][17]
+    double* const xch = g0L + 32 + (size_t)PP_NW * (16 * P12_XS);               // [wave][4][64] the partial of Z a wavefront hands to its partner
+    int* const flags = reinterpret_cast<int*>(xch + (size_t)PP_NW * 256);        // [wave][2]: tiles whose partial is ready / whose partner partial has been read
+    if (tid < 2 * PP_NW) flags[tid] = 0;
+#ifdef P12_STAMP
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = st_t0;
+#endif
+    for (int i = tid; i < DT * 256; i += 64 * PP_NW) {
+        gzL[i] = a.Gz[i];
+        const int j = i >> 8, s4 = (i >> 6) & 3, ln = i & 63, cc = ln & 15, qq = ln >> 4;
+        const int dimA = 16 * j + 4 * (cc & 3) + (cc >> 2), li = 4 * s4 + qq;
+        const bool in = dimA < d && li < q;
+        waL[i] = in ? a.W_mean[(size_t)dimA * q + li] : 0.0;
+        wxL[i] = in ? a.W_x[(size_t)dimA * q + li] : 0.0;
+    }
+    for (int k = tid; k < DP; k += 64 * PP_NW) { muL[k] = k < d ? a.Mu_mean[k] : 0.0; mxL[k] = k < d ? a.Mu_x[k] : 0.0; }
+    if (tid < 16) g0L[tid] = a.g0[tid];
+    __syncthreads();
+
+    const long r0 = (long)blockIdx.x * a.chunk_rows;
+    const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
+    const unsigned nrows = (unsigned)(r1 - r0);
+    const unsigned ntiles = (nrows + 15) >> 4;
+    double* const Xc = a.X + (size_t)r0 * DP;
+    const unsigned char* const Mc = a.M + (size_t)r0 * DP;
+    double* const Zc = a.Z + (size_t)r0 * QP;
+    const unsigned lo = a.lo_upd > r0 ? (unsigned)((a.lo_upd < r1 ? a.lo_upd : r1) - r0) : 0u;
+    const unsigned hi = a.hi_upd > r0 ? (unsigned)((a.hi_upd < r1 ? a.hi_upd : r1) - r0) : 0u;
+    const unsigned vlo = a.vin_lo > r0 ? (unsigned)((a.vin_lo < r1 ? a.vin_lo : r1) - r0) : 0u;
+    const unsigned vhi = a.vin_hi > r0 ? (unsigned)((a.vin_hi < r1 ? a.vin_hi : r1) - r0) : 0u;
+    const bool z0_here = a.keep_z0 && a.row_offset == 0 && r0 == 0;
+    // g0 and the kept z_0 stay in LDS (g0L[16..32)): as registers they were spilled, and a reload from scratch inside the loop is
+    // a memory load that every row in flight has to land in front of
+    if (wave == 0 && lane < 16) g0L[16 + lane] = z0_here ? Zc[lane] : 0.0;
+    __syncthreads();
+
+    d4 sxz[NB][2], szz = d4{0, 0, 0, 0};
+    double sx[NB][2], sxx = 0.0, sz = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { sxz[b][p] = d4{0, 0, 0, 0}; sx[b][p] = 0.0; }
+
+    // ---- the stream of X: position pos of a tile = block pos % 8 (0..7 phase A, 8..15 phase C); the set of position pos is pos % 4
+    d4 rx[RING][2]; unsigned rm[RING][2];
+    // workgroup b walks its chunk from tile (rot) on, round: the chunks lie a fixed 8 MB apart, and 256 workgroups in step at that
+    // stride would keep asking the same few HBM channels
+    const unsigned rot = ntiles ? (unsigned)((blockIdx.x * PP_ROT) % ntiles) : 0u;
+    auto TI = [&](unsigned tl) { const unsigned u = tl + rot; return u >= ntiles ? u - ntiles : u; };
+    auto fetch = [&](d4 (&x)[2], unsigned (&m)[2], unsigned tile, int b) {
+        const unsigned rw = 16u * TI(tile) + c;
+        const unsigned row = rw < nrows ? rw : nrows - 1;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * (NB * half + b) + jj;
+            const unsigned off = row * DP + ((FULL || j < DT) ? 16 * j + 4 * qk : 0);
+            x[jj] = *reinterpret_cast<const d4*>(Xc + off);
+            m[jj] = *reinterpret_cast<const unsigned*>(Mc + off);
+        }
+    };
+    auto zfetch = [&](double (&z)[QS], unsigned tile) {
+        const unsigned rw = 16u * TI(tile) + c;
+        const unsigned row = rw < nrows ? rw : nrows - 1;
+#pragma unroll
+        for (int s4 = 0; s4 < QS; ++s4) z[s4] = Zc[(size_t)row * QP + 4 * s4 + qk];
+    };
+    double zq[QS];                      // previous z of the tile's rows, operand of the recomputation
+    unsigned t = pair;
+    int seq = 0;                        // tiles of this pair so far
+    if (t < ntiles) {
+        // in the order of the loop (z first, the blocks behind it): the counter of outstanding loads the compiler waits on at the
+        // loop head is the minimum over the way in and the way round
+        zfetch(zq, t);
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) fetch(rx[u], rm[u], t, u);
+    }
+    for (; t < ntiles; t += PP_NW / 2) {
+        const unsigned n0 = 16u * TI(t), rowl = n0 + c;
+        const unsigned tnext = (t + PP_NW / 2 < ntiles) ? t + PP_NW / 2 : t;
+        const bool rowv = rowl >= vlo && rowl < vhi;
+        const bool rowupd = rowl < nrows && rowl >= lo && rowl < hi;
+        d4 zacc = d4{0, 0, 0, 0};
+        d4 z;
+        double za[QS];
+#pragma unroll
+        for (int pos = 0; pos < 2 * NB; ++pos) {
+            const int b = pos & (NB - 1);
+            const int gb = NB * half + b;           // the block's place in the row
+            d4 (&xa)[2] = rx[pos & (RING - 1)];
+            unsigned (&ma)[2] = rm[pos & (RING - 1)];
+            if (pos < NB) {
+                // ---- A: recompute what the sweep before left unstored, then this block's part of Z.  All operands of the block
+                // are requested from LDS first (one wait per block, not one per product: a single wavefront per SIMD has nobody
+                // to hide an LDS round trip behind), the ones of the recomputation ahead of the ones of the Z product.
+                // (two wavefronts share the SIMD here: the operands of one 16-column tile at a time, the other wavefront covers the
+                // LDS round trip -- and the registers of a whole block's operands are not there to be had)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    if (FULL || 2 * gb + jj < DT) {
+                        const int j = 2 * gb + jj;
+                        double wxo[QS], gzo[4];
+                        d4 pred = *reinterpret_cast<const d4*>(mxL + 16 * j + 4 * qk);
+#pragma unroll
+                        for (int s4 = 0; s4 < QS; ++s4) wxo[s4] = wxL[(j * 4 + s4) * 64 + lane];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gzo[e] = gzL[(j * 4 + e) * 64 + lane];
+#pragma unroll
+                        for (int s4 = 0; s4 < QS; ++s4) pred = MFMA(wxo[s4], zq[s4], pred);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (rowv && ((ma[jj] >> (8 * e)) & 0xffu) == 0) xa[jj][e] = pred[e];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zacc = MFMA(xa[jj][e], gzo[e], zacc);
+                    }
+                }
+            } else {
+                // ---- C: prediction, imputation, statistics of this block
+                if (FULL || 2 * gb < DT) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        d4 v = xa[jj];
+                        if (FULL || 2 * gb + jj < DT) {
+                            const int j = 2 * gb + jj;
+                            double wao[QS];
+                            d4 pred = *reinterpret_cast<const d4*>(muL + 16 * j + 4 * qk);
+#pragma unroll
+                            for (int s4 = 0; s4 < QS; ++s4) wao[s4] = waL[(j * 4 + s4) * 64 + lane];
+#pragma unroll
+                            for (int s4 = 0; s4 < QS; ++s4) pred = MFMA(wao[s4], za[s4], pred);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (rowupd && ((ma[jj] >> (8 * e)) & 0xffu) == 0) v[e] = pred[e];
+                        } else v = d4{0, 0, 0, 0};
+                        *reinterpret_cast<d4*>(xtw + c * P12_XS + 16 * jj + 4 * qk) = v;
+                    }
+                    wave_lds_sync();
+                    d4 xn[2];
+                    d2 v2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v2[r] = *reinterpret_cast<const d2*>(xtw + (4 * r + qk) * P12_XS + 2 * c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool live = (n0 + 4 * r + qk < nrows) && (FULL || 32 * gb + 2 * c < DP);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const double x = live ? v2[r][p] : 0.0;
+                            xn[p][r] = x; sx[b][p] += x; sxx += x * x;
+                        }
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) sxz[b][p] = MFMA(xn[p][s4], z[s4], sxz[b][p]);
+                    wave_lds_sync();                    // the piece has been read: the next block may overwrite it
+                }
+            }
+            // the set of three positions on: same tile while it lasts, then the wavefront's next tile
+            // (pinned between two scheduling barriers: at the register limit the compiler otherwise sinks these loads to just before
+            // their use three positions later -- the listing showed waits for all but two or three loads in flight -- and the ring
+            // hides nothing)
+            {
+                const int np = pos + AHEAD;
+                __builtin_amdgcn_sched_barrier(0);
+                if (np < 2 * NB) fetch(rx[np & (RING - 1)], rm[np & (RING - 1)], t, np & (NB - 1));
+                else fetch(rx[np & (RING - 1)], rm[np & (RING - 1)], tnext, np - 2 * NB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (pos == NB - 1) {
+                // ---- the pair's hand-over: my partial into my slot (once the partner has read the one before), flag up; the partner's
+                ++seq;
+                STAMP(0);
+                while (__hip_atomic_load(&flags[2 * (wave ^ 1) + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq - 1) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xch[(size_t)wave * 256 + r * 64 + lane] = zacc[r];
+                __hip_atomic_store(&flags[2 * wave], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(&flags[2 * (wave ^ 1)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+                STAMP(1);
+                d4 other;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) other[r] = xch[(size_t)(wave ^ 1) * 256 + r * 64 + lane];
+                __hip_atomic_store(&flags[2 * wave + 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // ---- B: the tile's z (accumulator layout: lane (qk, c), register r = row 4 r + qk, latent index c), the same bits in
+                // both wavefronts: part_0 + part_1 - g0
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned row = n0 + 4 * r + qk;
+                    double v = ((half == 0 ? zacc[r] : other[r]) + (half == 0 ? other[r] : zacc[r])) - g0L[c];
+                    const bool keep = z0_here && row == 0;      // z_0 was stored by Xs[0].update() itself (keep_z0)
+                    if (keep) v = g0L[16 + c];
+                    if (row < nrows) { if (!keep && half == 0) Zc[(size_t)row * QP + c] = v; }
+                    else v = 0.0;
+                    z[r] = v;
+                    if (half == 0) sz += v;
+                    zTw[c * 17 + 4 * r + qk] = v;
+                }
+                if (half == 0) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) szz = MFMA(z[s4], z[s4], szz);
+                }
+                zfetch(zq, tnext);                      // rows of this pair's next tile: nobody writes them before wavefront 0 of the pair does
+                wave_lds_sync();
+#pragma unroll
+                for (int s4 = 0; s4 < QS; ++s4) za[s4] = zTw[(4 * s4 + qk) * 17 + c];
+                wave_lds_sync();                        // (z transposed shares its place with the 32-column piece of phase C)
+                STAMP(2);
+            }
+        }
+        STAMP(3);
+    }
+#ifdef P12_STAMP
+    if (lane == 0 && wave < 2) {        // phase A | the wait for the partner | phase B | phase C | - | whole kernel in shader ticks, in 100 MHz ticks | tiles
+        unsigned long long* o = g_p12_stamp + ((size_t)blockIdx.x * 2 + wave) * 12;
+        for (int i = 0; i < 4; ++i) o[i] = st_acc[i];
+        o[10] = __builtin_amdgcn_s_memtime() - st_t0; o[9] = __builtin_amdgcn_s_memrealtime() - st_r0; o[11] = (unsigned long long)seq;
+    }
+#endif
+    // ---- the wavefronts' sums into one per workgroup, in wavefront order (LDS: the tables are done with)
+    __syncthreads();
+    double* const red = ldsr;           // [Sxz 256 x 16 | sx 256 | Szz 16 x 16 | sz 16 | sxx]
+    for (int w = 0; w < PP_NW; ++w) {
+        if (wave == w) {
+            const bool first = w < 2;               // the first wavefront on each half of the columns
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int dim = 32 * (NB * half + b) + 2 * (4 * r + qk) + p;
+                        double* o = red + (size_t)dim * QP + c;
+                        *o = first ? sxz[b][p][r] : *o + sxz[b][p][r];
+                    }
+                    double s = sx[b][p];
+                    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                    if (qk == 0) { double* o = red + 4096 + 32 * (NB * half + b) + 2 * c + p; *o = first ? s : *o + s; }
+                }
+            if (half == 0) {                        // z belongs to the pair: its first wavefront has summed it
+                const bool f0 = w == 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { double* o = red + 4352 + (4 * r + qk) * QP + c; *o = f0 ? szz[r] : *o + szz[r]; }
+                double s = sz;
+                s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                if (qk == 0) { double* o = red + 4608 + c; *o = f0 ? s : *o + s; }
+            }
+            const double sq = wsum(sxx);
+            if (lane == 0) { double* o = red + 4624; *o = (w == 0) ? sq : *o + sq; }
+        }
+        __syncthreads();
+    }
+    double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
+    for (int i = tid; i < DP * QP; i += 64 * PP_NW) P[a.SL.oSxz + i] = red[i];
+    for (int i = tid; i < DP; i += 64 * PP_NW) P[a.SL.osx + i] = red[4096 + i];
+    for (int i = tid; i < QP * QP; i += 64 * PP_NW) P[a.SL.oSzz + i] = red[4352 + i];
+    if (tid < QP) P[a.SL.osz + tid] = red[4608 + tid];
+    if (tid < a.DT) P[a.SL.total + tid] = tid == 0 ? red[4624] : 0.0;
+}
+
 // The missing entries of rows [vin_lo, vin_hi) into X: <W>_x z_n + <Mu>_x, formed exactly as stage 0 of k_pca_pass12<.., LAZY> forms
 // them (same operands, same chain of MFMAs: bit for bit what the next sweep would have used).  Same mapping: a workgroup per row
 // chunk, wavefront w on columns [32 w, 32 w + 32).
@@ -1437,17 +1724,25 @@ int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
     if (lazy && h->xlazy) { a.vin_lo = h->vlo; a.vin_hi = h->vhi; }
     a.save_wx = lazy ? 1 : 0;
     if (lazy && h->rows_ok) {
-        // the row-owning sweep (k_pca_rows) on its own partition of the rows: one workgroup per CU, equal shares of 16-row tiles
+        // the row-owning sweeps (k_pca_rows, k_pca_pairs) on their own partition of the rows: one workgroup per CU, equal shares of 16-row tiles
         a.nchunk = h->nchunkB; a.chunk_rows = h->chunk_rowsB;
-        size_t need = 3 * (size_t)h->DT * 256 + 2 * (size_t)h->DP + 16 + PR_NW * (16 * 17 + 16 * P12_XS);
+        const bool pairs = h->rows_ok == 2;
+        size_t need = 3 * (size_t)h->DT * 256 + 2 * (size_t)h->DP + 16 +
+                      (pairs ? 16 + PP_NW * (16 * P12_XS) + PP_NW * 256 + 8 : PR_NW * (16 * 17 + 16 * P12_XS));
         if (need < 4640) need = 4640;                   // the final reduction's buffer
         const size_t lds = need * sizeof(double);
         if (!h->rows_attr_set) {
             HIPCHK(hipFuncSetAttribute((const void*)k_pca_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIPCHK(hipFuncSetAttribute((const void*)k_pca_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void*)k_pca_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void*)k_pca_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             h->rows_attr_set = true;
         }
-        if (h->DT == 16) hipLaunchKernelGGL(k_pca_rows<true>, dim3(a.nchunk), dim3(64 * PR_NW), lds, h->stream, a);
+        if (pairs) {
+            if (h->DT == 16) hipLaunchKernelGGL(k_pca_pairs<true>, dim3(a.nchunk), dim3(64 * PP_NW), lds, h->stream, a);
+            else hipLaunchKernelGGL(k_pca_pairs<false>, dim3(a.nchunk), dim3(64 * PP_NW), lds, h->stream, a);
+        }
+        else if (h->DT == 16) hipLaunchKernelGGL(k_pca_rows<true>, dim3(a.nchunk), dim3(64 * PR_NW), lds, h->stream, a);
         else hipLaunchKernelGGL(k_pca_rows<false>, dim3(a.nchunk), dim3(64 * PR_NW), lds, h->stream, a);
         hipLaunchKernelGGL(k_pca_rowvar, dim3(a.nchunk), dim3(256), 0, h->stream, a);
         HIPCHK(hipGetLastError());

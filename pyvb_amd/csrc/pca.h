@@ -60,7 +60,7 @@ struct pyvb_pca {
     bool xlazy; long vlo, vhi;           // the missing entries of rows [vlo, vhi) are not in X: they stand for <W>_x z_n + <Mu>_x
                                          // (k_pca_pass12<.., LAZY>); pca_materialize_x puts them there
     bool lazy_ok;                        // PYVB_PCA_WRITEBACK=1 in the environment at creation turns the lazy sweep off (A/B measurements)
-    bool rows_ok;                        // PYVB_PCA_SWEEP=rows at creation: the lazy sweep is k_pca_rows instead of k_pca_pass12<.., LAZY>
+    int rows_ok;                         // the lazy sweep is k_pca_pass12<.., LAZY> (0), k_pca_rows (1) or k_pca_pairs (2): chosen at creation (api_pca.hip, PYVB_PCA_SWEEP)
     int nchunkB; long chunk_rowsB;       // k_pca_rows' partition of the rows: a workgroup per CU
     int part_chunks;                     // chunks of the partial statistics in `part` now
     bool rows_attr_set;

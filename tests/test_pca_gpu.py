@@ -55,12 +55,13 @@ def test_golden_fixtures(path):
     b.close()
 
 
+@pytest.mark.parametrize("sweep", ["rows", "pairs"])
 @pytest.mark.parametrize("path", [f for f in FILES if "default_init" not in f], ids=lambda p: os.path.basename(p)[4:-4])
-def test_golden_fixtures_through_the_row_owning_sweep(path, monkeypatch):
-    """k_pca_rows (a wavefront owns whole rows; PYVB_PCA_SWEEP=rows at handle creation): measured slower than the sweep in use
-    (pyvb_amd/csrc/k_pca.hip) and kept as an alternative -- it has to give the reference's numbers all the same."""
+def test_golden_fixtures_through_the_row_owning_sweeps(path, sweep, monkeypatch):
+    """k_pca_rows (a wavefront owns whole rows) and k_pca_pairs (a pair of wavefronts does, half the columns each), chosen with
+    PYVB_PCA_SWEEP at handle creation (pyvb_amd/csrc/k_pca.hip): they have to give the reference's numbers all the same."""
     from pyvb_amd.pca import PCABatch
-    monkeypatch.setenv("PYVB_PCA_SWEEP", "rows")
+    monkeypatch.setenv("PYVB_PCA_SWEEP", sweep)
     N, d, q, init, pri, z = _load(path)
     b = PCABatch.from_problem(init, pri)
     for it in range(1, int(max(z["iters"])) + 1):
@@ -76,7 +77,7 @@ def test_golden_fixtures_through_the_row_owning_sweep(path, monkeypatch):
     b.close()
 
 
-@pytest.mark.parametrize("sweep", ["columns", "rows"])
+@pytest.mark.parametrize("sweep", ["columns", "rows", "pairs"])
 def test_imputed_entries_are_recomputed_not_stored(sweep, monkeypatch):
     """Round 4: the sweep of an iteration leaves the imputed entries of X unstored (they are <W> z_n + <Mu> of what IS stored; the
     next sweep recomputes them, pyvb_pca_get_state and every other reader has them put into X first: pca_materialize_x).  A run
