@@ -9,7 +9,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(cc)):
     acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-    if not any(s in k for s in ("k_sweep", "k_stats", "k_prep", "k_cols", "k_gy", "k_pca_pass", "k_pca_pairs", "k_pca_rows")):
+    if not any(s in k for s in ("k_sweep", "k_stats", "k_prep", "k_cols", "k_gy", "k_pca_pass", "k_pca_pairs", "k_pca_rows", "_big")):
         continue
     big = [x for x in d if x > 0.5 * max(d)]
     md = sum(big) / len(big)

@@ -171,6 +171,13 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
     double* xs = lds + 2 * BDS * 64;                // [128] boundary state exchange
     double* vs = xs + BDP;                          // [128] boundary scratch
     const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
+#ifdef BIG_CLOCK        // (profiles/build_variant.sh k_big clock "-DBIG_CLOCK": the chip's clock while this kernel runs, from its two time counters)
+    const unsigned long long ck_c0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+    struct ClockReport { unsigned long long c0, r0; int on, mode; __device__ ~ClockReport() {
+        if (on) { const unsigned long long dc = __builtin_amdgcn_s_memtime() - c0, dr = __builtin_amdgcn_s_memrealtime() - r0;
+                  printf("k_sweep_big<%d>: %.1f us, %.3f GHz\n", mode, dr / 100.0, dc / (dr * 10.0)); } } }
+        ck_report{ck_c0, ck_r0, blockIdx.x == 300 && blockIdx.y == 0 && threadIdx.x == 0, MODE};
+#endif
     const int part = blockIdx.y;            // the time axis is dealt out to a.W workgroups per replicate when there are few replicates (k_sweep.hip: SPLIT)
     const int T = a.T, D = a.D, K = a.K;
     const bool fwd = (a.dir == 0);

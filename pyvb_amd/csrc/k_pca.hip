@@ -1272,31 +1272,44 @@ __global__ void __launch_bounds__(512) k_pca_materialize(PcaArgs a) {
 
 // the variances of the missing entries of the chunk's rows (1 / <beta> for the rows being updated) and their sums:
 // sum_n #missing_n var_n, and sum over partially observed rows of #missing_n log var_n.  One workgroup per chunk.
-__global__ void __launch_bounds__(256) k_pca_rowvar(PcaArgs a) {
-    __shared__ double red[4];
+// (256 or 1024 threads: with a chunk per CU a thread of 256 walked 15 rows one dependent trip to memory after the other, 24 us)
+__global__ void __launch_bounds__(1024) k_pca_rowvar(PcaArgs a) {
+    __shared__ double red[3][16];
+    const int nt = blockDim.x;
     if (a.save_wx && blockIdx.x == 0) {         // the parameters the sweep before this launch imputed with (k_pca_pass12<.., LAZY>)
-        for (int i = threadIdx.x; i < a.d * a.q; i += 256) a.W_x[i] = a.W_mean[i];
-        for (int i = threadIdx.x; i < a.d; i += 256) a.Mu_x[i] = a.Mu_mean[i];
+        for (int i = threadIdx.x; i < a.d * a.q; i += nt) a.W_x[i] = a.W_mean[i];
+        for (int i = threadIdx.x; i < a.d; i += nt) a.Mu_x[i] = a.Mu_mean[i];
     }
     const long r0 = (long)blockIdx.x * a.chunk_rows;
     const long r1 = (r0 + a.chunk_rows < a.N) ? r0 + a.chunk_rows : a.N;
     const double var_new = a.scal[PS_BETA_B] / a.scal[PS_BETA_A];
+    const double log_new = log(var_new), qld_new = 0.5 / (0.5 * a.d * log(1.0 / var_new));
     double sxv = 0.0, slv = 0.0, sql = 0.0;
-    for (long row = r0 + threadIdx.x; row < r1; row += 256) {
+    for (long row = r0 + threadIdx.x; row < r1; row += nt) {
         const int nm = a.nmiss[row];
-        double v = a.xvar[row];
         int cnt = nm;                       // entries of the row that carry this variance
-        if (nm > 0 && row >= a.lo_upd && row < a.hi_upd) {
-            v = var_new; a.xvar[row] = v;
+        const bool upd = nm > 0 && row >= a.lo_upd && row < a.hi_upd;
+        double v = var_new;
+        if (upd) {
+            a.xvar[row] = v;
             if (a.pinned) a.pinned[row] = 1;    // pass 2 (same stream, before this kernel) has conditioned the row just now
-        } else if (a.pinned && !a.pinned[row]) cnt = a.d;       // not updated yet: the initial covariance v I on all entries
+        } else {
+            v = a.xvar[row];
+            if (a.pinned && !a.pinned[row]) cnt = a.d;          // not updated yet: the initial covariance v I on all entries
+        }
         sxv += cnt * v;
-        if (nm > 0 && nm < a.d) slv += nm * log(v);
-        if (nm == a.d) sql += 0.5 / (0.5 * a.d * log(1.0 / v));     // a latent row: qprec = I / v (gaussian.py:120, quirk Q1)
+        if (nm > 0 && nm < a.d) slv += nm * (upd ? log_new : log(v));
+        if (nm == a.d) sql += upd ? qld_new : 0.5 / (0.5 * a.d * log(1.0 / v));     // a latent row: qprec = I / v (gaussian.py:120, quirk Q1)
     }
     double* P = a.part + (size_t)blockIdx.x * (a.SL.total + a.DT);
-    sxv = bsum(sxv, red); slv = bsum(slv, red); sql = bsum(sql, red);
-    if (threadIdx.x == 0) { P[a.SL.osxv] = sxv; P[a.SL.oslv] = slv; P[a.SL.osql] = sql; }
+    sxv = wsum(sxv); slv = wsum(slv); sql = wsum(sql);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sxv; red[1][threadIdx.x >> 6] = slv; red[2][threadIdx.x >> 6] = sql; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+        for (int w = 0; w < nt / 64; ++w) t += red[threadIdx.x][w];
+        P[threadIdx.x == 0 ? a.SL.osxv : (threadIdx.x == 1 ? a.SL.oslv : a.SL.osql)] = t;
+    }
 }
 
 // sum the per-chunk partials in two deterministic stages (no atomics: results must not depend on timing)
@@ -1625,7 +1638,14 @@ template <int... MODES>
 __global__ void __launch_bounds__(256) k_pca_small(PcaArgs a) {
     __shared__ double sm[64 * 64 + 64 * 64 + 64 + 1088], red[4], wst[256 * 32];     // wst: <W> [d][q] staged by wtw_lds
     int first = 1;
+#ifdef SMALL_STAMP      // (bash profiles/build_pca_variant.sh sstamp "-DSMALL_STAMP": where the single-workgroup steps spend their microseconds)
+    unsigned long long st = __builtin_amdgcn_s_memrealtime();
+    ((first ? (void)(first = 0) : (__threadfence(), __syncthreads()), pca_small_body<MODES>(a, sm, red, wst), __syncthreads(),
+      (threadIdx.x == 0 ? (void)printf("small mode %d: %.2f us\n", MODES, (__builtin_amdgcn_s_memrealtime() - st) / 100.0) : (void)0),
+      st = __builtin_amdgcn_s_memrealtime()), ...);
+#else
     ((first ? (void)(first = 0) : (__threadfence(), __syncthreads()), pca_small_body<MODES>(a, sm, red, wst)), ...);
+#endif
 }
 
 // q_ln_det (gaussian.py:120, quirk Q1) of every X_n that has no observed entry -- a latent node with qprec = I / var_n --
@@ -1691,7 +1711,7 @@ int pca_launch_pass2(pyvb_pca* h, long lo_upd, long hi_upd) {
     const bool pin = h->Xdata != nullptr;
     if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass2<1, true>), grid, block, 0, h->stream, a); else hipLaunchKernelGGL((k_pca_pass2<1, false>), grid, block, 0, h->stream, a); }
     else { if (pin) hipLaunchKernelGGL((k_pca_pass2<2, true>), grid, block, 0, h->stream, a); else hipLaunchKernelGGL((k_pca_pass2<2, false>), grid, block, 0, h->stream, a); }
-    hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(a.chunk_rows >= 2048 ? 1024 : 256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     h->part_chunks = h->nchunk;
     return PYVB_OK;
@@ -1744,7 +1764,7 @@ int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
         }
         else if (h->DT == 16) hipLaunchKernelGGL(k_pca_rows<true>, dim3(a.nchunk), dim3(64 * PR_NW), lds, h->stream, a);
         else hipLaunchKernelGGL(k_pca_rows<false>, dim3(a.nchunk), dim3(64 * PR_NW), lds, h->stream, a);
-        hipLaunchKernelGGL(k_pca_rowvar, dim3(a.nchunk), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_pca_rowvar, dim3(a.nchunk), dim3(a.chunk_rows >= 2048 ? 1024 : 256), 0, h->stream, a);
         HIPCHK(hipGetLastError());
         h->part_chunks = a.nchunk;
         h->xlazy = true; h->vlo = lo_upd; h->vhi = hi_upd;
@@ -1758,7 +1778,7 @@ int pca_launch_pass12(pyvb_pca* h, long lo_upd, long hi_upd) {
     if (lazy) hipLaunchKernelGGL((k_pca_pass12<1, false, true>), grid, block, lds, h->stream, a);
     else if (h->QT == 1) { if (pin) hipLaunchKernelGGL((k_pca_pass12<1, true>), grid, block, lds, h->stream, a); else hipLaunchKernelGGL((k_pca_pass12<1, false>), grid, block, lds, h->stream, a); }
     else { if (pin) hipLaunchKernelGGL((k_pca_pass12<2, true>), grid, block, lds, h->stream, a); else hipLaunchKernelGGL((k_pca_pass12<2, false>), grid, block, lds, h->stream, a); }
-    hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_pca_rowvar, dim3(h->nchunk), dim3(a.chunk_rows >= 2048 ? 1024 : 256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     if (lazy) { h->xlazy = true; h->vlo = lo_upd; h->vhi = hi_upd; }
     return PYVB_OK;
