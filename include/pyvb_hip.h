@@ -265,7 +265,9 @@ int pyvb_graph_tape_create(pyvb_graph* g, const int* ops, int nops, int* tape_id
  * blocks[nb][2] = (first record, number of records); the blocks of one launch run side by side, one workgroup each (the
  * updates of nodes none of which reads what another writes: [z.update() for z in Zs] of a PCA-like graph).  The caller
  * guarantees that independence; blocks and launches must tile the tape in order (checked).  Without a program one workgroup
- * interprets the whole tape. */
+ * interprets the whole tape.  What a block "writes" includes the GAPS of a strided destination: the extent of a COPY2D or FILL
+ * with ld > cols is the whole span (rows - 1) * ld + cols, which a block may hold in LDS from its start and write back at its
+ * end -- that span, gaps included, must be disjoint from everything any other block of the same launch writes. */
 int pyvb_graph_tape_set_program(pyvb_graph* g, int tape_id, const int* blocks, int nblocks, const int* launches, int nlaunches);
 int pyvb_graph_tape_run(pyvb_graph* g, int tape_id);
 int pyvb_graph_tape_destroy(pyvb_graph* g, int tape_id);

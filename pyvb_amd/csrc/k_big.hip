@@ -881,7 +881,7 @@ int launch_prep_big(pyvb_lds* h) {
 // (The first version kept the matrix as [col][row] in LDS, one thread per row: two wavefronts per CU, five barriers and four
 // dependent global loads per column -- 7.4 ms at N = 1024, D = K = 128.)
 #define CB_H 64         // columns per lane
-__global__ void __launch_bounds__(256) k_cols_big(ParamArgs a) {
+__global__ void __launch_bounds__(256) k_cols_big_rows(ParamArgs a) {
     extern __shared__ double lds[];
     double* Gl = lds;                       // [128][128] zero padded
     double* plp = Gl + BDP * BDP;           // [4 wavefronts][128 columns] sums of log precision
@@ -1008,16 +1008,372 @@ __global__ void __launch_bounds__(256) k_cols_big(ParamArgs a) {
     }
 }
 
+// ---- Round 4: the same pass on the matrix cores, blocked.
+// What paced k_cols_big_rows (3.9 ms at N = 1024, D = K = 128, no MFMA at all) is that every column costs every wavefront a pass over
+// a row of G in LDS (the broadcast reads of four wavefronts: ~1000 LDS cycles per column) and a 64-deep select chain.  Here a wavefront
+// owns 32 ROWS of the matrix outright (row tiles 2w, 2w+1) and keeps, in MFMA accumulator layout (lane (q, c), register e of tile
+// (m, nn) = element (16 m + 4 e + q, 16 nn + c)),
+//     Mx  the matrix itself, and
+//     S   its product with G-without-diagonal:  S[r][i] = sum_{j != i} M[r][j] G[j][i]  -- the "dot" of column i, for all i at once.
+// S starts as M_old G_off (a 128^3 product, 512 MFMAs per wavefront) and is kept current as columns change: a block of 16 columns
+// is swept column by column inside the 16 lanes that hold one row's 16 entries (the new value of column j is formed in lane c = j,
+// its change delta_j goes to the row's other lanes by one cross-lane read, S[r][16 I + c] += delta_j G[j][c] -- 16 doubles of G per
+// lane), and when the block is done its 32 x 16 panel of changes updates S for the other column tiles by MFMA (panel through 4 KB
+// of the wavefront's own LDS into A-operand order).  No workgroup barrier in the pass; precisions, variances, logarithms are
+// elementwise per block.  The residual of the noise node, sum_i M (S + M g_ii) + var g_ii, is elementwise on S = M_new G_off, formed afresh.
+// Same formulas, other summation order than k_cols_big_rows (kept: PYVB_COLS_BIG=rows).
+#define CBP 17      // row stride of a wavefront's panel
+__global__ void __launch_bounds__(256) k_cols_big(ParamArgs a) {
+    extern __shared__ double lds[];
+#ifdef COLS_STAMP       // (profiles/build_variant.sh k_big cstamp "-DCOLS_STAMP": where a workgroup's time goes, shader-clock ticks)
+    unsigned long long cs_t = __builtin_amdgcn_s_memtime(), cs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cs_acc[i] += t_ - cs_t; cs_t = t_; } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+    double* Gl = lds;                       // [128][128] zero padded, zero diagonal
+    double* plp = Gl + BDP * BDP;           // [4 wavefronts][128 columns] sums of log precision
+    double* pkn = plp + 4 * BDP;            // [4][128] numbers of known entries
+    double* gd = pkn + 4 * BDP;             // [128] the diagonal of G
+    double* red = gd + BDP;                 // [8]
+    const int WHICH = a.which0 + blockIdx.y, n = blockIdx.x, tid = threadIdx.x, D = a.D, K = a.K;
+    const int rows = WHICH == 0 ? D : K;
+    const int lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    double* panel = red + 8 + wave * (32 * CBP);
+    double* M = (WHICH == 0 ? a.A_mean : a.C_mean) + (size_t)n * rows * D;
+    double* V = (WHICH == 0 ? a.A_var : a.C_var) + (size_t)n * D * rows;
+    double* qld = (WHICH == 0 ? a.qld_A : a.qld_C) + (size_t)n * D;
+    const double* pm = WHICH == 0 ? a.pri.A_pm : a.pri.C_pm;    // [row][col]
+    const double* pp = WHICH == 0 ? a.pri.A_pp : a.pri.C_pp;    // [col][row]
+    const double* obs = WHICH == 0 ? a.pri.A_obs : a.pri.C_obs; // [row][col], NaN = not known
+    const double* mo = a.mom + (size_t)n * mom_total(D, K);
+    const double* G = mo + (WHICH == 0 ? MOM_GA(D, K) : MOM_GC(D, K));
+    const double* H = mo + (WHICH == 0 ? MOM_HA(D, K) : MOM_HC(D, K));
+#pragma unroll 8
+    for (int u = 0; u < BDP * BDP / 256; ++u) {         // (unconditional loads, eight and more in flight)
+        const int idx = tid + 256 * u, i = idx >> 7, j = idx & 127;
+        const double v = G[(size_t)(i < D ? i : D - 1) * D + (j < D ? j : D - 1)];
+        Gl[(idx & ~127) | (j ^ ((i & 1) << 4))] = (i < D && j < D && i != j) ? v : 0.0;     // odd rows: neighbouring 16-column tiles swapped (see mma16)
+    }
+    if (tid < BDP) gd[tid] = tid < D ? G[(size_t)tid * D + tid] : 0.0;
+    for (int idx = tid; idx < 8 * BDP; idx += 256) plp[idx] = 0.0;          // plp and pkn: a wavefront without rows leaves zeros
+    __syncthreads();
+    CSTAMP(0);
+    const bool work = 32 * wave < rows;     // this wavefront has rows at all (K may be small)
+    const int nbl = (D + 15) >> 4;          // column blocks in use
+    // this lane's eight rows: (mm, e) -> 32 wave + 16 mm + 4 e + q
+    bool live[2][4]; int rowc[2][4]; double lam[2][4];
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 32 * wave + 16 * mm + 4 * e + q;
+            live[mm][e] = row < rows; rowc[mm][e] = row < rows ? row : 0;
+            lam[mm][e] = live[mm][e] ? (WHICH == 0 ? a.Q_a[(size_t)n * D + rowc[mm][e]] / a.Q_b[(size_t)n * D + rowc[mm][e]]
+                                                   : a.R_a[(size_t)n * K + rowc[mm][e]] / a.R_b[(size_t)n * K + rowc[mm][e]]) : 0.0;
+        }
+    d4 S[2][BDT];
+    // this lane's eight entries of column block J (accumulator layout) from the matrix in memory; zero beyond the matrix
+    auto load_m = [&](d4 (&p)[2], int J) {
+        const int col = 16 * J + c, colc = col < D ? col : D - 1;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {           // (unconditional loads from clamped places: a branch per entry otherwise)
+                const double v = M[(size_t)rowc[mm][e] * D + colc];
+                p[mm][e] = (live[mm][e] && col < D) ? v : 0.0;
+            }
+    };
+    // S[.][nn] += P G_off[16 J .., 16 nn ..] for a 32 x 16 panel P given as A operands (av[mm][s4] = P[16 mm + c][4 s4 + q]); nn == skip
+    // is left out, and so is nn < lo.  The B operands of a column tile are requested while the tile before it is multiplied.
+    auto mma16 = [&](const double (&av)[2][4], int J, int skip, int lo) {
+        // (G in LDS has no room for a padded row stride, and rows 1 KB apart share their banks: the four rows a B operand read
+        // touches would meet in them.  Odd rows keep each pair of 16-column tiles swapped, so that the rows q = 0, 2 and q = 1, 3
+        // of a read lie 32 banks apart.)
+        const double* gj = Gl + (size_t)(16 * J + q) * BDP + c;
+        const int sw = (q & 1) << 4;
+        double b[2][4];
+        auto fetch_b = [&](double (&bv)[4], int nn) {
+            const int nc = nn < BDT ? nn : BDT - 1;
+            const double* gp = gj + 16 * nc + ((nc & 1) ? -sw : sw);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) bv[s4] = gp[(size_t)(4 * s4) * BDP];
+        };
+        fetch_b(b[0], 0);
+#pragma unroll
+        for (int nn = 0; nn < BDT; ++nn) {
+            fetch_b(b[(nn + 1) & 1], nn + 1);
+            if (nn == skip || nn < lo || nn >= nbl) continue;       // wavefront-uniform
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)          // one chain after the other (accumulators taken in turn run at half the rate: mm128)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) S[mm][nn] = MFMA(av[mm][s4], b[nn & 1][s4], S[mm][nn]);
+        }
+    };
+    // the same for a panel given in accumulator layout (p[mm][e]): through this wavefront's 4 KB of LDS into A-operand order
+    auto rank16 = [&](const d4 (&p)[2], int J, int skip, int lo) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) panel[(16 * mm + 4 * e + q) * CBP + c] = p[mm][e];
+        asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+        double av[2][4];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) av[mm][s4] = panel[(16 * mm + c) * CBP + 4 * s4 + q];
+        mma16(av, J, skip, lo);
+        asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    };
+    const bool fuse1 = (a.fuse & 1) != 0;
+    // S = M G_off for the matrix as it stands in memory, as mm128 forms a product: a row tile's 32 A operands straight from memory
+    // (lane (q, c): row 16 mm + c of this wavefront's 32, columns 4 k + q), a column tile is ONE chain of 32 dependent MFMAs whose
+    // B operands were requested while the chain before it ran
+    auto full_product = [&]() {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+            const int row = 32 * wave + 16 * mm + c;
+            const double* mp = M + (size_t)(row < rows ? row : 0) * D;
+            double av[BDS], bA[BDS], bB[BDS];
+#pragma unroll
+            for (int k = 0; k < BDS; ++k) {
+                const int col = 4 * k + q;
+                const double v = mp[col < D ? col : D - 1];
+                av[k] = (row < rows && col < D) ? v : 0.0;
+            }
+            const double* g0 = Gl + (size_t)q * BDP + c;
+            const int sw = (q & 1) << 4;
+            auto fetch = [&](double (&bv)[BDS], int nn) {
+                const int nc = nn < BDT ? nn : BDT - 1;
+                const double* gp = g0 + 16 * nc + ((nc & 1) ? -sw : sw);
+#pragma unroll
+                for (int k = 0; k < BDS; ++k) bv[k] = gp[(size_t)(4 * k) * BDP];
+            };
+            auto chain = [&](const double (&bv)[BDS], d4& acc) {
+                acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < BDS; ++k) acc = MFMA(av[k], bv[k], acc);
+            };
+            fetch(bA, 0);
+#pragma unroll
+            for (int nn = 0; nn < BDT; nn += 2) {
+                fetch(bB, nn + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                chain(bA, S[mm][nn]);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(bA, nn + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                chain(bB, S[mm][nn + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    if (work) {
+        full_product();
+        CSTAMP(1);
+        // ---- the pass, block by block
+        const int I0 = a.c0 >> 4, I1 = (a.c1 + 15) >> 4;
+        // what a block needs from memory (its entries of the matrix, of H, of the column priors, the known values) is requested
+        // before the panel update of the block before it, which covers the trip
+        double r_p0[2][4], r_pm[2][4], r_ob[2][4], r_h[2][4]; d4 r_m[2];
+        auto load_raw = [&](int J) {
+            const int cj = 16 * J + c, cjc = cj < D ? cj : D - 1;
+            load_m(r_m, J);
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = rowc[mm][e];
+                    r_h[mm][e] = H[(size_t)r * D + cjc]; r_p0[mm][e] = pp[(size_t)cjc * rows + r];
+                    r_pm[mm][e] = pm[(size_t)r * D + cjc]; r_ob[mm][e] = obs[(size_t)r * D + cjc];
+                }
+        };
+        load_raw(I0 < nbl ? I0 : 0);
+#pragma unroll 1
+        for (int I = I0; I < I1 && I < nbl; ++I) {
+            d4 Sc[2], Mc[2], Mo[2];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) Mo[mm] = r_m[mm];
+#pragma unroll
+            for (int nn = 0; nn < BDT; ++nn)
+                if (nn == I) {
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) Sc[mm] = S[mm][nn];
+                }
+            const int col = 16 * I + c, colc = col < D ? col : D - 1;
+            const bool incol = col < D && col >= a.c0 && col < a.c1;
+            const double gii = gd[col];
+            // per entry: val = av + lv (hv - S)  with av = p0 pm / prec, lv = lam / prec  (qmu, gaussian.py:122-123: (p0 pm + lam (H - dot)) qcov);
+            // a known entry (Gaussian.observe on a column, LDS_knowns_in_A.py:73-74; gaussian.py:125-134, :109-110) has av = its value,
+            // lv = 0, a row beyond the matrix av = lv = 0
+            double hv[2][4], av[2][4], lv[2][4];
+            double nks = 0.0, mprod = 1.0;
+            int esum = 0;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = rowc[mm][e];
+                    const double p0 = r_p0[mm][e], pmv = r_pm[mm][e], ob = r_ob[mm][e];
+                    hv[mm][e] = r_h[mm][e];
+                    const double prec = p0 + lam[mm][e] * gii;                          // qprec  gaussian.py:117
+                    const double var = 1.0 / prec;                                      // qcov   gaussian.py:118-119
+                    const bool known = ob == ob;
+                    av[mm][e] = live[mm][e] ? (known ? ob : p0 * pmv * var) : 0.0;
+                    lv[mm][e] = (live[mm][e] && !known) ? lam[mm][e] * var : 0.0;
+                    const bool mine = live[mm][e] && incol;
+                    // sum of log prec = log of the product of the mantissas + ln 2 x the sum of the exponents: one logarithm per lane and block
+                    mprod *= mine ? __builtin_amdgcn_frexp_mant(prec) : 1.0;
+                    esum += mine ? __builtin_amdgcn_frexp_exp(prec) : 0;
+                    nks += (mine && known) ? 1.0 : 0.0;
+                    if (mine) V[(size_t)colc * rows + r] = known ? 0.0 : var;
+                    Mc[mm][e] = Mo[mm][e];
+                }
+            double lps = log(mprod) + 0.6931471805599453 * (double)esum;       // (a precision that is not positive: NaN, as the sum of logarithms)
+            lps += __shfl_xor(lps, 16, 64); lps += __shfl_xor(lps, 32, 64);
+            nks += __shfl_xor(nks, 16, 64); nks += __shfl_xor(nks, 32, 64);
+            if (q == 0 && incol) { plp[wave * BDP + col] = lps; pkn[wave * BDP + col] = nks; }
+            CSTAMP(2);
+            const double* gcol = Gl + (size_t)(16 * I) * BDP;       // row 16 I + j: column (col) in even rows, (col ^ 16) in odd ones
+            const int j0 = (a.c0 > 16 * I) ? a.c0 - 16 * I : 0;
+            int j1 = a.c1 - 16 * I; if (j1 > 16) j1 = 16; if (j1 > D - 16 * I) j1 = D - 16 * I;
+#pragma unroll 1
+            for (int j = j0; j < j1; ++j) {
+                const bool is = c == j;
+                const double gjc = gcol[(size_t)j * BDP + (col ^ ((j & 1) << 4))];      // G[16 I + j][16 I + c], zero on the diagonal
+                const int src = ((lane & 48) | j) << 2;
+                // (in three rounds -- all changes, all cross-lane reads, all updates: entry by entry, each read waited for its own
+                // trip through the LDS crossbar, eight trips a column)
+                double dl[2][4], db[2][4];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double val = __builtin_fma(lv[mm][e], hv[mm][e] - Sc[mm][e], av[mm][e]);
+                        dl[mm][e] = val - Mc[mm][e];                // (only lane c = j's is read below)
+                        Mc[mm][e] = is ? val : Mc[mm][e];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        db[mm][e] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(dl[mm][e])), __builtin_amdgcn_ds_bpermute(src, __double2loint(dl[mm][e])));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Sc[mm][e] = __builtin_fma(db[mm][e], gjc, Sc[mm][e]);
+            }
+            CSTAMP(3);
+            d4 dp[2];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) dp[mm] = Mc[mm] - Mo[mm];
+#pragma unroll
+            for (int nn = 0; nn < BDT; ++nn)
+                if (nn == I) {
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) S[mm][nn] = Sc[mm];
+                }
+            // the block's new values
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (live[mm][e] && incol) M[(size_t)rowc[mm][e] * D + col] = Mc[mm][e];
+            __builtin_amdgcn_sched_barrier(0);
+            load_raw(I + 1 < nbl ? I + 1 : I);
+            __builtin_amdgcn_sched_barrier(0);
+            rank16(dp, I, I, I + 1);        // the blocks still to come
+            CSTAMP(4);
+        }
+    }
+    __syncthreads();
+    if (tid >= a.c0 && tid < a.c1 && tid < BDP) {
+        const double lp = ((plp[tid] + plp[BDP + tid]) + plp[2 * BDP + tid]) + plp[3 * BDP + tid];
+        const double nk = ((pkn[tid] + pkn[BDP + tid]) + pkn[2 * BDP + tid]) + pkn[3 * BDP + tid];
+        if ((int)nk < rows) qld[tid] = 0.5 / (0.5 * lp);                                // quirk Q1, gaussian.py:120: of the whole precision
+    }
+    if (fuse1) {
+        // res[k] = 1/2 own[k] + 1/2 (sum_ij M[k,i] G[i,j] M[k,j] + sum_i var_i[k] G[i,i]) - sum_i H[k,i] M[k,i]   (node.py:260-271)
+        // S is formed afresh from the new matrix (behind the barrier above: this wavefront's own stores): the same sums whether the
+        // columns were updated in this launch or in one before it
+        CSTAMP(5);
+        if (work && a.c0 < a.c1) full_product();
+        CSTAMP(6);
+        double rr[2][4];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double es = 0.0, hm = 0.0;
+                if (work) {
+#pragma unroll
+                    for (int nn = 0; nn < BDT; ++nn) {
+                        const int col = 16 * nn + c, colc = col < D ? col : D - 1;
+                        const double g = gd[col];                               // zero beyond the matrix
+                        const double mv = M[(size_t)rowc[mm][e] * D + colc];    // (this lane stored it, if it changed)
+                        const double m = col < D ? mv : 0.0;
+                        const double vi = V[(size_t)colc * rows + rowc[mm][e]], hi = H[(size_t)rowc[mm][e] * D + colc];
+                        es += m * (S[mm][nn][e] + m * g) + vi * g;
+                        hm += hi * m;
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { es += __shfl_xor(es, o, 64); hm += __shfl_xor(hm, o, 64); }
+                const int r = rowc[mm][e];
+                const double own = WHICH == 0 ? mo[MOM_DP(D, K) + r] : a.Syy[(size_t)n * K + r];
+                rr[mm][e] = 0.5 * own + 0.5 * es - hm;
+                if (work && live[mm][e] && c == 0) (WHICH == 0 ? a.resQ : a.resR)[(size_t)n * rows + r] = rr[mm][e];
+            }
+        if (a.fuse & 2) {
+            const double* b0 = WHICH == 0 ? a.pri.Q_b0 : a.pri.R_b0;
+            double* qb = (WHICH == 0 ? a.Q_b : a.R_b) + (size_t)n * rows;
+            if (a.noise == PYVB_NOISE_GAMMA) {
+                double t = 0.0;
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t += (work && live[mm][e] && c == 0) ? rr[mm][e] : 0.0;
+                t = wave_sum(t);
+                __syncthreads();
+                if (lane == 0) red[wave] = t;
+                __syncthreads();
+                t = ((red[0] + red[1]) + red[2]) + red[3];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (work && live[mm][e] && c == 0) qb[rowc[mm][e]] = b0[0] + t;
+            } else {
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (work && live[mm][e] && c == 0) qb[rowc[mm][e]] = b0[rowc[mm][e]] + rr[mm][e];
+            }
+        }
+    }
+#ifdef COLS_STAMP
+    CSTAMP(7);
+    if (blockIdx.x == 100 && tid == 0)
+        printf("k_cols_big which %d: G to LDS %llu | M G_off %llu | block setup (loads, 1/x, log) %llu | 16 columns %llu | panel update %llu | to the barrier %llu | M G_off again %llu | residual %llu\n",
+               WHICH, cs_acc[0], cs_acc[1], cs_acc[2], cs_acc[3], cs_acc[4], cs_acc[5], cs_acc[6], cs_acc[7]);
+#endif
+}
+
 int launch_cols_big(pyvb_lds* h, int which, int c0, int c1, int fuse) {
     ParamArgs a = make_args(h);
     a.c0 = c0; a.c1 = c1; a.which0 = which == 1 ? 1 : 0; a.fuse = fuse;
-    const size_t lds = ((size_t)BDP * BDP + 9 * BDP + 8) * sizeof(double);
+    static const bool by_rows = [] { const char* e = getenv("PYVB_COLS_BIG"); return e && e[0] == 'r'; }();     // the kernel of round 3, for comparison
+    const size_t lds_rows = ((size_t)BDP * BDP + 9 * BDP + 8) * sizeof(double);
+    const size_t lds = ((size_t)BDP * BDP + 9 * BDP + 8 + 4 * 32 * CBP) * sizeof(double);
     if (!h->big_attr_cols) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_cols_big_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
         HIPCHK(hipFuncSetAttribute((const void*)k_cols_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         h->big_attr_cols = true;
     }
     TimedLaunch tl(h, PYVB_K_PARAMS);
-    hipLaunchKernelGGL(k_cols_big, dim3(h->N, which == 2 ? 2 : 1), dim3(256), lds, h->stream, a);
+    if (by_rows) hipLaunchKernelGGL(k_cols_big_rows, dim3(h->N, which == 2 ? 2 : 1), dim3(256), lds_rows, h->stream, a);
+    else hipLaunchKernelGGL(k_cols_big, dim3(h->N, which == 2 ? 2 : 1), dim3(256), lds, h->stream, a);
     HIPCHK(hipGetLastError());
     return PYVB_OK;
 }
