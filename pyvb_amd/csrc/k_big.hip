@@ -31,7 +31,15 @@
 #define BDP 128     // padded dimension
 #define BDT 8       // 16-row tiles
 #define BDS 32      // k-steps of 4
+#ifdef BLD_OVERRIDE
+#define BLD BLD_OVERRIDE
+#else
 #define BLD 130     // row stride of the LDS work matrix (A-operand reads conflict free)
+#endif
+#ifndef CHAIN_RUN
+#define CHAIN_RUN 32    // dependent MFMAs on one accumulator before the next accumulator takes its turn (k_gy_big, k_sweep_big);
+                        // runs of 16 or 8 measured the same as whole chains (lds_d128: 49.9 / 49.9 / 49.7 ms)
+#endif
 
 // ======================================================================================================================
 // sweep
@@ -126,11 +134,15 @@ __global__ void __launch_bounds__(256) k_gy_big(BigGyArgs a) {
     auto block = [&](const d2 (&yv)[BDS / 2], int t) {
         d4 acc[NT];
 #pragma unroll
-        for (int mm = 0; mm < NT; ++mm) {       // one dependent chain per accumulator (profiles/r01/microbench_f64.txt)
-            acc[mm] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int mm = 0; mm < NT; ++mm) acc[mm] = d4{0.0, 0.0, 0.0, 0.0};
+        // runs of CHAIN_RUN dependent MFMAs, the accumulators in turn (profiles/r01/microbench_f64.txt: at one wavefront per SIMD
+        // runs of 16 over several accumulators sustain more than one chain to its end, single MFMAs in turn far less)
 #pragma unroll
-            for (int s = 0; s < BDS; ++s) acc[mm] = MFMA(gr[mm][s], yv[s >> 1][s & 1], acc[mm]);
-        }
+        for (int s0 = 0; s0 < BDS; s0 += CHAIN_RUN)
+#pragma unroll
+            for (int mm = 0; mm < NT; ++mm)
+#pragma unroll
+                for (int s = s0; s < s0 + CHAIN_RUN; ++s) acc[mm] = MFMA(gr[mm][s], yv[s >> 1][s & 1], acc[mm]);
         double* ur = (t <= T - 2) ? Un + (size_t)t * BDP : trash;
 #pragma unroll
         for (int mm = 0; mm < NT; ++mm) *reinterpret_cast<d4*>(ur + ((NT * w + mm) * 4 + q) * 4) = acc[mm];
@@ -281,11 +293,13 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
         auto iprod = [&](int j) {
             const double* st = ring + ((j - jstart) % 3) * (BDS * 64);
 #pragma unroll
-            for (int mm = 0; mm < NTW; ++mm) {
-                accI[mm] = d4{0.0, 0.0, 0.0, 0.0};
+            for (int mm = 0; mm < NTW; ++mm) accI[mm] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int s = 0; s < BDS; ++s) accI[mm] = MFMA(ip[mm][s], st[s * 64 + lane], accI[mm]);
-            }
+            for (int s0 = 0; s0 < BDS; s0 += CHAIN_RUN)
+#pragma unroll
+                for (int mm = 0; mm < NTW; ++mm)
+#pragma unroll
+                    for (int s = s0; s < s0 + CHAIN_RUN; ++s) accI[mm] = MFMA(ip[mm][s], st[s * 64 + lane], accI[mm]);
         };
         // cv: U rows of step j; cv_fill: the set that takes the rows of step j + 2
         auto step = [&](int j, const double* xr, double* xw, const d4 (&cv)[NTW], d4 (&cv_fill)[NTW]) {
@@ -299,9 +313,11 @@ __global__ void __launch_bounds__(512 / NTW) k_sweep_big(BigSweepArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             // R mu_{t-dir} (new): the segments' state
 #pragma unroll
-            for (int mm = 0; mm < NTW; ++mm)
+            for (int s0 = 0; s0 < BDS; s0 += CHAIN_RUN)
 #pragma unroll
-                for (int s = 0; s < BDS; ++s) acc[mm] = MFMA(rn[mm][s], xr[s * 64 + lane], acc[mm]);
+                for (int mm = 0; mm < NTW; ++mm)
+#pragma unroll
+                    for (int s = s0; s < s0 + CHAIN_RUN; ++s) acc[mm] = MFMA(rn[mm][s], xr[s * 64 + lane], acc[mm]);
             if constexpr (MODE != 2) {
                 if (fwd) {                      // c_t for the backward sweep, this wavefront's rows
                     double* ur = (act && j >= 0) ? Uw + (size_t)(tbase + sgn * j) * BDP : trash + 256;
@@ -695,8 +711,17 @@ __device__ __forceinline__ int warmup128(double* W, int tid, double* red) {
     return best;
 }
 
+// a pass over the 128 x 128 elements by the workgroup's 256 threads, eight loads in flight per thread (rolled, with one: ~60 000
+// cycles a pass, and the kernel makes eight of them)
+#define STAGE_LOOP _Pragma("unroll 8") for (int u_ = 0, idx = threadIdx.x; u_ < BDP * BDP / 256; ++u_, idx += 256)
 __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     extern __shared__ double lds[];
+#ifdef PREP_STAMP       // (profiles/build_variant.sh k_big pstamp "-DPREP_STAMP": where a workgroup's time goes, shader-clock ticks)
+    unsigned long long ps_t = __builtin_amdgcn_s_memtime(), ps_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ps_acc[i] += t_ - ps_t; ps_t = t_; } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
     double* Pm = lds;                       // [128][BLD]
     double* qbar = Pm + BDP * BLD;          // [128]
     double* rbar = qbar + BDP;
@@ -742,7 +767,7 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     // The means are staged, zero padded, in the LDS work matrix first: both operands of a product are then LDS reads without
     // bounds logic (fetching them from the arrays inside the product: 424k cycles per product, 3x this).
     double* S2 = S1 + BDP * BDP;
-    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = C_at(k, j); }
+    STAGE_LOOP { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = C_at(k, j); }
     __syncthreads();
     if (dense)      // <C>^T (E[R]<C>): the second operand straight from the array (the rare, untuned case)
         mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i]; }, [&](int k, int j) { return RC_at(k, j); },
@@ -751,7 +776,7 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i] * rbar[k]; }, [&](int k, int j) { return Pm[k * BLD + j]; },
           [&](int i, int j, double v) { S1[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? rowp[i] : 0.0) : 0.0; });
     __syncthreads();
-    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = A_at(k, j); }
+    STAGE_LOOP { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = A_at(k, j); }
     __syncthreads();
     if (dense)
         mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i]; }, [&](int k, int j) { return QA_at(k, j); },
@@ -760,9 +785,10 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i] * qbar[k]; }, [&](int k, int j) { return Pm[k * BLD + j]; },
           [&](int i, int j, double v) { S2[(size_t)i * BDP + j] = (i < D && j < D) ? S1[(size_t)i * BDP + j] + v + (i == j ? colp[i] : 0.0) : 0.0; });
     __syncthreads();
-    for (int idx = tid; idx < BDP * BDP; idx += 256) Pm[(idx >> 7) * BLD + (idx & 127)] = S2[idx];
+    STAGE_LOOP Pm[(idx >> 7) * BLD + (idx & 127)] = S2[idx];
     __syncthreads();
 
+    PSTAMP(0);
     // the three posterior precisions (gaussian.py:117), inverted one after the other (qcov, :118-119; q_ln_det, :120)
     const int ta = tid >> 4, tb = tid & 15;
     for (int cc = 0; cc < 3; ++cc) {
@@ -774,16 +800,21 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
             for (int cb = 0; cb < 8; ++cb) {
                 const int i = 8 * ta + ra, j = 8 * tb + cb;
                 const bool in = i < D && j < D;
-                const double qd = dense ? (in ? Qd[(size_t)i * D + j] : 0.0) : ((in && i == j) ? qbar[i] : 0.0);
+                const size_t at = (size_t)(i < D ? i : D - 1) * D + (j < D ? j : D - 1);     // (loads from clamped places, unconditional: no branch per element)
+                double qd = 0.0;
+                if (dense) { const double t = Qd[at]; qd = in ? t : 0.0; }
+                else qd = (in && i == j) ? qbar[i] : 0.0;
                 const double pad = (!in && i == j) ? 1.0 : 0.0;
                 double x;
-                if (c == 0) x = (in ? a.x0_prec[(size_t)i * D + j] : 0.0) + Pm[i * BLD + j];
+                if (c == 0) { const double t = a.x0_prec[at]; x = (in ? t : 0.0) + Pm[i * BLD + j]; }
                 else if (c == 1) x = qd + Pm[i * BLD + j];
                 else x = qd + S1[(size_t)i * BDP + j];
                 v[ra][cb] = x + pad;
             }
         __syncthreads();
+        PSTAMP(1);
         gj_wg128(v, D, tid, gjrc, pivs);
+        PSTAMP(2);
         if (tid < 64) {
             double lp = 0.0;
             for (int k = tid; k < D; k += 64) {
@@ -807,6 +838,7 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
             }
         __syncthreads();
     }
+    PSTAMP(1);
     if (tid < BDP) {
         g[L.oqr + tid] = qbar[tid]; g[L.oqr + BDP + tid] = rbar[tid];
         double s = 0.0;        // L0 m0: the Constant mean parent of X_0 through its Constant precision
@@ -814,36 +846,43 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
         g[L.ow0 + tid] = s;
     }
     // gains of the interior class: F = Sigma <Q><A>, B = Sigma <A>^T<Q>, G = Sigma <C>^T<R>
-    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int k = idx >> 7, j = idx & 127; S2[idx] = dense ? QA_at(k, j) : qbar[k] * A_at(k, j); }
+    STAGE_LOOP { const int k = idx >> 7, j = idx & 127; S2[idx] = dense ? QA_at(k, j) : qbar[k] * A_at(k, j); }
     __syncthreads();
     mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return S2[(size_t)k * BDP + j]; },
           [&](int i, int j, double v) { const bool in = i < D && j < D; g[L.oFn + pos_nat(i, j, BDS)] = in ? v : 0.0; S1[(size_t)i * BDP + j] = in ? v : 0.0; });
     __syncthreads();
     // the B operands of the next two products are transposes of row-major matrices: written out once, transposed and scaled,
     // so that the products read them along rows like the others (a lane per matrix row would touch a cache line per element)
-    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int j = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + j] = dense ? QA_at(j, k) : A_at(j, k) * qbar[j]; }
+    STAGE_LOOP { const int j = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + j] = dense ? QA_at(j, k) : A_at(j, k) * qbar[j]; }
     __syncthreads();
     mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return S2[(size_t)k * BDP + j]; },
           [&](int i, int j, double v) { g[L.oBn + pos_nat(i, j, BDS)] = (i < D && j < D) ? v : 0.0; });
     __syncthreads();
-    for (int idx = tid; idx < BDP * BDP; idx += 256) { const int l = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + l] = dense ? RC_at(l, k) : C_at(l, k) * rbar[l]; }
+    STAGE_LOOP { const int l = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + l] = dense ? RC_at(l, k) : C_at(l, k) * rbar[l]; }
     __syncthreads();
     mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int l) { return S2[(size_t)k * BDP + l]; },
           [&](int i, int l, double v) { g[L.oGp + pos_perm(i, l, BDS)] = (i < D && l < K) ? v : 0.0; });
     __syncthreads();
+    PSTAMP(3);
     // warm-up lengths: powers of F, and of B^T (inf-norm of powers of B^T = 1-norm of powers of B)
-    for (int idx = tid; idx < BDP * BDP; idx += 256) Pm[(idx >> 7) * BLD + (idx & 127)] = S1[idx];
+    STAGE_LOOP Pm[(idx >> 7) * BLD + (idx & 127)] = S1[idx];
     __syncthreads();
     int Jw = warmup128(Pm, tid, rowp);
     if (tid == 0) a.warm[n * 2 + 0] = Jw;
     __syncthreads();
-    for (int idx = tid; idx < BDP * BDP; idx += 256) {
+    STAGE_LOOP {
         const int i = idx >> 7, j = idx & 127;
         Pm[i * BLD + j] = g[L.oBn + pos_nat(j, i, BDS)];       // B^T (zero padded by the store above)
     }
     __syncthreads();
     Jw = warmup128(Pm, tid, rowp);
     if (tid == 0) a.warm[n * 2 + 1] = Jw;
+#ifdef PREP_STAMP
+    PSTAMP(4);
+    if (blockIdx.x == 100 && tid == 0)
+        printf("k_prep_big: moments (2 products) %llu | tiles in and out of the three inversions %llu | the three inversions %llu | gains (3 products) %llu | warm-up bounds (10 squarings) %llu\n",
+               ps_acc[0], ps_acc[1], ps_acc[2], ps_acc[3], ps_acc[4]);
+#endif
 }
 
 int launch_prep_big(pyvb_lds* h) {
