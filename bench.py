@@ -171,10 +171,10 @@ def pca_workload(steps, warmup, with_cpu, comm=None, rank=0, world=1, device=0, 
         tpath = os.path.join(REPO, "profiles", tag, "traffic_pca_pmc.json")
         if world == 1 and N == 1000000 and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            hit = [v["hbm_bytes_per_launch"] for k, v in tj.items() if "k_pca_pass12" in k]
+            hit = [(k, v["hbm_bytes_per_launch"]) for k, v in tj.items() if "k_pca_pairs" in k or "k_pca_pass12" in k]
             if hit:
-                traffic = hit[0]
-                tsrc = "profiles/%s/traffic_pca_pmc.json: k_pca_pass12, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (committed; not measured in this run)" % tag
+                traffic = hit[0][1]
+                tsrc = "profiles/%s/traffic_pca_pmc.json: %s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (committed; not measured in this run)" % (tag, hit[0][0].split("(")[0].replace("void ", ""))
                 break
     step_s = dt / steps
     QP, DP = 16, 256
@@ -193,7 +193,13 @@ def pca_workload(steps, warmup, with_cpu, comm=None, rank=0, world=1, device=0, 
             "roofline": {"bound": "hbm", "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": alg / step_s / 1e9 / (HBM_PEAK_GBS * world), "algorithmic_bytes": alg, "algorithmic_bytes_two_sweeps": alg2,
                          "traffic": traffic, "traffic_source": tsrc,
-                         "kernel": "whole iteration (k_pca_pass12 + reductions + small kernels)"},
+                         "kernel": "whole iteration (the sweep k_pca_pairs + reductions + small kernels)",
+                         # the sweep is as much a matrix-core kernel as a streaming one: per entry of X three 16-deep products of the
+                         # algorithm (z = Gz x, the prediction W z, the statistic x z^T: 6 q flops) and a fourth that recomputes the
+                         # entries the sweep before did not store; at fp64 the machine balance is 9.8 flop/byte, this is 9.6 / 12.8
+                         "mfma": {"algorithmic_flops": 6.0 * q * N * d, "executed_flops": 8.0 * q * N * d, "peak": FP64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                                  "achieved": 6.0 * q * N * d / step_s / 1e12, "frac": 6.0 * q * N * d / step_s / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+                                  "executed_frac": 8.0 * q * N * d / step_s / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world)}},
             "cpu_baseline": cpu}
 
 

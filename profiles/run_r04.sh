@@ -16,6 +16,14 @@ if [ "$PART" = A ]; then
     rocprofv3 --kernel-trace --pmc $C -d $OUT/tr/$C -o t --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/tr_$C.log 2>&1
   done
   python3 $ROOT/profiles/traffic_summary.py $OUT/tr k_sweep k_stats k_prep k_cols k_gy_big k_pca_pass12 k_pca_pairs k_pca_small k_pca_reduce k_pca_rowvar > $OUT/traffic_pmc.json
+  python3 - $OUT <<'PY'
+import json, sys
+out = sys.argv[1]
+t = json.load(open(out + "/traffic_pmc.json"))
+json.dump({k: v for k, v in t.items() if "_big" not in k and "k_pca" not in k}, open(out + "/traffic_headline.json", "w"), indent=1)
+json.dump({k: v for k, v in t.items() if "k_pca" in k and "k_pca_pass12" not in k}, open(out + "/traffic_pca_pmc.json", "w"), indent=1)    # (k_pca_pass12: the small parity copy's sweep)
+json.dump({k: v for k, v in t.items() if "_big" in k}, open(out + "/traffic_d128_pmc.json", "w"), indent=1)
+PY
   rm -rf $OUT/stats/*.db $OUT/tr/*/*.db 2>/dev/null || true
   ls -l $OUT
 fi

@@ -586,13 +586,22 @@ struct BigPrepArgs {
 // taken in turn at twice that), its 32 B operands fetched while the chain before it runs.  (Operands fetched where they were
 // used, eight accumulators in turn: 620 cycles per MFMA with operands in global memory, 170 with both in LDS -- cycle stamps.)
 // b_at should walk memory along j for neighbouring lanes (row-major B): its loads are 16 lanes x 8 contiguous bytes.
+#ifdef PREP_STAMP
+#define MMSTAMP(i) do { if (mst) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); mst[i] += t_ - mt; mt = t_; } } while (0)
+#else
+#define MMSTAMP(i) do { } while (0)
+#endif
 template <class FA, class FB, class FS>
-__device__ __forceinline__ void mm128(int wave, int lane, FA a_at, FB b_at, FS store) {
+__device__ __forceinline__ void mm128(int wave, int lane, FA a_at, FB b_at, FS store, unsigned long long* mst = nullptr) {
     const int r = lane & 15, q = lane >> 4;
+#ifdef PREP_STAMP
+    unsigned long long mt = __builtin_amdgcn_s_memtime();
+#endif
     for (int m = wave; m < BDT; m += 4) {
         double av[BDS], bA[BDS], bB[BDS];
 #pragma unroll
         for (int s = 0; s < BDS; ++s) av[s] = a_at(16 * m + r, 4 * s + q);
+        MMSTAMP(0);
         auto fetch = [&](double (&bv)[BDS], int nn) {
             const int nc = nn < BDT ? nn : BDT - 1;
 #pragma unroll
@@ -600,10 +609,21 @@ __device__ __forceinline__ void mm128(int wave, int lane, FA a_at, FB b_at, FS s
         };
         auto chain = [&](const double (&bv)[BDS], int nn) {
             d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            MMSTAMP(1);
+#if defined(MM_WAIT)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif defined(MM_FENCE)
+            asm volatile("" ::: "memory");
+#endif
 #pragma unroll
             for (int s = 0; s < BDS; ++s) acc = MFMA(av[s], bv[s], acc);
+#ifdef PREP_STAMP
+            if (mst) { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+#endif
+            MMSTAMP(2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) store(16 * m + 4 * e + q, 16 * nn + r, acc[e]);
+            MMSTAMP(3);
         };
         fetch(bA, 0);
 #pragma unroll 1
@@ -717,7 +737,7 @@ __device__ __forceinline__ int warmup128(double* W, int tid, double* red) {
 __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     extern __shared__ double lds[];
 #ifdef PREP_STAMP       // (profiles/build_variant.sh k_big pstamp "-DPREP_STAMP": where a workgroup's time goes, shader-clock ticks)
-    unsigned long long ps_t = __builtin_amdgcn_s_memtime(), ps_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ps_t = __builtin_amdgcn_s_memtime(), ps_acc[6] = {0, 0, 0, 0, 0, 0}, ps_mm[4] = {0, 0, 0, 0}, ps_t0 = 0;
 #define PSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ps_acc[i] += t_ - ps_t; ps_t = t_; } while (0)
 #else
 #define PSTAMP(i) do { } while (0)
@@ -769,23 +789,34 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     double* S2 = S1 + BDP * BDP;
     STAGE_LOOP { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = C_at(k, j); }
     __syncthreads();
+#ifdef PREP_STAMP
+    ps_t0 = __builtin_amdgcn_s_memtime();
+#endif
     if (dense)      // <C>^T (E[R]<C>): the second operand straight from the array (the rare, untuned case)
         mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i]; }, [&](int k, int j) { return RC_at(k, j); },
               [&](int i, int j, double v) { S1[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? rowp[i] : 0.0) : 0.0; });
     else
     mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i] * rbar[k]; }, [&](int k, int j) { return Pm[k * BLD + j]; },
-          [&](int i, int j, double v) { S1[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? rowp[i] : 0.0) : 0.0; });
+          [&](int i, int j, double v) { S1[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? rowp[i] : 0.0) : 0.0; }
+#if defined(PREP_STAMP) && !defined(PREP_STAMP_NOMM)
+          , ps_mm
+#endif
+          );
+#ifdef PREP_STAMP
+    ps_t = __builtin_amdgcn_s_memtime(); ps_acc[5] += ps_t - ps_t0;
+#endif
     __syncthreads();
     STAGE_LOOP { const int k = idx >> 7, j = idx & 127; Pm[k * BLD + j] = A_at(k, j); }
     __syncthreads();
     if (dense)
         mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i]; }, [&](int k, int j) { return QA_at(k, j); },
-              [&](int i, int j, double v) { S2[(size_t)i * BDP + j] = (i < D && j < D) ? S1[(size_t)i * BDP + j] + v + (i == j ? colp[i] : 0.0) : 0.0; });
+              [&](int i, int j, double v) { S2[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? colp[i] : 0.0) : 0.0; });
     else
     mm128(wave, lane, [&](int i, int k) { return Pm[k * BLD + i] * qbar[k]; }, [&](int k, int j) { return Pm[k * BLD + j]; },
-          [&](int i, int j, double v) { S2[(size_t)i * BDP + j] = (i < D && j < D) ? S1[(size_t)i * BDP + j] + v + (i == j ? colp[i] : 0.0) : 0.0; });
+          [&](int i, int j, double v) { S2[(size_t)i * BDP + j] = (i < D && j < D) ? v + (i == j ? colp[i] : 0.0) : 0.0; });
     __syncthreads();
-    STAGE_LOOP Pm[(idx >> 7) * BLD + (idx & 127)] = S2[idx];
+    // (the sum of the two moment matrices is formed in this pass: read inside the second product's stores, S1 cost every chain a trip to memory)
+    STAGE_LOOP Pm[(idx >> 7) * BLD + (idx & 127)] = S1[idx] + S2[idx];
     __syncthreads();
 
     PSTAMP(0);
@@ -845,23 +876,17 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
         if (tid < D) for (int j = 0; j < D; ++j) s += a.x0_prec[(size_t)tid * D + j] * a.x0_mean[j];
         g[L.ow0 + tid] = s;
     }
-    // gains of the interior class: F = Sigma <Q><A>, B = Sigma <A>^T<Q>, G = Sigma <C>^T<R>
-    STAGE_LOOP { const int k = idx >> 7, j = idx & 127; S2[idx] = dense ? QA_at(k, j) : qbar[k] * A_at(k, j); }
-    __syncthreads();
-    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return S2[(size_t)k * BDP + j]; },
-          [&](int i, int j, double v) { const bool in = i < D && j < D; g[L.oFn + pos_nat(i, j, BDS)] = in ? v : 0.0; S1[(size_t)i * BDP + j] = in ? v : 0.0; });
-    __syncthreads();
-    // the B operands of the next two products are transposes of row-major matrices: written out once, transposed and scaled,
-    // so that the products read them along rows like the others (a lane per matrix row would touch a cache line per element)
-    STAGE_LOOP { const int j = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + j] = dense ? QA_at(j, k) : A_at(j, k) * qbar[j]; }
-    __syncthreads();
-    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int j) { return S2[(size_t)k * BDP + j]; },
-          [&](int i, int j, double v) { g[L.oBn + pos_nat(i, j, BDS)] = (i < D && j < D) ? v : 0.0; });
-    __syncthreads();
-    STAGE_LOOP { const int l = idx >> 7, k = idx & 127; S2[(size_t)k * BDP + l] = dense ? RC_at(l, k) : C_at(l, k) * rbar[l]; }
-    __syncthreads();
-    mm128(wave, lane, [&](int i, int k) { return Pm[i * BLD + k]; }, [&](int k, int l) { return S2[(size_t)k * BDP + l]; },
-          [&](int i, int l, double v) { g[L.oGp + pos_perm(i, l, BDS)] = (i < D && l < K) ? v : 0.0; });
+    // gains of the interior class: F = Sigma <Q><A>, B = Sigma <A>^T<Q>, G = Sigma <C>^T<R>, each formed TRANSPOSED: the operand a
+    // chain re-reads eight times over (B) is then Sigma, which sits in LDS, and the other factor is the A operand, read once per row
+    // tile straight from the parameter arrays -- no staging pass, no operand fetched from global memory inside the chains (round 3
+    // staged the right-hand factors in the global scratch and read them there: 190 000 cycles a product against 60 000 for a product
+    // with both operands in LDS).  Element (i, j) of a transposed product is element (j, i) of the gain; same products, same sums.
+    mm128(wave, lane, [&](int i, int k) { return dense ? QA_at(k, i) : qbar[k] * A_at(k, i); }, [&](int k, int j) { return Pm[j * BLD + k]; },
+          [&](int i, int j, double v) { const bool in = i < D && j < D; g[L.oFn + pos_nat(j, i, BDS)] = in ? v : 0.0; S1[(size_t)j * BDP + i] = in ? v : 0.0; });
+    mm128(wave, lane, [&](int i, int k) { return dense ? QA_at(i, k) : A_at(i, k) * qbar[i]; }, [&](int k, int j) { return Pm[j * BLD + k]; },
+          [&](int i, int j, double v) { g[L.oBn + pos_nat(j, i, BDS)] = (i < D && j < D) ? v : 0.0; });
+    mm128(wave, lane, [&](int l, int k) { return dense ? RC_at(l, k) : C_at(l, k) * rbar[l]; }, [&](int k, int j) { return Pm[j * BLD + k]; },
+          [&](int l, int j, double v) { g[L.oGp + pos_perm(j, l, BDS)] = (j < D && l < K) ? v : 0.0; });
     __syncthreads();
     PSTAMP(3);
     // warm-up lengths: powers of F, and of B^T (inf-norm of powers of B^T = 1-norm of powers of B)
@@ -879,6 +904,8 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
     if (tid == 0) a.warm[n * 2 + 1] = Jw;
 #ifdef PREP_STAMP
     PSTAMP(4);
+    if (blockIdx.x == 100 && tid == 0)
+        printf("first product: from the staged operands to its last store %llu (A operands %llu | B operands, waits %llu | 16 chains of 32 MFMAs %llu | stores %llu)\n", ps_acc[5], ps_mm[0], ps_mm[1], ps_mm[2], ps_mm[3]);
     if (blockIdx.x == 100 && tid == 0)
         printf("k_prep_big: moments (2 products) %llu | tiles in and out of the three inversions %llu | the three inversions %llu | gains (3 products) %llu | warm-up bounds (10 squarings) %llu\n",
                ps_acc[0], ps_acc[1], ps_acc[2], ps_acc[3], ps_acc[4]);
