@@ -165,6 +165,70 @@ __global__ void __launch_bounds__(256) k_gy_big(BigGyArgs a) {
     }
 }
 
+// Round 4: the same product with EIGHT wavefronts, one row tile each, two to a SIMD -- and the block of y shared through LDS.
+// At one wavefront per SIMD a chain of dependent MFMAs sustains 70 % of the pipe (profiles/r01/microbench_f64.txt; k_gy_big: 69 %
+// busy by the counters), with two it sustains 92 %; what stopped round 3's eight-wavefront form (11.0 against 7.3 ms) was that every
+// wavefront fetched all of y from memory.  Here the workgroup's 512 threads fetch a block of 16 time steps once (a block ahead, into
+// registers, then into the other of two LDS buffers: one barrier per block) and every wavefront reads its B operands from there.
+// Measured at N = 1024, T = 10^4, D = K = 128: lds_d128 49.24 ms against 49.41 with k_gy_big on the same box -- the product moves
+// 21 GB (Y in, G y_t out) in 7.5 ms, and reads and writes together do not pass 5 TB/s on this part (profiles/microbench/hbm_read.hip:
+// a copy makes 2.4-2.8 TB/s each way): it is the traffic of the c_t buffer, not the matrix pipe, that the kernel waits for.  Kept
+// behind PYVB_GY_BIG=8 with the tests of the class run through it once; k_gy_big stays the kernel in use.
+#define GY_LDY 130      // row stride of a y block in LDS: the 16 lanes of a 16-byte operand read fall into 64 different banks
+template <bool Y4>      // Y4: K a multiple of 4 -- a thread's four entries of a block are one 32-byte load
+__global__ void __launch_bounds__(512) k_gy_big8(BigGyArgs a) {
+    __shared__ double yl[2][16 * GY_LDY];
+    const int n = blockIdx.y, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int T = a.T, K = a.K;
+    const double* g = a.gains + (size_t)n * a.L.gains_total + a.L.oGp;
+    const double* Yn = a.Y + (size_t)n * T * K;
+    double* Un = a.U + (size_t)n * T * BDP;
+    double* const trash = a.trash + (size_t)n * 512 + 256;
+    double gr[BDS];
+#pragma unroll
+    for (int s = 0; s < BDS; ++s) gr[s] = g[((size_t)w * BDS + s) * 64 + lane];
+    // staging: thread -> time step srow of the block, entries scol .. scol + 3
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    const int tb0 = 1 + blockIdx.x * a.nblk * 16;
+    d4 stage;
+    auto fetch = [&](int tb) {
+        const int t = tb + srow;
+        const double* yp = Yn + (size_t)(t <= T - 2 ? t : 1) * K;
+        if constexpr (Y4) {
+            const d4 v = *reinterpret_cast<const d4*>(yp + (scol < K ? scol : 0));
+            stage = scol < K ? v : d4{0.0, 0.0, 0.0, 0.0};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double v = yp[scol + e < K ? scol + e : K - 1]; stage[e] = scol + e < K ? v : 0.0; }
+        }
+    };
+    auto put = [&](int buf) {
+        double* d = yl[buf] + srow * GY_LDY + scol;
+        *reinterpret_cast<d2*>(d) = d2{stage[0], stage[1]};
+        *reinterpret_cast<d2*>(d + 2) = d2{stage[2], stage[3]};
+    };
+    fetch(tb0); put(0);
+    __syncthreads();
+    for (int b = 0; b < a.nblk; ++b) {
+        const int tb = tb0 + b * 16;
+        if (tb > T - 2) break;                                  // block-uniform
+        const bool more = b + 1 < a.nblk && tb + 16 <= T - 2;
+        if (more) fetch(tb + 16);
+        const double* yb = yl[b & 1] + c * GY_LDY + 2 * q;      // B operand of step s = 2 i + j: y_t[8 i + 2 q + j], t = tb + c
+        d2 yv[BDS / 2];
+#pragma unroll
+        for (int i = 0; i < BDS / 2; ++i) yv[i] = *reinterpret_cast<const d2*>(yb + 8 * i);
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < BDS; ++s) acc = MFMA(gr[s], yv[s >> 1][s & 1], acc);
+        const int t = tb + c;
+        double* ur = (t <= T - 2) ? Un + (size_t)t * BDP : trash;
+        *reinterpret_cast<d4*>(ur + (w * 4 + q) * 4) = acc;
+        if (more) put((b + 1) & 1);
+        __syncthreads();
+    }
+}
+
 // The sweep proper.  The parameters are frozen between the two sweeps of an iteration, and the backward update
 //   mu_t <- B mu_{t+1}(new) + F mu_{t-1}(forward result) + G y_t
 // contains c_t = F mu_{t-1} + G y_t, which the forward sweep has just formed (k_sweep.hip).
@@ -413,8 +477,13 @@ int launch_sweep_big(pyvb_lds* h, int direction) {
         ga.nblk = blocks < 32 ? ((blocks + 1) & ~1) : 32;
         TimedLaunch tl(h, PYVB_K_GY);
         const dim3 grid((blocks + ga.nblk - 1) / ga.nblk, h->N);
-        if ((h->K & 1) == 0) hipLaunchKernelGGL(k_gy_big<true>, grid, dim3(256), 0, h->stream, ga);
-        else hipLaunchKernelGGL(k_gy_big<false>, grid, dim3(256), 0, h->stream, ga);
+        static const bool four = [] { const char* e = getenv("PYVB_GY_BIG"); return !(e && e[0] == '8'); }();     // PYVB_GY_BIG=8: k_gy_big8 (measured the same: see there)
+        if (four) {
+            if ((h->K & 1) == 0) hipLaunchKernelGGL(k_gy_big<true>, grid, dim3(256), 0, h->stream, ga);
+            else hipLaunchKernelGGL(k_gy_big<false>, grid, dim3(256), 0, h->stream, ga);
+        }
+        else if ((h->K & 3) == 0) hipLaunchKernelGGL(k_gy_big8<true>, grid, dim3(512), 0, h->stream, ga);
+        else hipLaunchKernelGGL(k_gy_big8<false>, grid, dim3(512), 0, h->stream, ga);
     }
     {
         TimedLaunch tl(h, direction == PYVB_FORWARD ? PYVB_K_SWEEP_FWD : PYVB_K_SWEEP_BWD);
