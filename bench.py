@@ -125,11 +125,15 @@ def pca_workload(steps, warmup, with_cpu, comm=None, rank=0, world=1, device=0, 
         return b, float((~obs).sum())
 
     b, nmiss = shard(N)
-    b.iterate(warmup); b.sync()
+    # an iteration takes a millisecond: at the headline's 3 + 20 steps the timed region would be 20 ms, taken right after seconds of
+    # host-side data generation with the GPU idle (measured: 1.00 ms per step that way against 0.94 over 100 steps).  The timed loop
+    # of this workload is therefore at least 10 + 100 steps; the parity copy below keeps the headline's counts (the oracle runs them too).
+    t_warm, t_steps = max(warmup, 10), max(steps, 100)
+    b.iterate(t_warm); b.sync()
     if comm is not None:
         comm.barrier()
     t0 = time.perf_counter()
-    b.iterate(steps); b.sync()
+    b.iterate(t_steps); b.sync()
     if comm is not None:
         comm.barrier()
     dt = time.perf_counter() - t0
@@ -176,7 +180,7 @@ def pca_workload(steps, warmup, with_cpu, comm=None, rank=0, world=1, device=0, 
                 traffic = hit[0][1]
                 tsrc = "profiles/%s/traffic_pca_pmc.json: %s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (committed; not measured in this run)" % (tag, hit[0][0].split("(")[0].replace("void ", ""))
                 break
-    step_s = dt / steps
+    step_s = dt / t_steps
     QP, DP = 16, 256
     stats_doubles = (QP * QP + DP * QP + DP + QP + 4 + 7) // 8 * 8         # pyvb_amd/csrc/pca.h: pca_stats_layout
     coll_bytes = 8 * (stats_doubles + 2 * (QP + DP))
@@ -185,8 +189,8 @@ def pca_workload(steps, warmup, with_cpu, comm=None, rank=0, world=1, device=0, 
          % ("rccl" if transport == "rccl" else "host (over TCP: DEGRADED)", 8 * stats_doubles, 8 * (QP + DP), coll_bytes))
     return {"workload": "VB-PCA N=%d d=%d q=%d, 10%% missing (%s), rows sharded over %d GPU(s)"
                         % (N, d, q, "BASELINE configs[4]" if N == 1000000 else "not a BASELINE configuration", world),
-            "metric": "VB-PCA iterations/sec", "value": steps / dt, "unit": "VB iterations/s", "n_gpus": world, "scaling": "strong",
-            "steps": steps, "warmup": warmup, "ms_per_step": step_s * 1e3, "dtype": "f64", "rel_err_vs_numpy": parity,
+            "metric": "VB-PCA iterations/sec", "value": t_steps / dt, "unit": "VB iterations/s", "n_gpus": world, "scaling": "strong",
+            "steps": t_steps, "warmup": t_warm, "ms_per_step": step_s * 1e3, "dtype": "f64", "rel_err_vs_numpy": parity,
             "parity_checked_on": "a %d-row copy of the problem sharded the same way, %d iterations, same kernels and collectives" % (n_s, warmup + steps),
             "elbo_total": float(elbo.sum()), "collective": collective, "collective_bytes_per_step": 0 if world == 1 else coll_bytes,
             "degraded": world > 1 and transport != "rccl",
