@@ -268,3 +268,130 @@ __device__ __forceinline__ void gj_wg128(double (&v)[8][8], int D, int tid, doub
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same with GJR pivots to a step (-DGJ_RANK=2 or 4; profiles/build_variant.sh): a step takes the GJR rows and columns of its pivots as
+// they stand (published by their owners at the end of the step before), inverts the GJR x GJR pivot block B in every thread, and applies
+//     M[i,j] -= C_i B^-1 R_j      M[B,j] = B^-1 R_j      M[i,B] = -C_i B^-1      M[B,B] = B^-1
+// -- the arithmetic of GJR single-pivot steps behind one barrier; the pivots of the small elimination are those of the single steps.
+// An experiment of round 4, not in the shipped library: correct with 2 and with 4 (all tests of the 128-wide class) and no faster --
+// the three inversions of k_prep_big take 850 000 cycles per workgroup with a pivot per barrier, 881 000 with two, 1 017 000 with
+// four (there the 128 + 64 + 64 live doubles per thread run through accumulator-register moves).  The barrier is not what a pivot's
+// 2 200 cycles are made of (profiles/r04/prep_big_stamps.txt).
+#ifdef GJ_RANK
+#define GJR GJ_RANK
+#undef GJB_BUF
+#define GJB_BUF (2 * GJR * 128)
+__device__ __forceinline__ void gj_wg128_blocked(double (&v)[8][8], int D, int tid, double* rc, double* pivs) {
+    const int a = tid >> 4, b = tid & 15;
+    constexpr int NH = 8 / GJR;             // steps per 8 x 8 tile
+    auto publish = [&](double* buf, int P1, int h1) {       // rows and columns 8 P1 + GJR h1 .. of the matrix as it stands
+        if (a == P1) {
+#pragma unroll
+            for (int r4 = 0; r4 < GJR; ++r4)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+                    double x = 0.0;
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh) x = (hh == h1) ? v[GJR * hh + r4][cb] : x;
+                    buf[r4 * 128 + 8 * b + cb] = x;
+                }
+        }
+        if (b == P1) {
+#pragma unroll
+            for (int c4 = 0; c4 < GJR; ++c4)
+#pragma unroll
+                for (int ra = 0; ra < 8; ++ra) {
+                    double x = 0.0;
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh) x = (hh == h1) ? v[ra][GJR * hh + c4] : x;
+                    buf[GJR * 128 + c4 * 128 + 8 * a + ra] = x;
+                }
+        }
+    };
+    publish(rc, 0, 0);
+    int cur = 0;
+    for (int P = 0; 8 * P < D; ++P) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int p = 8 * P + GJR * h;
+            if (p >= D) continue;                                   // block-uniform (rows beyond D carry the identity)
+            __syncthreads();
+            const double* row = rc + cur * GJB_BUF;
+            const double* col = row + GJR * 128;
+            double* nbuf = rc + (cur ^ 1) * GJB_BUF;
+            double dm[GJR][GJR];
+#pragma unroll
+            for (int r4 = 0; r4 < GJR; ++r4)
+#pragma unroll
+                for (int c4 = 0; c4 < GJR; ++c4) dm[r4][c4] = row[r4 * 128 + p + c4];
+#pragma unroll
+            for (int k = 0; k < GJR; ++k) {
+                const double piv = dm[k][k];
+                if (tid == 0 && p + k < D) pivs[p + k] = piv;
+                const double d = 1.0 / piv;
+#pragma unroll
+                for (int j = 0; j < GJR; ++j) if (j != k) dm[k][j] *= d;
+#pragma unroll
+                for (int i = 0; i < GJR; ++i) {
+                    if (i == k) continue;
+                    const double f = dm[i][k];
+#pragma unroll
+                    for (int j = 0; j < GJR; ++j) if (j != k) dm[i][j] = __builtin_fma(-f, dm[k][j], dm[i][j]);
+                    dm[i][k] = -f * d;
+                }
+                dm[k][k] = d;
+            }
+            double T[GJR][8];
+            {
+                double rj[GJR][8];
+#pragma unroll
+                for (int r4 = 0; r4 < GJR; ++r4)
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb) rj[r4][cb] = row[r4 * 128 + 8 * b + cb];
+#pragma unroll
+                for (int r4 = 0; r4 < GJR; ++r4)
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb) {
+                        double t = dm[r4][0] * rj[0][cb];
+#pragma unroll
+                        for (int m = 1; m < GJR; ++m) t = __builtin_fma(dm[r4][m], rj[m][cb], t);
+                        T[r4][cb] = t;
+                    }
+            }
+#pragma unroll
+            for (int ra = 0; ra < 8; ++ra) {
+                double ci[GJR];
+#pragma unroll
+                for (int c4 = 0; c4 < GJR; ++c4) ci[c4] = col[c4 * 128 + 8 * a + ra];
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+                    double x = v[ra][cb];
+#pragma unroll
+                    for (int c4 = 0; c4 < GJR; ++c4) x = __builtin_fma(-ci[c4], T[c4][cb], x);
+                    v[ra][cb] = x;
+                }
+                if (b == P) {                                       // the pivots' columns: -C_i B^-1
+#pragma unroll
+                    for (int c4 = 0; c4 < GJR; ++c4) {
+                        double t = ci[0] * dm[0][c4];
+#pragma unroll
+                        for (int m = 1; m < GJR; ++m) t = __builtin_fma(ci[m], dm[m][c4], t);
+                        v[ra][GJR * h + c4] = -t;
+                    }
+                }
+            }
+            if (a == P) {                                           // the pivots' rows: B^-1 R_j, and B^-1 itself where they cross the columns
+#pragma unroll
+                for (int r4 = 0; r4 < GJR; ++r4)
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb)
+                        v[GJR * h + r4][cb] = (b == P && cb >= GJR * h && cb < GJR * h + GJR) ? dm[r4][(cb - GJR * h) & (GJR - 1)] : T[r4][cb];
+            }
+            if (h + 1 < NH) publish(nbuf, P, h + 1); else publish(nbuf, P + 1, 0);
+            cur ^= 1;
+        }
+    }
+    __syncthreads();
+}
+#define gj_wg128 gj_wg128_blocked
+#endif
