@@ -194,6 +194,31 @@ def test_stagewise_vs_oracle_beyond_64(T, D, K, N, kind):
     _stagewise(Y, st0, pri, iters=3)
 
 
+def test_column_ranges_on_the_128_wide_class():
+    """As[i].update() / Cs[i].update() for a RANGE of columns (pyvb_lds_update_columns) on the blocked column kernel of the 128-wide
+    class (k_cols_big: blocks of 16 columns): ranges that start and end inside a block, span several, are a single column, are the
+    last column; some entries of A and C known.  Against the oracle's column loop over the same ranges, then Q and R from the result."""
+    T, D, K, N = 12, 100, 70, 2
+    Y, st0, pri = synth.make_problem(T, D, K, N, seed=57)
+    rng = np.random.default_rng(3)
+    pri["A_obs"] = np.where(rng.random((D, D)) < 0.05, rng.standard_normal((D, D)) * 0.2, np.nan)
+    pri["C_obs"] = np.where(rng.random((K, D)) < 0.05, rng.standard_normal((K, D)), np.nan)
+    b = _batch(Y, st0, pri)
+    st = O.expand_state(st0, pri, T)
+    O.sweep(st, pri, Y, "forward"); b.sweep("forward")
+    O.sweep(st, pri, Y, "backward"); b.sweep("backward")
+    S = O.statistics(st, Y)
+    for which, lo, hi in [("A", 5, 77), ("C", 0, 1), ("A", 99, 100), ("C", 17, 33), ("A", 0, 100), ("C", 30, 100), ("A", 15, 17), ("C", 0, 100)]:
+        (O.update_A if which == "A" else O.update_C)(st, pri, S, cols=(lo, hi))
+        b.update_columns(which, lo, hi)
+        g = b.get_state()
+        _close(g["A_mean"], st["A_mean"], "A_mean after %s[%d:%d]" % (which, lo, hi)); _close(g["C_mean"], st["C_mean"], "C_mean after %s[%d:%d]" % (which, lo, hi))
+    O.update_Q(st, pri, S, T); b.update_Q()
+    O.update_R(st, pri, S, T); b.update_R()
+    _compare_params(b, st, "after the column ranges: ")
+    b.close()
+
+
 @pytest.mark.parametrize("T,D,K,N,kind", [(25, 40, 100, 2, "diagonal_gamma"), (20, 72, 66, 1, "gamma")])
 def test_outputs_with_missing_entries_beyond_64(T, D, K, N, kind):
     """Y with NaN (gaussian.py:90-96) where K (or D) exceeds 64: the output kernels handle two entries per lane."""

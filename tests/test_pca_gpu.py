@@ -115,6 +115,29 @@ def test_imputed_entries_are_recomputed_not_stored(sweep, monkeypatch):
     assert np.all(np.abs(ea - ref) <= RTOL * np.abs(ref).sum())
 
 
+def test_the_sweep_a_long_problem_gets_by_default_with_fewer_than_sixteen_latents(monkeypatch):
+    """From 512 rows per CU on (and d > 192) a handle takes the pair-owning sweep without being asked (api_pca.hip); here with q = 7
+    and d = 250 -- padded latent indices and a padded column tile in the kernel that otherwise only meets q = 16 at that size --
+    against the oracle and against the column-owning sweep on the same problem."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    from pyvb_amd.pca import PCABatch
+    N, d, q = 140000, 250, 7
+    init, pri = G.pca_problem(N, d, q, seed=5)
+    monkeypatch.delenv("PYVB_PCA_SWEEP", raising=False)
+    a = PCABatch.from_problem(init, pri); a.iterate(3); sa = a.get_state(); ea = a.elbo(); a.close()
+    monkeypatch.setenv("PYVB_PCA_SWEEP", "columns")
+    c = PCABatch.from_problem(init, pri); c.iterate(3); sc = c.get_state(); ec = c.elbo(); c.close()
+    st = P.make_state(init, pri, N, d, q)
+    for _ in range(3):
+        ref = P.iterate(st, pri)
+    for k in ("W_mean", "W_var", "Z", "X", "Mu_mean", "beta_b"):
+        _close(sa[k], st[k], "default sweep vs oracle: " + k)
+        _close(sa[k], sc[k], "default sweep vs column-owning sweep: " + k)
+    assert np.all(np.abs(ea - ref) <= RTOL * np.abs(ref).sum()) and np.all(np.abs(ea - ec) <= 1e-10 * np.abs(ec).sum())
+
+
 @pytest.mark.parametrize("N,d,q", [(300, 20, 4), (1000, 64, 16), (77, 33, 17), (5000, 256, 16), (16, 3, 1), (17, 250, 31)])
 def test_stagewise_vs_oracle(N, d, q):
     import importlib.util
