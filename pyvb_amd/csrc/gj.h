@@ -13,6 +13,13 @@
 // costs one barrier, and the NP independent eliminations interleave to cover its latency.
 // rc: scratch [NP][2][GJ_BUF], pivs [NP][64].  On return v holds the inverses and pivs the pivots,
 // whose logs sum to 2 * sum log diag(chol(P)).
+// (Layout of a pivot's LDS vectors.  Shifting the second half of the row by two doubles -- GJ_ROW(j) = j + 2 (j / 32), against the
+// two-way bank conflict of threads whose b differ by eight, by four in gj_wave -- was measured and is NOT used: no difference in
+// k_prep, and the Wishart column eliminations got slower, 5.57 against 5.36 ms.  The four-way conflict of gj_wg128 below is another
+// matter: there the padded row pays.)
+#define GJ_ROW(j) (j)
+#define GJ_COL 64
+#define GJ_D 128
 #define GJ_BUF 136      // row (64), column (64), 1/pivot, padding
 template <int NP>
 __device__ __forceinline__ void gj_inverse(double (&v)[NP][16], int D, int tid, double* rc, double* pivs) {
@@ -22,13 +29,13 @@ __device__ __forceinline__ void gj_inverse(double (&v)[NP][16], int D, int tid, 
         double* row = rc + (c * 2) * GJ_BUF;
         if (a == 0) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) row[4 * b + cb] = v[c][cb];           // row 0
+            for (int cb = 0; cb < 4; ++cb) row[GJ_ROW(4 * b) + cb] = v[c][cb];   // row 0
         }
         if (b == 0) {
 #pragma unroll
-            for (int ra = 0; ra < 4; ++ra) row[64 + 4 * a + ra] = v[c][4 * ra];  // column 0
+            for (int ra = 0; ra < 4; ++ra) row[GJ_COL + 4 * a + ra] = v[c][4 * ra];  // column 0
         }
-        if (tid == 0) row[128] = 1.0 / v[c][0];
+        if (tid == 0) row[GJ_D] = 1.0 / v[c][0];
     }
     int cur = 0;
     for (int P = 0; 4 * P < D; ++P) {
@@ -41,14 +48,14 @@ __device__ __forceinline__ void gj_inverse(double (&v)[NP][16], int D, int tid, 
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
                 const double* row = rc + (c * 2 + cur) * GJ_BUF;
-                const double* col = row + 64;
+                const double* col = row + GJ_COL;
                 double* nrow = rc + (c * 2 + (cur ^ 1)) * GJ_BUF;
-                double* ncol = nrow + 64;
-                const double d = row[128];
-                if (tid == 0) pivs[c * 64 + p] = row[p];
+                double* ncol = nrow + GJ_COL;
+                const double d = row[GJ_D];
+                if (tid == 0) pivs[c * 64 + p] = row[GJ_ROW(p)];
                 double rj[4], ci[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { rj[k] = row[4 * b + k] * d; ci[k] = col[4 * a + k]; }
+                for (int k = 0; k < 4; ++k) { rj[k] = row[GJ_ROW(4 * b) + k] * d; ci[k] = col[4 * a + k]; }
 #pragma unroll
                 for (int ra = 0; ra < 4; ++ra)
 #pragma unroll
@@ -63,13 +70,13 @@ __device__ __forceinline__ void gj_inverse(double (&v)[NP][16], int D, int tid, 
                 }
                 if (a == P1) {
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) nrow[4 * b + cb] = v[c][4 * q1 + cb];
+                    for (int cb = 0; cb < 4; ++cb) nrow[GJ_ROW(4 * b) + cb] = v[c][4 * q1 + cb];
                 }
                 if (b == P1) {
 #pragma unroll
                     for (int ra = 0; ra < 4; ++ra) ncol[4 * a + ra] = v[c][4 * ra + q1];
                 }
-                if (a == P1 && b == P1) nrow[128] = 1.0 / v[c][4 * q1 + q1];
+                if (a == P1 && b == P1) nrow[GJ_D] = 1.0 / v[c][4 * q1 + q1];
             }
             cur ^= 1;
         }
@@ -87,7 +94,7 @@ __device__ __forceinline__ void gj_inverse(double (&v)[NP][16], int D, int tid, 
 // workgroup barrier in the loop and the wavefronts of a workgroup invert different matrices independently.
 // rc: this wavefront's scratch [2][GJW_BUF]; pivs: [64] pivots (their logs sum to ln det).  Used for the column
 // covariances under Wishart noise (k_wishart.hip), where a replicate needs 2 D inversions per iteration.
-#define GJW_BUF 136     // row (64), column (64), 1/pivot, padding
+#define GJW_BUF GJ_BUF   // the same layout
 __device__ __forceinline__ double gjw_recip(double x) {
     // v_rcp_f64 and two Newton steps: the IEEE division is ~40 instructions that all 64 lanes would sit through for one pivot
     double r = __builtin_amdgcn_rcp(x);
@@ -107,13 +114,13 @@ __device__ __forceinline__ void gj_wave(double (&v)[8][8], int D, int lane, doub
         double* row = rc;
         if (a == 0) {
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb) row[8 * b + cb] = v[0][cb];           // row 0
+            for (int cb = 0; cb < 8; ++cb) row[GJ_ROW(8 * b) + cb] = v[0][cb];   // row 0
         }
         if (b == 0) {
 #pragma unroll
-            for (int ra = 0; ra < 8; ++ra) row[64 + 8 * a + ra] = v[ra][0];      // column 0
+            for (int ra = 0; ra < 8; ++ra) row[GJ_COL + 8 * a + ra] = v[ra][0];  // column 0
         }
-        if (lane == 0) row[128] = gjw_recip(v[0][0]);
+        if (lane == 0) row[GJ_D] = gjw_recip(v[0][0]);
     }
     int cur = 0;
     for (int P = 0; 8 * P < D; ++P) {
@@ -124,14 +131,14 @@ __device__ __forceinline__ void gj_wave(double (&v)[8][8], int D, int lane, doub
             const int P1 = (pp == 7) ? P + 1 : P, q1 = (pp + 1) & 7;    // where row / column p + 1 live
             gjw_sync();
             const double* row = rc + cur * GJW_BUF;
-            const double* col = row + 64;
+            const double* col = row + GJ_COL;
             double* nrow = rc + (cur ^ 1) * GJW_BUF;
-            double* ncol = nrow + 64;
-            const double d = row[128];
-            if (lane == 0) pivs[p] = row[p];
+            double* ncol = nrow + GJ_COL;
+            const double d = row[GJ_D];
+            if (lane == 0) pivs[p] = row[GJ_ROW(p)];
             double rj[8], ci[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { rj[k] = row[8 * b + k] * d; ci[k] = col[8 * a + k]; }
+            for (int k = 0; k < 8; ++k) { rj[k] = row[GJ_ROW(8 * b) + k] * d; ci[k] = col[8 * a + k]; }
 #pragma unroll
             for (int ra = 0; ra < 8; ++ra)
 #pragma unroll
@@ -146,13 +153,13 @@ __device__ __forceinline__ void gj_wave(double (&v)[8][8], int D, int lane, doub
             }
             if (a == P1) {
 #pragma unroll
-                for (int cb = 0; cb < 8; ++cb) nrow[8 * b + cb] = v[q1][cb];
+                for (int cb = 0; cb < 8; ++cb) nrow[GJ_ROW(8 * b) + cb] = v[q1][cb];
             }
             if (b == P1) {
 #pragma unroll
                 for (int ra = 0; ra < 8; ++ra) ncol[8 * a + ra] = v[ra][q1];
             }
-            if (a == P1 && b == P1) nrow[128] = gjw_recip(v[q1][q1]);
+            if (a == P1 && b == P1) nrow[GJ_D] = gjw_recip(v[q1][q1]);
             cur ^= 1;
         }
     }
@@ -173,22 +180,22 @@ __device__ __forceinline__ void gj_wave_subset(double (&v)[8][8], unsigned long 
             const int p = 8 * P + pp;
             if (!((mask >> p) & 1ull)) continue;                // wave-uniform
             double* row = rc;
-            double* col = rc + 64;
+            double* col = rc + GJ_COL;
             gjw_sync();
             if (a == P) {
 #pragma unroll
-                for (int cb = 0; cb < 8; ++cb) row[8 * b + cb] = v[pp][cb];
+                for (int cb = 0; cb < 8; ++cb) row[GJ_ROW(8 * b) + cb] = v[pp][cb];
             }
             if (b == P) {
 #pragma unroll
                 for (int ra = 0; ra < 8; ++ra) col[8 * a + ra] = v[ra][pp];
             }
-            if (a == P && b == P) { row[128] = gjw_recip(v[pp][pp]); pivs2[p] = v[pp][pp]; }
+            if (a == P && b == P) { row[GJ_D] = gjw_recip(v[pp][pp]); pivs2[p] = v[pp][pp]; }
             gjw_sync();
-            const double d = row[128];
+            const double d = row[GJ_D];
             double rj[8], ci[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { rj[k] = row[8 * b + k] * d; ci[k] = col[8 * a + k]; }
+            for (int k = 0; k < 8; ++k) { rj[k] = row[GJ_ROW(8 * b) + k] * d; ci[k] = col[8 * a + k]; }
 #pragma unroll
             for (int ra = 0; ra < 8; ++ra)
 #pragma unroll
@@ -210,41 +217,57 @@ __device__ __forceinline__ void gj_wave_subset(double (&v)[8][8], unsigned long 
 // ---------------------------------------------------------------------------------------------------------------------
 // 128-wide: the whole workgroup on one matrix (k_big.hip: k_prep_big; k_wishart_big.hip)
 // Inverse of the symmetric positive definite matrix held as 8 x 8 tiles by the 16 x 16 threads of the workgroup (thread
-// (a = tid / 16, b = tid % 16) owns elements (8a + ra, 8b + cb)), Gauss-Jordan without pivoting as gj.h; rc: [2][264] doubles
-// of LDS (row 128, column 128, 1/pivot), pivs: [128].
-#define GJB_BUF 264
+// (a = tid / 16, b = tid % 16) owns elements (8a + ra, 8b + cb)), Gauss-Jordan without pivoting as gj.h; rc: [2][GJB_BUF] doubles
+// of LDS (row, column, 1/pivot), pivs: [128].
+// The pivot row sits in LDS with a stride of NINE doubles per thread column (element j at 9 (j / 8) + j % 8): the sixteen threads that
+// differ in b read 8 b + k otherwise -- 64 bytes apart, four of the 64 banks, a four-way conflict on every one of the eight reads of a
+// pivot (stamps: 830 of a pivot's 2 300 cycles went to these reads).
+#define GJB_ROW(j) (9 * ((j) >> 3) + ((j) & 7))
+#define GJB_COL 144
+#define GJB_D 272
+#define GJB_BUF 280
 __device__ __forceinline__ void gj_wg128(double (&v)[8][8], int D, int tid, double* rc, double* pivs) {
     const int a = tid >> 4, b = tid & 15;
     if (a == 0) {
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb) rc[8 * b + cb] = v[0][cb];
+        for (int cb = 0; cb < 8; ++cb) rc[9 * b + cb] = v[0][cb];
     }
     if (b == 0) {
 #pragma unroll
-        for (int ra = 0; ra < 8; ++ra) rc[128 + 8 * a + ra] = v[ra][0];
+        for (int ra = 0; ra < 8; ++ra) rc[GJB_COL + 8 * a + ra] = v[ra][0];
     }
-    if (tid == 0) rc[256] = 1.0 / v[0][0];
+    if (tid == 0) rc[GJB_D] = 1.0 / v[0][0];
     int cur = 0;
+#ifdef GJ_STAMP     // (profiles/build_variant.sh k_big gjstamp "-DGJ_STAMP -DPREP_STAMP": what a pivot's cycles are made of)
+    unsigned long long gs_t = __builtin_amdgcn_s_memtime(), gs_acc[5] = {0, 0, 0, 0, 0};
+#define GSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gs_acc[i] += t_ - gs_t; gs_t = t_; } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
     for (int P = 0; 8 * P < D; ++P) {
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
             const int p = 8 * P + pp;
             if (p >= D) continue;                                   // block-uniform
             const int P1 = (pp == 7) ? P + 1 : P, q1 = (pp + 1) & 7;
+            GSTAMP(0);
             __syncthreads();
+            GSTAMP(1);
             const double* row = rc + cur * GJB_BUF;
-            const double* col = row + 128;
+            const double* col = row + GJB_COL;
             double* nrow = rc + (cur ^ 1) * GJB_BUF;
-            double* ncol = nrow + 128;
-            const double d = row[256];
-            if (tid == 0) pivs[p] = row[p];
+            double* ncol = nrow + GJB_COL;
+            const double d = row[GJB_D];
+            if (tid == 0) pivs[p] = row[GJB_ROW(p)];
             double rj[8], ci[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { rj[k] = row[8 * b + k] * d; ci[k] = col[8 * a + k]; }
+            for (int k = 0; k < 8; ++k) { rj[k] = row[9 * b + k] * d; ci[k] = col[8 * a + k]; }
+            GSTAMP(2);
 #pragma unroll
             for (int ra = 0; ra < 8; ++ra)
 #pragma unroll
                 for (int cb = 0; cb < 8; ++cb) v[ra][cb] = __builtin_fma(-ci[ra], rj[cb], v[ra][cb]);
+            GSTAMP(3);
             if (b == P) {
 #pragma unroll
                 for (int ra = 0; ra < 8; ++ra) v[ra][pp] = -ci[ra] * d;
@@ -255,17 +278,22 @@ __device__ __forceinline__ void gj_wg128(double (&v)[8][8], int D, int tid, doub
             }
             if (a == P1) {
 #pragma unroll
-                for (int cb = 0; cb < 8; ++cb) nrow[8 * b + cb] = v[q1][cb];
+                for (int cb = 0; cb < 8; ++cb) nrow[9 * b + cb] = v[q1][cb];
             }
             if (b == P1) {
 #pragma unroll
                 for (int ra = 0; ra < 8; ++ra) ncol[8 * a + ra] = v[ra][q1];
             }
-            if (a == P1 && b == P1) nrow[256] = 1.0 / v[q1][q1];
+            if (a == P1 && b == P1) nrow[GJB_D] = 1.0 / v[q1][q1];
             cur ^= 1;
         }
     }
     __syncthreads();
+#ifdef GJ_STAMP
+    GSTAMP(0);
+    if (blockIdx.x == 100 && (tid == 0 || tid == 200))
+        printf("gj_wg128 thread %d: fix-ups, publishing, 1/pivot %llu | at the barrier %llu | row, column, 1/pivot from LDS %llu | 64 multiply-adds %llu\n", tid, gs_acc[0], gs_acc[1], gs_acc[2], gs_acc[3]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
