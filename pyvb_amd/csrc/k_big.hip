@@ -925,17 +925,42 @@ __global__ void __launch_bounds__(256) k_prep_big(BigPrepArgs a) {
             lp = wave_sum(lp);
             if (tid == 0) a.qld[(size_t)n * 3 + c] = 0.5 / (0.5 * lp);
         }
+        // a thread's eight entries of a row are 64 contiguous bytes: with D a multiple of four they are stored as two 32-byte pieces
+        // (element by element a wavefront's store touched 64 separate sectors and wrote a quarter of each)
+        const bool vec = (D & 3) == 0;
+        if (vec) {
 #pragma unroll
-        for (int ra = 0; ra < 8; ++ra)
+            for (int ra = 0; ra < 8; ++ra) {
+                const int i = 8 * ta + ra;
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                const int i = 8 * ta + ra, j = 8 * tb + cb;
-                const bool in = i < D && j < D;
-                if (in) a.Sigma[((size_t)n * 3 + c) * D * D + (size_t)i * D + j] = v[ra][cb];
-                if (c == 0) g[L.oS0 + (size_t)i * BDP + j] = in ? v[ra][cb] : 0.0;
-                if (c == 2) g[L.oS2 + (size_t)i * BDP + j] = in ? v[ra][cb] : 0.0;
-                if (c == 1) Pm[i * BLD + j] = in ? v[ra][cb] : 0.0;          // every thread has read its tile of Pm: barriers inside gj_wg128
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int j0 = 8 * tb + 4 * hf;
+                    const bool in = i < D && j0 < D;
+                    const d4 val = in ? d4{v[ra][4 * hf], v[ra][4 * hf + 1], v[ra][4 * hf + 2], v[ra][4 * hf + 3]} : d4{0.0, 0.0, 0.0, 0.0};
+                    if (in) *reinterpret_cast<d4*>(a.Sigma + ((size_t)n * 3 + c) * D * D + (size_t)i * D + j0) = val;
+                    if (c == 0) *reinterpret_cast<d4*>(g + L.oS0 + (size_t)i * BDP + j0) = val;
+                    if (c == 2) *reinterpret_cast<d4*>(g + L.oS2 + (size_t)i * BDP + j0) = val;
+                    if (c == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Pm[i * BLD + j0 + e] = val[e];     // every thread has read its tile of Pm: barriers inside gj_wg128
+                    }
+                }
             }
+        } else {
+#pragma unroll
+            for (int ra = 0; ra < 8; ++ra) {
+                const int i = 8 * ta + ra;
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+                    const int j = 8 * tb + cb;
+                    const bool in = i < D && j < D;
+                    if (in) a.Sigma[((size_t)n * 3 + c) * D * D + (size_t)i * D + j] = v[ra][cb];
+                    if (c == 0) g[L.oS0 + (size_t)i * BDP + j] = in ? v[ra][cb] : 0.0;
+                    if (c == 2) g[L.oS2 + (size_t)i * BDP + j] = in ? v[ra][cb] : 0.0;
+                    if (c == 1) Pm[i * BLD + j] = in ? v[ra][cb] : 0.0;          // every thread has read its tile of Pm: barriers inside gj_wg128
+                }
+            }
+        }
         __syncthreads();
     }
     PSTAMP(1);
