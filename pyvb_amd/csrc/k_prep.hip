@@ -144,6 +144,12 @@ __device__ __forceinline__ int warmup_length(double* W1, double* W2, int LD, int
 template <int DT, int KT, bool DENSE>
 __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     constexpr int DP = 16 * DT, DS = 4 * DT, KS = 4 * KT, LD = DP + 2;
+#ifdef PREP64_STAMP     // (profiles/build_variant.sh k_prep p64 "-DPREP64_STAMP": where a workgroup's time goes, shader-clock ticks)
+    unsigned long long qs_t = __builtin_amdgcn_s_memtime(), qs_acc[6] = {0, 0, 0, 0, 0, 0};
+#define QSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); qs_acc[i] += t_ - qs_t; qs_t = t_; } while (0)
+#else
+#define QSTAMP(i) do { } while (0)
+#endif
     // <A> and <C> are MFMA operands straight from global memory (L2-resident, 32 KB each): keeping them in
     // LDS too would put the workgroup over half of the CU's 160 KB and halve the occupancy of a kernel
     // that is all latency.  Zero padded by the accessors.
@@ -226,6 +232,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     __syncthreads();
     }
 
+    QSTAMP(0);
     // the three posterior precisions, qprec = pprec + (m1 from Mult(C,.) + m1 from Mult(A,.))  gaussian.py:117,
     // inverted together in registers (qcov, gaussian.py:118-119)
     double sig[3][16];
@@ -240,12 +247,15 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
             double qd;
             if constexpr (DENSE) qd = in ? Qd[i * D + j] : 0.0; else qd = (in && i == j) ? qbar[i] : 0.0;
             const double pad = (!in && i == j) ? 1.0 : 0.0;         // identity in the padding keeps pivots finite
-            sig[0][u] = (in ? a.x0_prec[i * D + j] : 0.0) + mac + pad;
+            const double x0p = a.x0_prec[(i < D ? i : D - 1) * D + (j < D ? j : D - 1)];       // (unconditional, from a clamped place)
+            sig[0][u] = (in ? x0p : 0.0) + mac + pad;
             sig[1][u] = qd + mac + pad;
             sig[2][u] = qd + mc + pad;
         }
     __syncthreads();
+    QSTAMP(1);
     gj_inverse<3>(sig, D, tid, gjbuf, gjbuf + 3 * 2 * GJ_BUF);
+    QSTAMP(2);
     if (tid < 64) {                                                 // q_ln_det, gaussian.py:120 (quirk Q1)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -260,6 +270,16 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
             if (tid == 0) a.qld[(size_t)n * 3 + c] = 0.5 / (0.5 * lp);
         }
     }
+    if ((D & 3) == 0) {         // a thread's four entries of a row are 32 contiguous bytes: one store (element by element they were 48 scattered ones)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ra = 0; ra < 4; ++ra) {
+                const int i = 4 * ta + ra, j0 = 4 * tb;
+                if (i < D && j0 < D)
+                    *reinterpret_cast<d4*>(a.Sigma + ((size_t)n * 3 + c) * D * D + (size_t)i * D + j0) = d4{sig[c][4 * ra], sig[c][4 * ra + 1], sig[c][4 * ra + 2], sig[c][4 * ra + 3]};
+            }
+    } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -269,6 +289,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
                 const int i = 4 * ta + ra, j = 4 * tb + cb;
                 if (i < D && j < D) a.Sigma[((size_t)n * 3 + c) * D * D + i * D + j] = sig[c][4 * ra + cb];
             }
+    }
 
     // the boundary classes are used as they are (one matrix-vector chain per sweep, k_sweep.hip): Sigma_0,
     // Sigma_2, the noise expectations and L0 m0 go into the block
@@ -293,6 +314,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
         if (tid < D) for (int j = 0; j < D; ++j) s += a.x0_prec[tid * D + j] * a.x0_mean[j];
         g[L.ow0 + tid] = s;
     }
+    QSTAMP(1);
     // gains of the interior class
 #pragma unroll
     for (int ra = 0; ra < 4; ++ra)
@@ -351,6 +373,7 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     }
     __syncthreads();
 
+    QSTAMP(3);
     // warm-up lengths of the segmented sweeps.  W holds F (forward recurrence matrix); the backward
     // one, B, is read back transposed (powers of B^T in the inf-norm = powers of B in the 1-norm).
     int J = warmup_length<DT>(W, P, LD, D, tid, rowp);
@@ -363,6 +386,11 @@ __global__ void __launch_bounds__(PREP_THREADS) k_prep(PrepArgs a) {
     __syncthreads();
     J = warmup_length<DT>(W, P, LD, D, tid, rowp);
     if (tid == 0) a.warm[n * 2 + 1] = J;
+#ifdef PREP64_STAMP
+    QSTAMP(4);
+    if (blockIdx.x == 100 && tid == 0)
+        printf("k_prep: moments %llu | tiles in and out %llu | three inversions %llu | gains %llu | warm-up bounds %llu\n", qs_acc[0], qs_acc[1], qs_acc[2], qs_acc[3], qs_acc[4]);
+#endif
 }
 
 template <int DT, int KT>
